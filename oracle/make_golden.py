@@ -1,0 +1,313 @@
+"""TEST INFRASTRUCTURE — generates tests/golden/* from the UNMODIFIED reference (build container only).
+
+    python -m oracle.make_golden            # rewrites every fixture
+
+The reference ships no tests or golden vectors; these fixtures are outputs of
+the reference's own modules (train/operations.py, train/seg_oprs.py, train/model_seg.py,
+search/model_search.py) run on CPU with seeded parameters (oracle/seeded.py) and are what pins both
+oracle/ref_ops.py and the HIP path.  Nothing here is imported by the product.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+from . import ref_loader
+from .seeded import seeded_input, seeded_state
+
+GOLD = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+WML = [4. / 12, 6. / 12, 8. / 12, 10. / 12, 1.]
+OPS_NAME = ["FactorizedReduce", "BasicResidual1x", "BasicResidual_downup_1x", "BasicResidual2x",
+            "BasicResidual_downup_2x"]   # search/operations.py:546
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+BIG, STEP = 30000, 5
+SHAPES = {}
+
+
+def _put(store, key, t):
+    """Arrays above BIG elements are stored as flat[::STEP] under key+'@STEP' (fixture size)."""
+    a = _np(t)
+    if a.size > BIG:
+        store["%s@%d" % (key, STEP)] = a.reshape(-1)[::STEP].copy()
+    else:
+        store[key] = a
+
+
+def _load_seeded(module, seed):
+    sd = seeded_state(module.state_dict(), seed)
+    module.load_state_dict(sd)
+    return sd
+
+
+# ------------------------------------------------------------------------------------------------
+# 1. shipped architectures: raw arch params + decoded structure
+# ------------------------------------------------------------------------------------------------
+def build_ref_net(model_seg, state, idx, lasts, training):
+    teacher = (idx == 0)
+    net = model_seg.Network_Multi_Path_Infer(
+        [state["alpha_%d_0" % idx].detach().clone(), state["alpha_%d_1" % idx].detach().clone(),
+         state["alpha_%d_2" % idx].detach().clone()],
+        [None, state["beta_%d_1" % idx].detach().clone(), state["beta_%d_2" % idx].detach().clone()],
+        [state["ratio_%d_0" % idx].detach().clone(), state["ratio_%d_1" % idx].detach().clone(),
+         state["ratio_%d_2" % idx].detach().clone()],
+        num_classes=19, layers=16, Fch=12, width_mult_list=WML,
+        stem_head_width=(1., 1.) if teacher else (8. / 12, 8. / 12), ignore_skip=teacher)
+    net.train(training)
+    net.build_structure(list(lasts))
+    return net
+
+
+def net_meta(net):
+    cells = {}
+    for key, cell in net.cells.items():
+        cells[key] = {"op": OPS_NAME.index(cell._op._op.__class__.__name__),
+                      "down": int(bool(cell._down)), "C_in": int(cell._C_in), "C_out": int(cell._C_out)}
+    return {
+        "lasts": [int(v) for v in net.lasts],
+        "ops": [[int(o) for o in ops] for ops in net.ops],
+        "paths": [[int(v) for v in p] for p in net.paths],
+        "downs": [[int(v) for v in p] for p in net.downs],
+        "widths": [[float(v) for v in p] for p in net.widths],
+        "branch_groups": [[[int(b) for b in g] for g in groups] for groups in net.branch_groups],
+        "cells": cells,
+        "ch_16": int(net.ch_16), "ch_8_2": int(net.ch_8_2), "ch_8_1": int(net.ch_8_1),
+        "state_shapes": {k: list(v.shape) for k, v in net.state_dict().items()},
+        "num_params": int(sum(p.numel() for p in net.parameters())),
+    }
+
+
+def gen_arch():
+    with ref_loader.reference("train") as wd:
+        import model_seg
+        from utils.darts_utils import objective_acc_lat
+        for idx in (0, 1):
+            state = torch.load(os.path.join(wd, "fasterseg", "arch_%d.pt" % idx), map_location="cpu",
+                               weights_only=False)
+            raw = {}
+            for k, v in state.items():
+                raw[k] = _np(v) if torch.is_tensor(v) else np.asarray(v)
+            np.savez_compressed(os.path.join(GOLD, "arch_%d.npz" % idx), **raw)
+            lat = lambda k: float(state[k])
+            meta = {"objective02": float(objective_acc_lat(float(state["mIoU02"]), lat("latency02"))),
+                    "objective12": float(objective_acc_lat(float(state["mIoU12"]), lat("latency12")))}
+            for training in (False, True):
+                for lasts in ([2, 1], [2, 0], [1], [2]):
+                    net = build_ref_net(model_seg, state, idx, lasts, training)
+                    meta["%s_%s" % ("train" if training else "eval", "".join(map(str, lasts)))] = net_meta(net)
+            with open(os.path.join(GOLD, "arch_%d.json" % idx), "w") as f:
+                json.dump(meta, f)
+            print("arch_%d: eval_21 params" % idx, meta["eval_21"]["num_params"])
+
+
+# ------------------------------------------------------------------------------------------------
+# 2. decode property cases: random arch params through network_metas (with its in-place mutation)
+# ------------------------------------------------------------------------------------------------
+def gen_decode_cases(n_cases=48):
+    out = []
+    with ref_loader.reference("train"):
+        import model_seg
+        rng = np.random.RandomState(7)
+        for case in range(n_cases):
+            layers = 16 if case % 3 else int(rng.choice([9, 12, 16]))
+            nw = 5 if case % 4 else 1
+            sharp = float(rng.choice([0.5, 2.0, 5.0]))
+            alphas = [torch.tensor(rng.randn(layers - s, 5) * sharp, dtype=torch.float32) for s in range(3)]
+            betas = [None, torch.tensor(rng.randn(layers - 2, 2) * sharp, dtype=torch.float32),
+                     torch.tensor(rng.randn(layers - 3, 2) * sharp, dtype=torch.float32)]
+            ratios = [torch.tensor(rng.randn(layers - 1, nw), dtype=torch.float32),
+                      torch.tensor(rng.randn(layers - 1, nw), dtype=torch.float32),
+                      torch.tensor(rng.randn(layers - 2, nw), dtype=torch.float32)]
+            ignore_skip = bool(case % 2)
+            rec = {"layers": layers, "ignore_skip": ignore_skip,
+                   "alphas": [a.tolist() for a in alphas], "betas": [None] + [b.tolist() for b in betas[1:]],
+                   "ratios": [r.tolist() for r in ratios]}
+            wml = WML if nw == 5 else ([1.] if ignore_skip else [4. / 12])
+            a = [t.clone() for t in alphas]
+            b = [None] + [t.clone() for t in betas[1:]]
+            metas = []
+            try:
+                for last in (0, 1, 2):    # same order + shared mutation as model_seg.py:198-200
+                    ops, path, downs, widths = model_seg.network_metas(a, b, ratios, wml, layers, last,
+                                                                       ignore_skip=ignore_skip)
+                    metas.append({"ops": [int(o) for o in ops], "path": [int(v) for v in path],
+                                  "downs": [int(v) for v in downs], "widths": [float(w) for w in widths]})
+                rec["metas"] = metas
+            except AssertionError:
+                rec["metas"] = None
+                rec["partial"] = metas
+            out.append(rec)
+    with open(os.path.join(GOLD, "decode_cases.json"), "w") as f:
+        json.dump(out, f)
+    print("decode cases:", len(out), "asserting:", sum(1 for r in out if r["metas"] is None))
+
+
+# ------------------------------------------------------------------------------------------------
+# 3. per-operator goldens (eval fwd, train fwd+bwd, slimmable)
+# ------------------------------------------------------------------------------------------------
+def _run_case(module, x, seed, training, store, name):
+    sd = _load_seeded(module, seed)
+    SHAPES[name] = {k: list(v.shape) for k, v in sd.items()}
+    module.train(training)
+    x = x.clone().requires_grad_(training)
+    y = module(x)
+    store[name + "/y"] = _np(y)
+    if training:
+        gy = seeded_input(tuple(y.shape), seed + 17)
+        (y * gy).sum().backward()
+        store[name + "/gx"] = _np(x.grad)
+        for k, p in module.named_parameters():
+            if p.grad is not None:
+                _put(store, name + "/g/" + k, p.grad)
+        after = module.state_dict()
+        for k in after:
+            if k.endswith("running_mean") or k.endswith("running_var"):
+                if not torch.equal(after[k], sd[k]):
+                    store[name + "/s/" + k] = _np(after[k])
+
+
+def gen_ops():
+    store = {}
+    index = []
+    with ref_loader.reference("train"):
+        import operations
+        import seg_oprs
+        import slimmable_ops
+        from genotypes import PRIMITIVES
+        seed = 100
+        # non-slimmable primitives
+        for kind in PRIMITIVES:
+            for stride in (1, 2):
+                for (n, cin, cout, h, w) in ((2, 16, 32, 10, 14), (1, 32, 32, 7, 14)):
+                    if stride == 2 and (h % 2 or w % 2):
+                        continue
+                    if kind == "skip" and stride == 1 and cin != cout:
+                        continue
+                    for training in (False, True):
+                        seed += 1
+                        name = "%s_s%d_n%dc%dk%dh%dw%d_%s" % (kind, stride, n, cin, cout, h, w,
+                                                                "train" if training else "eval")
+                        m = operations.OPS[kind](cin, cout, stride, False, [1.])
+                        _run_case(m, seeded_input((n, cin, h, w), seed), seed, training, store, name)
+                        index.append({"name": name, "type": "primitive", "kind": kind, "stride": stride,
+                                      "shape": [n, cin, h, w], "cout": cout, "training": training, "seed": seed,
+                                      "slimmable": False})
+        # slimmable primitives (train mode only: USBatchNorm2d has track_running_stats on the bank)
+        for kind in PRIMITIVES:
+            for stride in (1, 2):
+                for ratio in ((8. / 12, 6. / 12), (4. / 12, 1.)):
+                    seed += 1
+                    cin, cout = 48, 48 * stride
+                    m = operations.OPS[kind](cin, cout, stride, True, WML)
+                    m.set_ratio(ratio)
+                    cin_eff = slimmable_ops.make_divisible(cin * ratio[0])
+                    name = "slim_%s_s%d_r%d_%d" % (kind, stride, round(ratio[0] * 12), round(ratio[1] * 12))
+                    _run_case(m, seeded_input((2, cin_eff, 8, 12), seed), seed, True, store, name)
+                    index.append({"name": name, "type": "primitive", "kind": kind, "stride": stride,
+                                  "shape": [2, cin_eff, 8, 12], "cin_max": cin, "cout": cout, "training": True,
+                                  "seed": seed, "slimmable": True, "ratio": list(ratio)})
+        # ConvNorm / Head / FeatureFusion
+        for (k, stride, pad, cin, cout, h, w) in ((3, 2, 1, 3, 16, 16, 24), (3, 1, 1, 48, 32, 9, 12),
+                                                  (1, 1, 0, 64, 32, 6, 10), (3, 2, None, 16, 32, 12, 16)):
+            for training in (False, True):
+                seed += 1
+                name = "convnorm_k%ds%d_c%dk%dh%dw%d_%s" % (k, stride, cin, cout, h, w, "train" if training else "eval")
+                m = operations.ConvNorm(cin, cout, k, stride, pad, slimmable=False)
+                _run_case(m, seeded_input((2, cin, h, w), seed), seed, training, store, name)
+                index.append({"name": name, "type": "convnorm", "k": k, "stride": stride, "pad": pad,
+                              "shape": [2, cin, h, w], "cout": cout, "training": training, "seed": seed})
+        for (cin, h, w) in ((32, 8, 12), (320, 4, 6)):
+            for training in ((False, True) if cin <= 256 else (False,)):
+                seed += 1
+                name = "head_c%dh%dw%d_%s" % (cin, h, w, "train" if training else "eval")
+                m = seg_oprs.Head(cin, 19, True)
+                _run_case(m, seeded_input((2, cin, h, w), seed), seed, training, store, name)
+                index.append({"name": name, "type": "head", "shape": [2, cin, h, w], "training": training, "seed": seed})
+        for training in (False, True):
+            seed += 1
+            name = "ffm_c64_%s" % ("train" if training else "eval")
+            m = seg_oprs.FeatureFusion(64, 64, reduction=1, Fch=12, scale=8, branch=2)
+            _run_case(m, seeded_input((2, 64, 8, 12), seed), seed, training, store, name)
+            index.append({"name": name, "type": "ffm", "shape": [2, 64, 8, 12], "training": training, "seed": seed})
+    np.savez_compressed(os.path.join(GOLD, "ops.npz"), **store)
+    for rec in index:
+        rec["state_shapes"] = SHAPES[rec["name"]]
+    with open(os.path.join(GOLD, "ops_index.json"), "w") as f:
+        json.dump(index, f)
+    print("op cases:", len(index), "arrays:", len(store))
+
+
+# ------------------------------------------------------------------------------------------------
+# 4. whole-network goldens (BASELINE config C1 shape and a train-mode step)
+# ------------------------------------------------------------------------------------------------
+def gen_nets():
+    store = {}
+    with ref_loader.reference("train") as wd:
+        import model_seg
+        for idx, shape in ((1, (1, 3, 128, 256)), (0, (1, 3, 64, 128))):
+            state = torch.load(os.path.join(wd, "fasterseg", "arch_%d.pt" % idx), map_location="cpu",
+                               weights_only=False)
+            net = build_ref_net(model_seg, state, idx, [2, 1], False)
+            _load_seeded(net, 12345)
+            net.eval()
+            x = seeded_input(shape, 5)
+            with torch.no_grad():
+                y = net(x)
+            store["arch%d_eval/logits_sub" % idx] = _np(y[:, :, ::4, ::4])
+            store["arch%d_eval/stats" % idx] = np.array([float(y.mean()), float(y.std()), float(y.abs().max()),
+                                                         float(y.double().sum())])
+            store["arch%d_eval/argmax_sub" % idx] = _np(y.argmax(1)[:, ::2, ::2]).astype(np.uint8)
+            print("arch%d eval logits" % idx, tuple(y.shape), store["arch%d_eval/stats" % idx])
+        # student train-mode forward/backward (3 heads) at a small crop
+        state = torch.load(os.path.join(wd, "fasterseg", "arch_1.pt"), map_location="cpu", weights_only=False)
+        net = build_ref_net(model_seg, state, 1, [2, 1], True)
+        _load_seeded(net, 12345)
+        net.train()
+        x = seeded_input((2, 3, 64, 128), 6).requires_grad_(True)
+        p8, p16, p32 = net(x)
+        loss = (p8 * seeded_input(tuple(p8.shape), 7)).sum() + 0.2 * (p16 * seeded_input(tuple(p16.shape), 8)).sum() \
+            + 0.2 * (p32 * seeded_input(tuple(p32.shape), 9)).sum()
+        loss.backward()
+        store["arch1_train/p8_sub"] = _np(p8[:, :, ::4, ::4])
+        store["arch1_train/p16_sub"] = _np(p16[:, :, ::4, ::4])
+        store["arch1_train/p32_sub"] = _np(p32[:, :, ::4, ::4])
+        store["arch1_train/loss"] = np.array([float(loss)])
+        store["arch1_train/gx"] = _np(x.grad)
+        norms = {k: float(p.grad.norm()) for k, p in net.named_parameters() if p.grad is not None}
+        for k in ("stem.0.conv.0.weight", "cells.3-0._op._op.conv1.weight", "heads8.conv_1x1.weight",
+                  "heads8.conv_1x1.bias", "cells.9-0._op._op.bn2.weight", "refines32.0.conv.0.weight",
+                  "ffm.conv_1x1.bn.bias"):
+            store["arch1_train/g/" + k] = _np(dict(net.named_parameters())[k].grad)
+        with open(os.path.join(GOLD, "arch1_train_gradnorms.json"), "w") as f:
+            json.dump(norms, f)
+        print("arch1 train loss", float(loss))
+    np.savez_compressed(os.path.join(GOLD, "nets.npz"), **store)
+
+
+# ------------------------------------------------------------------------------------------------
+# 5. the shipped latency LUT (key grammar + published per-op numbers)
+# ------------------------------------------------------------------------------------------------
+def gen_lut():
+    table = np.load(os.path.join(ref_loader.REFERENCE_ROOT, "search", "latency_lookup_table.npy"),
+                    allow_pickle=True).item()
+    with open(os.path.join(GOLD, "latency_lut_1080ti.json"), "w") as f:
+        json.dump({k: float(v) for k, v in sorted(table.items())}, f)
+    print("LUT entries:", len(table))
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    which = sys.argv[1:] or ["arch", "decode", "ops", "nets", "lut"]
+    for w in which:
+        {"arch": gen_arch, "decode": gen_decode_cases, "ops": gen_ops, "nets": gen_nets, "lut": gen_lut}[w]()
+
+
+if __name__ == "__main__":
+    main()
