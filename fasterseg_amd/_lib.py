@@ -1,0 +1,88 @@
+"""ctypes binding of libfasterseg_hip.so (the C ABI declared in include/fasterseg_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a symbol is absent this module raises, and
+every operator in fasterseg_amd.* fails with it.  The library handle is process-local and loaded lazily, so modules
+stay picklable (the reference evaluator pickles the network into spawned workers, tools/engine/evaluator.py:128-157).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfasterseg_hip.so")
+
+FS_F32, FS_BF16 = 0, 1
+FS_CONV_RELU, FS_CONV_TRANSPOSED, FS_CONV_ACCUM = 1, 2, 4
+
+c_int, c_ll, c_float, c_vp = ctypes.c_int, ctypes.c_longlong, ctypes.c_float, ctypes.c_void_p
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [(n, c_int) for n in ("N", "H", "W", "Cin", "Cout", "R", "S", "stride", "pad", "Ho", "Wo",
+                                     "x_cs", "y_cs", "dtype", "flags")]
+
+
+class ResizeDesc(ctypes.Structure):
+    _fields_ = [(n, c_int) for n in ("N", "Hi", "Wi", "Ho", "Wo", "C", "x_cs", "y_cs", "dtype", "relu", "out_nchw")]
+
+
+# name -> argtypes (restype is int status unless listed in _SPECIAL); order = include/fasterseg_hip.h
+SIGNATURES = {
+    "fs_pack_weight": [c_vp, c_vp, c_ll, c_ll, c_int, c_int, c_int, c_int, c_int, c_int, c_vp],
+    "fs_unpack_weight_grad": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_ll, c_ll, c_int],
+    "fs_conv2d_fwd": [c_vp, ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "fs_conv2d_wgrad": [c_vp, ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp],
+    "fs_conv_stem_fwd": [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int],
+    "fs_bilinear_fwd": [c_vp, ctypes.POINTER(ResizeDesc), c_vp, c_vp],
+    "fs_bilinear_bwd": [c_vp, ctypes.POINTER(ResizeDesc), c_vp, c_vp, c_vp],
+    "fs_bn_finalize": [c_vp, c_int, c_ll, c_vp, c_vp, c_vp, c_float, c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "fs_affine_act": [c_vp, c_ll, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int],
+    "fs_channel_stats": [c_vp, c_ll, c_int, c_vp, c_int, c_int, c_vp],
+    "fs_bn_bwd_reduce": [c_vp, c_ll, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_vp],
+    "fs_bn_bwd_apply": [c_vp, c_ll, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_ll, c_int,
+                        c_int, c_vp, c_int],
+    "fs_nchw_to_nhwc": [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int],
+    "fs_nhwc_to_nchw": [c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_int, c_vp],
+    "fs_copy_channels": [c_vp, c_ll, c_int, c_vp, c_int, c_vp, c_int, c_int],
+    "fs_axpy_channels": [c_vp, c_ll, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int],
+    "fs_dot": [c_vp, c_ll, c_int, c_vp, c_int, c_vp, c_int, c_int, c_vp],
+}
+_SPECIAL = {
+    "fs_last_error": ([], ctypes.c_char_p),
+    "fs_version": ([], c_int),
+    "fs_packed_weight_elems": ([c_int, c_int, c_int, c_int], c_ll),
+}
+ALL_SYMBOLS = sorted(list(SIGNATURES) + list(_SPECIAL))
+
+_lib = None
+
+
+class FasterSegHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library (loads on first use; raises if it is not built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libfasterseg_hip.so is not built (%s missing): run `python -m fasterseg_amd.build` "
+                              "— there is no CPU/eager fallback" % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.argtypes = argtypes
+            fn.restype = c_int
+        for name, (argtypes, restype) in _SPECIAL.items():
+            fn = getattr(handle, name)
+            fn.argtypes = argtypes
+            fn.restype = restype
+        _lib = handle
+    return _lib
+
+
+def call(name, *args):
+    """Invoke a status-returning entry point; raise FasterSegHipError(message) on failure."""
+    status = getattr(lib(), name)(*args)
+    if status != 0:
+        msg = lib().fs_last_error()
+        raise FasterSegHipError("%s failed (status %d): %s" % (name, status, msg.decode() if msg else "?"))

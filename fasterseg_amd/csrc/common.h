@@ -1,0 +1,96 @@
+// Shared device/host helpers for libfasterseg_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/fasterseg_hip.h"
+
+namespace fs {
+
+typedef uint16_t bf16_t;   // raw bfloat16 storage
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+// ---- error reporting (thread-local, never aborts) ---------------------------------------------
+void set_error(const char* fmt, ...);
+#define FS_REQUIRE(cond, code, ...)            \
+    do {                                       \
+        if (!(cond)) {                         \
+            fs::set_error(__VA_ARGS__);        \
+            return code;                       \
+        }                                      \
+    } while (0)
+
+inline fs_status check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+        return FS_ERR_LAUNCH;
+    }
+    return FS_OK;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+inline int elem_size(int dtype) { return dtype == FS_BF16 ? 2 : 4; }
+inline int vec_elems(int dtype) { return 16 / elem_size(dtype); }
+
+// ---- bf16 <-> f32 ------------------------------------------------------------------------------
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {   // round-to-nearest-even, NaN preserved
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int VEC = 4;
+    __device__ static __forceinline__ float load(const float* p) { return *p; }
+    __device__ static __forceinline__ void store(float* p, float v) { *p = v; }
+    // unpack a 16-byte vector into VEC floats
+    __device__ static __forceinline__ void unpack(const u32x4& v, float* out) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) out[i] = __uint_as_float(v[i]);
+    }
+    __device__ static __forceinline__ u32x4 pack(const float* in) {
+        u32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = __float_as_uint(in[i]);
+        return v;
+    }
+};
+template <> struct Elem<bf16_t> {
+    static constexpr int VEC = 8;
+    __device__ static __forceinline__ float load(const bf16_t* p) { return bf16_to_f32(*p); }
+    __device__ static __forceinline__ void store(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+    __device__ static __forceinline__ void unpack(const u32x4& v, float* out) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            out[2 * i] = __uint_as_float(v[i] << 16);
+            out[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
+        }
+    }
+    __device__ static __forceinline__ u32x4 pack(const float* in) {
+        u32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            v[i] = (uint32_t)f32_to_bf16(in[2 * i]) | ((uint32_t)f32_to_bf16(in[2 * i + 1]) << 16);
+        return v;
+    }
+};
+
+__device__ __forceinline__ u32x4 ldg16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
+__device__ __forceinline__ void stg16(void* p, const u32x4& v) { *reinterpret_cast<u32x4*>(p) = v; }
+
+// wave64 all-lane sum
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+}  // namespace fs

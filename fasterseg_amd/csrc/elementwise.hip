@@ -1,0 +1,468 @@
+// HBM-bound helpers around the convolutions: filter packing, layout changes, channel-slice copies,
+// scale-accumulate, per-channel reductions and the train-mode BatchNorm passes.  All NHWC, 16-byte vector
+// accesses (VEC = 4 fp32 / 8 bf16 channels per lane), grid-stride, wave64 reductions.
+//
+// Replaces (reference call sites): nn.BatchNorm2d train fwd/bwd (operations.py:39,80; slimmable_ops.py:58-70),
+// nn.ReLU (operations.py:74,147), torch.cat (operations.py:523; model_seg.py:307-331),
+// `result + op(x)*w*r0*r1` and beta-weighted sums (model_search.py:76-78,330-333).
+#include "common.h"
+
+namespace fs {
+
+static inline int grid_for(long long work, int block = 256, int cap = 8192) {
+    long long g = (work + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// filter packing
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void pack_weight_kernel(const float* __restrict__ w, long long o_stride, long long i_stride, int Cout, int Cin,
+                                   int R, int S, int tflip, T* __restrict__ out) {
+    const long long total = (long long)Cout * Cin * R * S;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        long long t = idx;
+        float v;
+        if (!tflip) {   // out[co][r][s][ci]
+            const int ci = (int)(t % Cin); t /= Cin;
+            const int s = (int)(t % S); t /= S;
+            const int r = (int)(t % R); t /= R;
+            const int co = (int)t;
+            v = w[co * o_stride + ci * i_stride + r * S + s];
+        } else {        // out[ci][R-1-r][S-1-s][co] = w[co][ci][r][s]
+            const int co = (int)(t % Cout); t /= Cout;
+            const int s2 = (int)(t % S); t /= S;
+            const int r2 = (int)(t % R); t /= R;
+            const int ci = (int)t;
+            v = w[co * o_stride + ci * i_stride + (R - 1 - r2) * S + (S - 1 - s2)];
+        }
+        Elem<T>::store(out + idx, v);
+    }
+}
+
+__global__ void unpack_wgrad_kernel(const float* __restrict__ dw, int Cout, int Cin, int R, int S, float* __restrict__ out,
+                                    long long o_stride, long long i_stride, int accumulate) {
+    const long long total = (long long)Cout * Cin * R * S;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        long long t = idx;
+        const int ci = (int)(t % Cin); t /= Cin;
+        const int s = (int)(t % S); t /= S;
+        const int r = (int)(t % R); t /= R;
+        const int co = (int)t;
+        float* dst = out + co * o_stride + ci * i_stride + r * S + s;
+        const float v = dw[idx];
+        *dst = accumulate ? (*dst + v) : v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// NCHW fp32 <-> NHWC (T): 64 pixels x 32 channels through an LDS tile, both sides coalesced
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(int C, int HW, const float* __restrict__ x, T* __restrict__ y,
+                                                           int y_cs, int c_pad) {
+    __shared__ float tile[32][65];
+    const int n = blockIdx.y;
+    const int p0 = blockIdx.x * 64;
+    const int tid = threadIdx.x;
+    for (int c0 = 0; c0 < c_pad; c0 += 32) {
+        for (int k = tid; k < 32 * 64; k += 256) {
+            const int c = k >> 6, pp = k & 63;
+            float v = 0.f;
+            if (c0 + c < C && p0 + pp < HW) v = x[((long long)n * C + c0 + c) * HW + p0 + pp];
+            tile[c][pp] = v;
+        }
+        __syncthreads();
+        for (int k = tid; k < 32 * 64; k += 256) {
+            const int pp = k >> 5, c = k & 31;
+            if (c0 + c < c_pad && p0 + pp < HW) Elem<T>::store(y + ((long long)n * HW + p0 + pp) * y_cs + c0 + c, tile[c][pp]);
+        }
+        __syncthreads();
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(int C, int HW, const T* __restrict__ x, int x_cs,
+                                                           float* __restrict__ y) {
+    __shared__ float tile[32][65];
+    const int n = blockIdx.y;
+    const int p0 = blockIdx.x * 64;
+    const int tid = threadIdx.x;
+    for (int c0 = 0; c0 < C; c0 += 32) {
+        for (int k = tid; k < 32 * 64; k += 256) {
+            const int pp = k >> 5, c = k & 31;
+            float v = 0.f;
+            if (c0 + c < C && p0 + pp < HW) v = Elem<T>::load(x + ((long long)n * HW + p0 + pp) * x_cs + c0 + c);
+            tile[c][pp] = v;
+        }
+        __syncthreads();
+        for (int k = tid; k < 32 * 64; k += 256) {
+            const int c = k >> 6, pp = k & 63;
+            if (c0 + c < C && p0 + pp < HW) y[((long long)n * C + c0 + c) * HW + p0 + pp] = tile[c][pp];
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// vector elementwise family: one lane = one 16-byte vector of one pixel
+// ---------------------------------------------------------------------------------------------------
+enum { EW_COPY = 0, EW_AFFINE = 1, EW_AXPY = 2, EW_AXPY_ACC = 3 };
+
+template <typename T, int OP>
+__global__ void ew_kernel(long long pixels, int cv, const T* __restrict__ x, int x_cs, T* __restrict__ y, int y_cs,
+                          const float* __restrict__ scale, const float* __restrict__ shift, int relu) {
+    constexpr int VEC = Elem<T>::VEC;
+    const long long total = pixels * cv;
+    float alpha = 1.f;
+    if (OP == EW_AXPY || OP == EW_AXPY_ACC) alpha = scale[0];
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const long long pix = idx / cv;
+        const int c = (int)(idx - pix * cv) * VEC;
+        u32x4 v = ldg16(x + pix * x_cs + c);
+        if (OP == EW_COPY) {
+            stg16(y + pix * y_cs + c, v);
+        } else {
+            float f[VEC];
+            Elem<T>::unpack(v, f);
+            if (OP == EW_AFFINE) {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    float o = f[i] * scale[c + i] + shift[c + i];
+                    f[i] = relu ? fmaxf(o, 0.f) : o;
+                }
+            } else if (OP == EW_AXPY) {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) f[i] *= alpha;
+            } else {
+                float g[VEC];
+                Elem<T>::unpack(ldg16(y + pix * y_cs + c), g);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) f[i] = g[i] + alpha * f[i];
+            }
+            stg16(y + pix * y_cs + c, Elem<T>::pack(f));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// per-channel reductions over pixels.  Thread t owns vector column (t % cv) and pixel rows t/cv + k*rpb.
+// MODE 0: stats  -> out[c] += sum x, out[C+c] += sum x^2
+// MODE 1: bn bwd -> out[c] += sum dz, out[C+c] += sum dz*xhat   (dz = dy * [y>0])
+// ---------------------------------------------------------------------------------------------------
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void chan_reduce_kernel(long long pixels, int C, const T* __restrict__ x, int x_cs,
+                                                          const T* __restrict__ dy, int dy_cs, const T* __restrict__ yo,
+                                                          int y_cs, const float* __restrict__ mean,
+                                                          const float* __restrict__ invstd, int relu,
+                                                          float* __restrict__ out, long long pix_per_block) {
+    constexpr int VEC = Elem<T>::VEC;
+    __shared__ float red[2][256][VEC + 1];
+    const int cv = C / VEC;
+    const int rpb = 256 / cv;            // pixel rows processed per iteration
+    const int tid = threadIdx.x;
+    const int col = tid % cv;
+    const int row = tid / cv;
+    const bool active = row < rpb;
+    float a0[VEC], a1[VEC], mu[VEC], is[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        a0[i] = 0.f; a1[i] = 0.f; mu[i] = 0.f; is[i] = 1.f;
+        if (MODE == 1) { mu[i] = mean[col * VEC + i]; is[i] = invstd[col * VEC + i]; }
+    }
+    const long long p_begin = blockIdx.x * pix_per_block;
+    long long p_end = p_begin + pix_per_block;
+    if (p_end > pixels) p_end = pixels;
+    if (active) {
+        for (long long pix = p_begin + row; pix < p_end; pix += rpb) {
+            float f[VEC];
+            Elem<T>::unpack(ldg16(x + pix * x_cs + col * VEC), f);
+            if (MODE == 0) {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) { a0[i] += f[i]; a1[i] += f[i] * f[i]; }
+            } else {
+                float g[VEC];
+                Elem<T>::unpack(ldg16(dy + pix * dy_cs + col * VEC), g);
+                if (relu) {
+                    float o[VEC];
+                    Elem<T>::unpack(ldg16(yo + pix * y_cs + col * VEC), o);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) g[i] = o[i] > 0.f ? g[i] : 0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) { a0[i] += g[i]; a1[i] += g[i] * (f[i] - mu[i]) * is[i]; }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { red[0][tid][i] = a0[i]; red[1][tid][i] = a1[i]; }
+    __syncthreads();
+    // column sums: thread t < cv*VEC*2 reduces one (which, channel)
+    for (int k = tid; k < 2 * C; k += 256) {
+        const int which = k / C, c = k - which * C;
+        const int cc = c / VEC, ci = c - cc * VEC;
+        float s = 0.f;
+        for (int r = 0; r < rpb; ++r) s += red[which][r * cv + cc][ci];
+        atomicAdd(out + which * C + c, s);
+    }
+}
+
+template <typename T>
+__global__ void bn_bwd_apply_kernel(long long pixels, int cv, const T* __restrict__ x, int x_cs, const T* __restrict__ dy,
+                                    int dy_cs, const T* __restrict__ yo, int y_cs, const float* __restrict__ mean,
+                                    const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                    const float* __restrict__ red, float inv_count, int relu, T* __restrict__ dx,
+                                    int dx_cs) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int C = cv * VEC;
+    const long long total = pixels * cv;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const long long pix = idx / cv;
+        const int c = (int)(idx - pix * cv) * VEC;
+        float f[VEC], g[VEC];
+        Elem<T>::unpack(ldg16(x + pix * x_cs + c), f);
+        Elem<T>::unpack(ldg16(dy + pix * dy_cs + c), g);
+        if (relu) {
+            float o[VEC];
+            Elem<T>::unpack(ldg16(yo + pix * y_cs + c), o);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) g[i] = o[i] > 0.f ? g[i] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            const float is = invstd[c + i];
+            const float xh = (f[i] - mean[c + i]) * is;
+            f[i] = gamma[c + i] * is * (g[i] - red[c + i] * inv_count - xh * red[C + c + i] * inv_count);
+        }
+        stg16(dx + pix * dx_cs + c, Elem<T>::pack(f));
+    }
+}
+
+__global__ void bn_finalize_kernel(int C, float count, const float* __restrict__ stats, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float eps, float momentum, float* running_mean,
+                                   float* running_var, float* mean, float* invstd, float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float m = stats[c] / count;
+    float var = stats[C + c] / count - m * m;
+    var = fmaxf(var, 0.f);
+    const float is = 1.0f / sqrtf(var + eps);
+    if (mean) mean[c] = m;
+    if (invstd) invstd[c] = is;
+    const float g = gamma ? gamma[c] : 1.f;
+    const float b = beta ? beta[c] : 0.f;
+    if (scale) scale[c] = g * is;
+    if (shift) shift[c] = b - m * g * is;
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+    if (running_var) {
+        const float unbiased = count > 1.f ? var * (count / (count - 1.f)) : var;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dot_kernel(long long pixels, int cv, const T* __restrict__ x, int x_cs,
+                                                  const T* __restrict__ y, int y_cs, float* __restrict__ out) {
+    constexpr int VEC = Elem<T>::VEC;
+    __shared__ float part[4];
+    const long long total = pixels * cv;
+    float acc = 0.f;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const long long pix = idx / cv;
+        const int c = (int)(idx - pix * cv) * VEC;
+        float f[VEC], g[VEC];
+        Elem<T>::unpack(ldg16(x + pix * x_cs + c), f);
+        Elem<T>::unpack(ldg16(y + pix * y_cs + c), g);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc += f[i] * g[i];
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+}
+
+static fs_status check_slice(const char* fn, const void* p, int cs, int C, int dtype) {
+    const int vec = vec_elems(dtype);
+    FS_REQUIRE(p != nullptr, FS_ERR_INVALID, "%s: null pointer", fn);
+    FS_REQUIRE(aligned16(p), FS_ERR_INVALID, "%s: operand not 16-byte aligned", fn);
+    FS_REQUIRE(C > 0 && C % vec == 0, FS_ERR_UNSUPPORTED, "%s: C=%d must be a positive multiple of %d", fn, C, vec);
+    FS_REQUIRE(cs >= C && cs % vec == 0, FS_ERR_INVALID, "%s: channel stride %d invalid for C=%d", fn, cs, C);
+    return FS_OK;
+}
+
+}  // namespace fs
+
+using namespace fs;
+
+#define DT_DISPATCH(dtype, ...)                         \
+    if ((dtype) == FS_F32) { typedef float T; __VA_ARGS__ } \
+    else { typedef bf16_t T; __VA_ARGS__ }
+
+extern "C" long long fs_packed_weight_elems(int Cout, int R, int S, int Cin) { return (long long)Cout * R * S * Cin; }
+
+extern "C" fs_status fs_pack_weight(void* stream, const float* w, long long o_stride, long long i_stride, int Cout, int Cin,
+                                    int R, int S, int dtype, int tflip, void* out) {
+    FS_REQUIRE(w && out, FS_ERR_INVALID, "fs_pack_weight: null pointer");
+    FS_REQUIRE(Cout > 0 && Cin > 0 && R > 0 && S > 0, FS_ERR_INVALID, "fs_pack_weight: bad shape");
+    FS_REQUIRE(dtype == FS_F32 || dtype == FS_BF16, FS_ERR_INVALID, "fs_pack_weight: bad dtype");
+    const long long total = (long long)Cout * Cin * R * S;
+    DT_DISPATCH(dtype, hipLaunchKernelGGL((pack_weight_kernel<T>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, w,
+                                          o_stride, i_stride, Cout, Cin, R, S, tflip, (T*)out);)
+    return check_launch("fs_pack_weight");
+}
+
+extern "C" fs_status fs_unpack_weight_grad(void* stream, const float* dw, int Cout, int Cin, int R, int S, float* out,
+                                           long long o_stride, long long i_stride, int accumulate) {
+    FS_REQUIRE(dw && out, FS_ERR_INVALID, "fs_unpack_weight_grad: null pointer");
+    const long long total = (long long)Cout * Cin * R * S;
+    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dw, Cout, Cin, R, S, out,
+                       o_stride, i_stride, accumulate);
+    return check_launch("fs_unpack_weight_grad");
+}
+
+extern "C" fs_status fs_nchw_to_nhwc(void* stream, int N, int C, int H, int W, const float* x, void* y, int y_cs, int c_pad,
+                                     int dtype) {
+    FS_REQUIRE(x && y && N > 0 && C > 0 && H > 0 && W > 0, FS_ERR_INVALID, "fs_nchw_to_nhwc: bad argument");
+    FS_REQUIRE(c_pad >= C && y_cs >= c_pad, FS_ERR_INVALID, "fs_nchw_to_nhwc: need C <= c_pad <= y_cs");
+    dim3 grid((H * W + 63) / 64, N);
+    DT_DISPATCH(dtype, hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, C, H * W, x, (T*)y,
+                                          y_cs, c_pad);)
+    return check_launch("fs_nchw_to_nhwc");
+}
+
+extern "C" fs_status fs_nhwc_to_nchw(void* stream, int N, int C, int H, int W, const void* x, int x_cs, int dtype, float* y) {
+    FS_REQUIRE(x && y && N > 0 && C > 0 && H > 0 && W > 0 && x_cs >= C, FS_ERR_INVALID, "fs_nhwc_to_nchw: bad argument");
+    dim3 grid((H * W + 63) / 64, N);
+    DT_DISPATCH(dtype, hipLaunchKernelGGL((nhwc_to_nchw_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, C, H * W,
+                                          (const T*)x, x_cs, y);)
+    return check_launch("fs_nhwc_to_nchw");
+}
+
+extern "C" fs_status fs_copy_channels(void* stream, long long pixels, int C, const void* x, int x_cs, void* y, int y_cs,
+                                      int dtype) {
+    fs_status s;
+    if ((s = check_slice("fs_copy_channels", x, x_cs, C, dtype)) != FS_OK) return s;
+    if ((s = check_slice("fs_copy_channels", y, y_cs, C, dtype)) != FS_OK) return s;
+    const int cv = C / vec_elems(dtype);
+    DT_DISPATCH(dtype, hipLaunchKernelGGL((ew_kernel<T, EW_COPY>), dim3(grid_for(pixels * cv)), dim3(256), 0, (hipStream_t)stream,
+                                          pixels, cv, (const T*)x, x_cs, (T*)y, y_cs, nullptr, nullptr, 0);)
+    return check_launch("fs_copy_channels");
+}
+
+extern "C" fs_status fs_affine_act(void* stream, long long pixels, int C, const void* x, int x_cs, const float* scale,
+                                   const float* shift, void* y, int y_cs, int dtype, int relu) {
+    fs_status s;
+    if ((s = check_slice("fs_affine_act", x, x_cs, C, dtype)) != FS_OK) return s;
+    if ((s = check_slice("fs_affine_act", y, y_cs, C, dtype)) != FS_OK) return s;
+    FS_REQUIRE(scale && shift, FS_ERR_INVALID, "fs_affine_act: null scale/shift");
+    const int cv = C / vec_elems(dtype);
+    DT_DISPATCH(dtype, hipLaunchKernelGGL((ew_kernel<T, EW_AFFINE>), dim3(grid_for(pixels * cv)), dim3(256), 0,
+                                          (hipStream_t)stream, pixels, cv, (const T*)x, x_cs, (T*)y, y_cs, scale, shift, relu);)
+    return check_launch("fs_affine_act");
+}
+
+extern "C" fs_status fs_axpy_channels(void* stream, long long pixels, int C, const void* x, int x_cs, const float* alpha,
+                                      void* y, int y_cs, int dtype, int accumulate) {
+    fs_status s;
+    if ((s = check_slice("fs_axpy_channels", x, x_cs, C, dtype)) != FS_OK) return s;
+    if ((s = check_slice("fs_axpy_channels", y, y_cs, C, dtype)) != FS_OK) return s;
+    FS_REQUIRE(alpha, FS_ERR_INVALID, "fs_axpy_channels: null alpha");
+    const int cv = C / vec_elems(dtype);
+    if (accumulate) {
+        DT_DISPATCH(dtype, hipLaunchKernelGGL((ew_kernel<T, EW_AXPY_ACC>), dim3(grid_for(pixels * cv)), dim3(256), 0,
+                                              (hipStream_t)stream, pixels, cv, (const T*)x, x_cs, (T*)y, y_cs, alpha, nullptr, 0);)
+    } else {
+        DT_DISPATCH(dtype, hipLaunchKernelGGL((ew_kernel<T, EW_AXPY>), dim3(grid_for(pixels * cv)), dim3(256), 0,
+                                              (hipStream_t)stream, pixels, cv, (const T*)x, x_cs, (T*)y, y_cs, alpha, nullptr, 0);)
+    }
+    return check_launch("fs_axpy_channels");
+}
+
+static int reduce_blocks(long long pixels, int rpb, long long* ppb) {
+    long long iters = (pixels + rpb - 1) / rpb;
+    long long blocks = (iters + 15) / 16;        // >= 16 iterations per block
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    long long per = (pixels + blocks - 1) / blocks;
+    per = (per + rpb - 1) / rpb * rpb;
+    *ppb = per;
+    return (int)((pixels + per - 1) / per);
+}
+
+extern "C" fs_status fs_channel_stats(void* stream, long long pixels, int C, const void* x, int x_cs, int dtype, float* stats) {
+    fs_status s;
+    if ((s = check_slice("fs_channel_stats", x, x_cs, C, dtype)) != FS_OK) return s;
+    FS_REQUIRE(stats, FS_ERR_INVALID, "fs_channel_stats: null stats");
+    const int cv = C / vec_elems(dtype);
+    FS_REQUIRE(cv <= 256, FS_ERR_UNSUPPORTED, "fs_channel_stats: C=%d too large", C);
+    long long ppb;
+    const int blocks = reduce_blocks(pixels, 256 / cv, &ppb);
+    DT_DISPATCH(dtype, hipLaunchKernelGGL((chan_reduce_kernel<T, 0>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, pixels, C,
+                                          (const T*)x, x_cs, (const T*)nullptr, 0, (const T*)nullptr, 0, nullptr, nullptr, 0,
+                                          stats, ppb);)
+    return check_launch("fs_channel_stats");
+}
+
+extern "C" fs_status fs_bn_finalize(void* stream, int C, long long count, const float* stats, const float* gamma,
+                                    const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                                    float* mean, float* invstd, float* scale, float* shift) {
+    FS_REQUIRE(stats && C > 0 && count > 0, FS_ERR_INVALID, "fs_bn_finalize: bad argument");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, C, (float)count, stats, gamma,
+                       beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
+    return check_launch("fs_bn_finalize");
+}
+
+extern "C" fs_status fs_bn_bwd_reduce(void* stream, long long pixels, int C, const void* x, int x_cs, const void* dy, int dy_cs,
+                                      const void* y_out, int y_cs, const float* mean, const float* invstd, int dtype, int relu,
+                                      float* red) {
+    fs_status s;
+    if ((s = check_slice("fs_bn_bwd_reduce", x, x_cs, C, dtype)) != FS_OK) return s;
+    if ((s = check_slice("fs_bn_bwd_reduce", dy, dy_cs, C, dtype)) != FS_OK) return s;
+    if (relu && (s = check_slice("fs_bn_bwd_reduce", y_out, y_cs, C, dtype)) != FS_OK) return s;
+    FS_REQUIRE(mean && invstd && red, FS_ERR_INVALID, "fs_bn_bwd_reduce: null pointer");
+    const int cv = C / vec_elems(dtype);
+    FS_REQUIRE(cv <= 256, FS_ERR_UNSUPPORTED, "fs_bn_bwd_reduce: C=%d too large", C);
+    long long ppb;
+    const int blocks = reduce_blocks(pixels, 256 / cv, &ppb);
+    DT_DISPATCH(dtype, hipLaunchKernelGGL((chan_reduce_kernel<T, 1>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, pixels, C,
+                                          (const T*)x, x_cs, (const T*)dy, dy_cs, (const T*)y_out, y_cs, mean, invstd, relu, red,
+                                          ppb);)
+    return check_launch("fs_bn_bwd_reduce");
+}
+
+extern "C" fs_status fs_bn_bwd_apply(void* stream, long long pixels, int C, const void* x, int x_cs, const void* dy, int dy_cs,
+                                     const void* y_out, int y_cs, const float* mean, const float* invstd, const float* gamma,
+                                     const float* red, long long count, int dtype, int relu, void* dx, int dx_cs) {
+    fs_status s;
+    if ((s = check_slice("fs_bn_bwd_apply", x, x_cs, C, dtype)) != FS_OK) return s;
+    if ((s = check_slice("fs_bn_bwd_apply", dy, dy_cs, C, dtype)) != FS_OK) return s;
+    if ((s = check_slice("fs_bn_bwd_apply", dx, dx_cs, C, dtype)) != FS_OK) return s;
+    if (relu && (s = check_slice("fs_bn_bwd_apply", y_out, y_cs, C, dtype)) != FS_OK) return s;
+    FS_REQUIRE(mean && invstd && gamma && red && count > 0, FS_ERR_INVALID, "fs_bn_bwd_apply: bad argument");
+    const int cv = C / vec_elems(dtype);
+    DT_DISPATCH(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(grid_for(pixels * cv)), dim3(256), 0, (hipStream_t)stream,
+                                          pixels, cv, (const T*)x, x_cs, (const T*)dy, dy_cs, (const T*)y_out, y_cs, mean, invstd,
+                                          gamma, red, 1.0f / (float)count, relu, (T*)dx, dx_cs);)
+    return check_launch("fs_bn_bwd_apply");
+}
+
+extern "C" fs_status fs_dot(void* stream, long long pixels, int C, const void* x, int x_cs, const void* y, int y_cs, int dtype,
+                            float* out) {
+    fs_status s;
+    if ((s = check_slice("fs_dot", x, x_cs, C, dtype)) != FS_OK) return s;
+    if ((s = check_slice("fs_dot", y, y_cs, C, dtype)) != FS_OK) return s;
+    FS_REQUIRE(out, FS_ERR_INVALID, "fs_dot: null out");
+    const int cv = C / vec_elems(dtype);
+    DT_DISPATCH(dtype, hipLaunchKernelGGL((dot_kernel<T>), dim3(grid_for(pixels * cv, 256, 1024)), dim3(256), 0,
+                                          (hipStream_t)stream, pixels, cv, (const T*)x, x_cs, (const T*)y, y_cs, out);)
+    return check_launch("fs_dot");
+}

@@ -1,0 +1,322 @@
+// Bilinear resampling with align_corners=True, NHWC, forward and backward (HBM-bound, 16-byte vectors).
+//
+// Replaces F.interpolate(mode='bilinear', align_corners=True) at reference search/operations.py:271,275,437,444,
+// train/model_seg.py:305,310,317,359-365, search/model_search.py:339-357 (ATen upsample_bilinear2d fwd/bwd).
+// Index arithmetic follows ATen exactly: scale = (in-1)/(out-1) in fp32 (0 when out==1), src = scale*dst,
+// i0 = (int)src, i1 = i0 + (i0 < in-1), l1 = src - i0, l0 = 1 - l1.
+// Fusions: optional ReLU after the interpolation (the "zoomed conv" ops apply ReLU after the up-sample,
+// operations.py:275-276), the store into a channel slice of a wider buffer (torch.cat, model_seg.py:307), and
+// the final logits written straight to a contiguous NCHW tensor (model_seg.py:365).
+// The backward is a gather over the output pixels that touch each input pixel: no atomics, deterministic.
+#include "common.h"
+
+namespace fs {
+
+struct Tap {
+    int i0, i1;
+    float l0, l1;
+};
+__device__ __forceinline__ Tap make_tap(float scale, int dst, int in_size) {
+    Tap t;
+    const float src = scale * (float)dst;
+    t.i0 = (int)src;
+    t.i1 = t.i0 + ((t.i0 < in_size - 1) ? 1 : 0);
+    t.l1 = src - (float)t.i0;
+    t.l0 = 1.f - t.l1;
+    return t;
+}
+static inline float host_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
+
+template <typename T>
+__global__ void bilinear_fwd_kernel(int N, int Hi, int Wi, int Ho, int Wo, int cv, float rh, float rw,
+                                    const T* __restrict__ x, int x_cs, T* __restrict__ y, int y_cs, int relu) {
+    constexpr int VEC = Elem<T>::VEC;
+    const long long total = (long long)N * Ho * Wo * cv;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        long long t = idx;
+        const int c = (int)(t % cv) * VEC; t /= cv;
+        const int ow = (int)(t % Wo); t /= Wo;
+        const int oh = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        const Tap th = make_tap(rh, oh, Hi), tw = make_tap(rw, ow, Wi);
+        const T* base = x + (long long)n * Hi * Wi * x_cs + c;
+        float p00[VEC], p01[VEC], p10[VEC], p11[VEC];
+        Elem<T>::unpack(ldg16(base + ((long long)th.i0 * Wi + tw.i0) * x_cs), p00);
+        Elem<T>::unpack(ldg16(base + ((long long)th.i0 * Wi + tw.i1) * x_cs), p01);
+        Elem<T>::unpack(ldg16(base + ((long long)th.i1 * Wi + tw.i0) * x_cs), p10);
+        Elem<T>::unpack(ldg16(base + ((long long)th.i1 * Wi + tw.i1) * x_cs), p11);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            float o = th.l0 * (tw.l0 * p00[i] + tw.l1 * p01[i]) + th.l1 * (tw.l0 * p10[i] + tw.l1 * p11[i]);
+            p00[i] = relu ? fmaxf(o, 0.f) : o;
+        }
+        stg16(y + (((long long)n * Ho + oh) * Wo + ow) * y_cs + c, Elem<T>::pack(p00));
+    }
+}
+
+// NHWC (channel stride padded to a multiple of 4, pad lanes readable) -> NCHW.  One lane: 4 consecutive ow, 4 channels.
+template <typename T, typename TO>
+__global__ void bilinear_fwd_nchw_kernel(int N, int Hi, int Wi, int Ho, int Wo, int C, float rh, float rw,
+                                         const T* __restrict__ x, int x_cs, TO* __restrict__ y) {
+    const int wq = Wo >> 2;
+    const int cg = (C + 3) >> 2;
+    const long long total = (long long)N * cg * Ho * wq;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        long long t = idx;
+        const int ow0 = (int)(t % wq) * 4; t /= wq;
+        const int oh = (int)(t % Ho); t /= Ho;
+        const int c0 = (int)(t % cg) * 4;
+        const int n = (int)(t / cg);
+        const Tap th = make_tap(rh, oh, Hi);
+        const T* r0 = x + ((long long)n * Hi + th.i0) * Wi * x_cs + c0;
+        const T* r1 = x + ((long long)n * Hi + th.i1) * Wi * x_cs + c0;
+        float out[4][4];   // [channel][q]
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const Tap tw = make_tap(rw, ow0 + q, Wi);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float p00 = Elem<T>::load(r0 + (long long)tw.i0 * x_cs + k);
+                const float p01 = Elem<T>::load(r0 + (long long)tw.i1 * x_cs + k);
+                const float p10 = Elem<T>::load(r1 + (long long)tw.i0 * x_cs + k);
+                const float p11 = Elem<T>::load(r1 + (long long)tw.i1 * x_cs + k);
+                out[k][q] = th.l0 * (tw.l0 * p00 + tw.l1 * p01) + th.l1 * (tw.l0 * p10 + tw.l1 * p11);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (c0 + k < C) {
+                TO* dst = y + (((long long)n * C + c0 + k) * Ho + oh) * Wo + ow0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Elem<TO>::store(dst + q, out[k][q]);
+            }
+        }
+    }
+}
+
+// generic scalar NCHW writer for Wo % 4 != 0
+template <typename T, typename TO>
+__global__ void bilinear_fwd_nchw_scalar_kernel(int N, int Hi, int Wi, int Ho, int Wo, int C, float rh, float rw,
+                                                const T* __restrict__ x, int x_cs, TO* __restrict__ y) {
+    const long long total = (long long)N * C * Ho * Wo;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        long long t = idx;
+        const int ow = (int)(t % Wo); t /= Wo;
+        const int oh = (int)(t % Ho); t /= Ho;
+        const int c = (int)(t % C);
+        const int n = (int)(t / C);
+        const Tap th = make_tap(rh, oh, Hi), tw = make_tap(rw, ow, Wi);
+        const T* b = x + (long long)n * Hi * Wi * x_cs + c;
+        const float p00 = Elem<T>::load(b + ((long long)th.i0 * Wi + tw.i0) * x_cs);
+        const float p01 = Elem<T>::load(b + ((long long)th.i0 * Wi + tw.i1) * x_cs);
+        const float p10 = Elem<T>::load(b + ((long long)th.i1 * Wi + tw.i0) * x_cs);
+        const float p11 = Elem<T>::load(b + ((long long)th.i1 * Wi + tw.i1) * x_cs);
+        Elem<TO>::store(y + idx, th.l0 * (tw.l0 * p00 + tw.l1 * p01) + th.l1 * (tw.l0 * p10 + tw.l1 * p11));
+    }
+}
+
+// candidate output range [lo, hi] whose taps may touch input index i (widened by one on both sides; the exact
+// membership test re-evaluates make_tap, so attribution is identical to the forward).
+__device__ __forceinline__ void cand_range(float scale, int i, int out_size, int& lo, int& hi) {
+    if (scale <= 0.f) {
+        lo = 0;
+        hi = out_size - 1;
+        return;
+    }
+    const float inv = 1.f / scale;
+    lo = (int)floorf((float)(i - 1) * inv) - 1;
+    hi = (int)ceilf((float)(i + 1) * inv) + 1;
+    if (lo < 0) lo = 0;
+    if (hi > out_size - 1) hi = out_size - 1;
+}
+__device__ __forceinline__ float tap_weight(const Tap& t, int i) {
+    float w = 0.f;
+    if (t.i0 == i) w += t.l0;
+    if (t.i1 == i) w += t.l1;
+    return w;
+}
+
+// DYL: 0 = dy NHWC (T, vectors), 1 = dy NCHW (TO scalar planes)
+template <typename T>
+__global__ void bilinear_bwd_kernel(int N, int Hi, int Wi, int Ho, int Wo, int cv, float rh, float rw,
+                                    const T* __restrict__ dy, int dy_cs, const T* __restrict__ yo, int yo_cs, int relu,
+                                    T* __restrict__ dx, int dx_cs) {
+    constexpr int VEC = Elem<T>::VEC;
+    const long long total = (long long)N * Hi * Wi * cv;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        long long t = idx;
+        const int c = (int)(t % cv) * VEC; t /= cv;
+        const int iw = (int)(t % Wi); t /= Wi;
+        const int ih = (int)(t % Hi);
+        const int n = (int)(t / Hi);
+        int hlo, hhi, wlo, whi;
+        cand_range(rh, ih, Ho, hlo, hhi);
+        cand_range(rw, iw, Wo, wlo, whi);
+        float acc[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+        for (int oh = hlo; oh <= hhi; ++oh) {
+            const float wh = tap_weight(make_tap(rh, oh, Hi), ih);
+            if (wh == 0.f) continue;
+            for (int ow = wlo; ow <= whi; ++ow) {
+                const float ww = tap_weight(make_tap(rw, ow, Wi), iw);
+                if (ww == 0.f) continue;
+                const long long opix = ((long long)n * Ho + oh) * Wo + ow;
+                float g[VEC];
+                Elem<T>::unpack(ldg16(dy + opix * dy_cs + c), g);
+                if (relu) {
+                    float o[VEC];
+                    Elem<T>::unpack(ldg16(yo + opix * yo_cs + c), o);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) g[i] = o[i] > 0.f ? g[i] : 0.f;
+                }
+                const float w = wh * ww;
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) acc[i] += w * g[i];
+            }
+        }
+        stg16(dx + (((long long)n * Hi + ih) * Wi + iw) * dx_cs + c, Elem<T>::pack(acc));
+    }
+}
+
+// backward of the NCHW logits up-sample: dy is NCHW fp32, dx is NHWC T; one lane per (input pixel, channel)
+template <typename T>
+__global__ void bilinear_bwd_nchw_kernel(int N, int Hi, int Wi, int Ho, int Wo, int C, float rh, float rw,
+                                         const float* __restrict__ dy, T* __restrict__ dx, int dx_cs) {
+    const long long total = (long long)N * Hi * Wi * C;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        long long t = idx;
+        const int iw = (int)(t % Wi); t /= Wi;      // iw fastest: neighbouring lanes read neighbouring dy columns
+        const int ih = (int)(t % Hi); t /= Hi;
+        const int c = (int)(t % C);
+        const int n = (int)(t / C);
+        int hlo, hhi, wlo, whi;
+        cand_range(rh, ih, Ho, hlo, hhi);
+        cand_range(rw, iw, Wo, wlo, whi);
+        const float* plane = dy + ((long long)n * C + c) * Ho * Wo;
+        float acc = 0.f;
+        for (int oh = hlo; oh <= hhi; ++oh) {
+            const float wh = tap_weight(make_tap(rh, oh, Hi), ih);
+            if (wh == 0.f) continue;
+            float row = 0.f;
+            for (int ow = wlo; ow <= whi; ++ow) {
+                const float ww = tap_weight(make_tap(rw, ow, Wi), iw);
+                row += ww * plane[(long long)oh * Wo + ow];
+            }
+            acc += wh * row;
+        }
+        Elem<T>::store(dx + (((long long)n * Hi + ih) * Wi + iw) * dx_cs + c, acc);
+    }
+}
+
+static inline int grid_for(long long work, int block = 256, int cap = 16384) {
+    long long g = (work + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+}  // namespace fs
+
+using namespace fs;
+
+static fs_status check_resize(const char* fn, const fs_resize_desc* d) {
+    FS_REQUIRE(d, FS_ERR_INVALID, "%s: null descriptor", fn);
+    FS_REQUIRE(d->N > 0 && d->Hi > 0 && d->Wi > 0 && d->Ho > 0 && d->Wo > 0 && d->C > 0, FS_ERR_INVALID,
+               "%s: non-positive dimension", fn);
+    FS_REQUIRE(d->dtype == FS_F32 || d->dtype == FS_BF16, FS_ERR_INVALID, "%s: bad dtype", fn);
+    if (!d->out_nchw) {
+        const int vec = vec_elems(d->dtype);
+        FS_REQUIRE(d->C % vec == 0 && d->x_cs % vec == 0 && d->y_cs % vec == 0 && d->x_cs >= d->C && d->y_cs >= d->C,
+                   FS_ERR_UNSUPPORTED, "%s: C=%d / strides (%d,%d) must be multiples of %d", fn, d->C, d->x_cs, d->y_cs, vec);
+    } else {
+        FS_REQUIRE(d->x_cs >= ((d->C + 3) / 4) * 4, FS_ERR_INVALID,
+                   "%s: NCHW output needs the input channel stride padded to a multiple of 4 (got %d for C=%d)", fn, d->x_cs,
+                   d->C);
+        FS_REQUIRE(!d->relu, FS_ERR_UNSUPPORTED, "%s: relu not supported with NCHW output", fn);
+    }
+    return FS_OK;
+}
+
+extern "C" fs_status fs_bilinear_fwd(void* stream, const fs_resize_desc* d, const void* x, void* y) {
+    fs_status s = check_resize("fs_bilinear_fwd", d);
+    if (s != FS_OK) return s;
+    FS_REQUIRE(x && y, FS_ERR_INVALID, "fs_bilinear_fwd: null pointer");
+    const float rh = host_scale(d->Hi, d->Ho), rw = host_scale(d->Wi, d->Wo);
+    hipStream_t st = (hipStream_t)stream;
+    if (!d->out_nchw) {
+        FS_REQUIRE(aligned16(x) && aligned16(y), FS_ERR_INVALID, "fs_bilinear_fwd: operands must be 16-byte aligned");
+        const int cv = d->C / vec_elems(d->dtype);
+        const long long total = (long long)d->N * d->Ho * d->Wo * cv;
+        if (d->dtype == FS_F32)
+            hipLaunchKernelGGL((bilinear_fwd_kernel<float>), dim3(grid_for(total)), dim3(256), 0, st, d->N, d->Hi, d->Wi, d->Ho,
+                               d->Wo, cv, rh, rw, (const float*)x, d->x_cs, (float*)y, d->y_cs, d->relu);
+        else
+            hipLaunchKernelGGL((bilinear_fwd_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, st, d->N, d->Hi, d->Wi, d->Ho,
+                               d->Wo, cv, rh, rw, (const bf16_t*)x, d->x_cs, (bf16_t*)y, d->y_cs, d->relu);
+    } else {
+        const bool out_f32 = (d->out_nchw == 1) || d->dtype == FS_F32;
+        if (d->Wo % 4 == 0) {
+            const long long total = (long long)d->N * ((d->C + 3) / 4) * d->Ho * (d->Wo / 4);
+            const dim3 g(grid_for(total));
+            if (d->dtype == FS_F32)
+                hipLaunchKernelGGL((bilinear_fwd_nchw_kernel<float, float>), g, dim3(256), 0, st, d->N, d->Hi, d->Wi, d->Ho, d->Wo,
+                                   d->C, rh, rw, (const float*)x, d->x_cs, (float*)y);
+            else if (out_f32)
+                hipLaunchKernelGGL((bilinear_fwd_nchw_kernel<bf16_t, float>), g, dim3(256), 0, st, d->N, d->Hi, d->Wi, d->Ho, d->Wo,
+                                   d->C, rh, rw, (const bf16_t*)x, d->x_cs, (float*)y);
+            else
+                hipLaunchKernelGGL((bilinear_fwd_nchw_kernel<bf16_t, bf16_t>), g, dim3(256), 0, st, d->N, d->Hi, d->Wi, d->Ho,
+                                   d->Wo, d->C, rh, rw, (const bf16_t*)x, d->x_cs, (bf16_t*)y);
+        } else {
+            const long long total = (long long)d->N * d->C * d->Ho * d->Wo;
+            const dim3 g(grid_for(total));
+            if (d->dtype == FS_F32)
+                hipLaunchKernelGGL((bilinear_fwd_nchw_scalar_kernel<float, float>), g, dim3(256), 0, st, d->N, d->Hi, d->Wi, d->Ho,
+                                   d->Wo, d->C, rh, rw, (const float*)x, d->x_cs, (float*)y);
+            else if (out_f32)
+                hipLaunchKernelGGL((bilinear_fwd_nchw_scalar_kernel<bf16_t, float>), g, dim3(256), 0, st, d->N, d->Hi, d->Wi, d->Ho,
+                                   d->Wo, d->C, rh, rw, (const bf16_t*)x, d->x_cs, (float*)y);
+            else
+                hipLaunchKernelGGL((bilinear_fwd_nchw_scalar_kernel<bf16_t, bf16_t>), g, dim3(256), 0, st, d->N, d->Hi, d->Wi,
+                                   d->Ho, d->Wo, d->C, rh, rw, (const bf16_t*)x, d->x_cs, (bf16_t*)y);
+        }
+    }
+    return check_launch("fs_bilinear_fwd");
+}
+
+extern "C" fs_status fs_bilinear_bwd(void* stream, const fs_resize_desc* d, const void* dy, const void* y_out, void* dx) {
+    fs_status s = check_resize("fs_bilinear_bwd", d);
+    if (s != FS_OK) return s;
+    FS_REQUIRE(dy && dx, FS_ERR_INVALID, "fs_bilinear_bwd: null pointer");
+    FS_REQUIRE(!d->relu || y_out, FS_ERR_INVALID, "fs_bilinear_bwd: relu backward needs y_out");
+    const float rh = host_scale(d->Hi, d->Ho), rw = host_scale(d->Wi, d->Wo);
+    hipStream_t st = (hipStream_t)stream;
+    if (!d->out_nchw) {
+        const int cv = d->C / vec_elems(d->dtype);
+        const long long total = (long long)d->N * d->Hi * d->Wi * cv;
+        if (d->dtype == FS_F32)
+            hipLaunchKernelGGL((bilinear_bwd_kernel<float>), dim3(grid_for(total)), dim3(256), 0, st, d->N, d->Hi, d->Wi, d->Ho,
+                               d->Wo, cv, rh, rw, (const float*)dy, d->y_cs, (const float*)y_out, d->y_cs, d->relu, (float*)dx,
+                               d->x_cs);
+        else
+            hipLaunchKernelGGL((bilinear_bwd_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, st, d->N, d->Hi, d->Wi, d->Ho,
+                               d->Wo, cv, rh, rw, (const bf16_t*)dy, d->y_cs, (const bf16_t*)y_out, d->y_cs, d->relu, (bf16_t*)dx,
+                               d->x_cs);
+    } else {
+        FS_REQUIRE(d->out_nchw == 1 || d->dtype == FS_F32, FS_ERR_UNSUPPORTED, "fs_bilinear_bwd: NCHW gradient must be fp32");
+        const long long total = (long long)d->N * d->Hi * d->Wi * d->C;
+        if (d->dtype == FS_F32)
+            hipLaunchKernelGGL((bilinear_bwd_nchw_kernel<float>), dim3(grid_for(total)), dim3(256), 0, st, d->N, d->Hi, d->Wi,
+                               d->Ho, d->Wo, d->C, rh, rw, (const float*)dy, (float*)dx, d->x_cs);
+        else
+            hipLaunchKernelGGL((bilinear_bwd_nchw_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, st, d->N, d->Hi, d->Wi,
+                               d->Ho, d->Wo, d->C, rh, rw, (const float*)dy, (bf16_t*)dx, d->x_cs);
+    }
+    return check_launch("fs_bilinear_bwd");
+}

@@ -1,0 +1,153 @@
+// Convolution weight gradient on gfx950:  dW[co][r][s][ci] = sum_m dY[m][co] * X[pix(m)+(r,s)][ci].
+//
+// Replaces conv2d backward-weight (the autograd of F.conv2d at reference slimmable_ops.py:47 and of every
+// nn.Conv2d in operations.py / seg_oprs.py).  GEMM view per filter tap (r,s): D[co][ci], contraction over the
+// output pixels m (split across blocks, fp32 atomics into the packed gradient).  Both operands are NHWC, i.e.
+// "k-major": a chunk of 32 pixels is staged as [pixel][channel] rows in LDS (fp32, bf16 inputs are widened while
+// staging so the accumulation is exact-fp32 MFMA) and the v_mfma_f32_32x32x2_f32 operands are single ds_read_b32
+// per lane (lanes 0-31 = 32 consecutive channels of pixel k, lanes 32-63 of pixel k+1: conflict free).
+#include "common.h"
+
+namespace fs {
+
+struct WgradArgs {
+    const unsigned char* x;
+    const unsigned char* dy;
+    float* dw;
+    int H, W, Cin, Cout, R, S, stride, pad, Ho, Wo;
+    int x_cs, dy_cs;
+    int M, HoWo;
+    int tiles_ci;
+    long long slab;   // pixels per block
+};
+
+constexpr int KC = 32;      // pixels per chunk
+constexpr int BCH = 64;     // channels per block tile (both operands)
+constexpr int PITCH = BCH + 4;
+
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
+    constexpr int VEC = Elem<T>::VEC;
+    constexpr int VR = BCH / VEC;                 // vectors per staged row
+    constexpr int NV = (KC * VR + 255) / 256;     // vectors per thread per operand
+    __shared__ __attribute__((aligned(16))) float sA[KC][PITCH];   // dY  [pixel][co]
+    __shared__ __attribute__((aligned(16))) float sB[KC][PITCH];   // X   [pixel][ci]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile_co = blockIdx.y / p.tiles_ci, tile_ci = blockIdx.y % p.tiles_ci;
+    const int co0 = tile_co * BCH, ci0 = tile_ci * BCH;
+    const int tap = blockIdx.z;
+    const int tr = tap / p.S, ts = tap - tr * p.S;
+    const long long m_begin = blockIdx.x * p.slab;
+    long long m_end = m_begin + p.slab;
+    if (m_end > p.M) m_end = p.M;
+
+    u32x4 ra[NV], rb[NV];
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    auto load_chunk = [&](long long mc) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = tid + i * 256;
+            const int row = v / VR, cvec = (v - row * VR) * VEC;
+            ra[i] = zero4;
+            rb[i] = zero4;
+            const long long m = mc + row;
+            if (v < KC * VR && m < m_end) {
+                if (co0 + cvec < p.Cout) ra[i] = ldg16(p.dy + (m * p.dy_cs + co0 + cvec) * (long long)sizeof(T));
+                const int n = (int)(m / p.HoWo);
+                const int rem = (int)(m - (long long)n * p.HoWo);
+                const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+                const int ih = oh * p.stride - p.pad + tr, iw = ow * p.stride - p.pad + ts;
+                if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W && ci0 + cvec < p.Cin) {
+                    const long long pix = ((long long)n * p.H + ih) * p.W + iw;
+                    rb[i] = ldg16(p.x + (pix * p.x_cs + ci0 + cvec) * (long long)sizeof(T));
+                }
+            }
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = tid + i * 256;
+            if (v < KC * VR) {
+                const int row = v / VR, cvec = (v - row * VR) * VEC;
+                float fa[VEC], fb[VEC];
+                Elem<T>::unpack(ra[i], fa);
+                Elem<T>::unpack(rb[i], fb);
+#pragma unroll
+                for (int q = 0; q < VEC; q += 4) {
+                    *reinterpret_cast<f32x4*>(&sA[row][cvec + q]) = f32x4{fa[q], fa[q + 1], fa[q + 2], fa[q + 3]};
+                    *reinterpret_cast<f32x4*>(&sB[row][cvec + q]) = f32x4{fb[q], fb[q + 1], fb[q + 2], fb[q + 3]};
+                }
+            }
+        }
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    if (m_begin < m_end) {
+        load_chunk(m_begin);
+        for (long long mc = m_begin; mc < m_end; mc += KC) {
+            store_chunk();
+            __syncthreads();
+            if (mc + KC < m_end) load_chunk(mc + KC);
+            const float* pa = &sA[lane >> 5][wm * 32 + (lane & 31)];
+            const float* pb = &sB[lane >> 5][wn * 32 + (lane & 31)];
+#pragma unroll
+            for (int k = 0; k < KC; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[k * PITCH], pb[k * PITCH], acc, 0, 0, 0);
+            __syncthreads();
+        }
+    }
+    // D[i = co][j = ci]: col = lane&31 -> ci, row -> co
+    const int ci = ci0 + wn * 32 + (lane & 31);
+    if (ci < p.Cin) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (co < p.Cout) atomicAdd(p.dw + (((long long)co * p.R + tr) * p.S + ts) * p.Cin + ci, acc[r]);
+        }
+    }
+}
+
+}  // namespace fs
+
+using namespace fs;
+
+extern "C" fs_status fs_conv2d_wgrad(void* stream, const fs_conv_desc* d, const void* x, const void* dy, float* dw_packed) {
+    FS_REQUIRE(d && x && dy && dw_packed, FS_ERR_INVALID, "fs_conv2d_wgrad: null argument");
+    FS_REQUIRE(d->dtype == FS_F32 || d->dtype == FS_BF16, FS_ERR_INVALID, "fs_conv2d_wgrad: bad dtype");
+    const int vec = vec_elems(d->dtype);
+    FS_REQUIRE(d->Cin % vec == 0 && d->Cout % vec == 0, FS_ERR_UNSUPPORTED,
+               "fs_conv2d_wgrad: Cin=%d and Cout=%d must be multiples of %d", d->Cin, d->Cout, vec);
+    FS_REQUIRE(d->x_cs % vec == 0 && d->y_cs % vec == 0 && d->x_cs >= d->Cin && d->y_cs >= d->Cout, FS_ERR_INVALID,
+               "fs_conv2d_wgrad: bad channel strides (%d,%d)", d->x_cs, d->y_cs);
+    FS_REQUIRE(aligned16(x) && aligned16(dy), FS_ERR_INVALID, "fs_conv2d_wgrad: operands must be 16-byte aligned");
+    FS_REQUIRE(!(d->flags & FS_CONV_TRANSPOSED), FS_ERR_UNSUPPORTED, "fs_conv2d_wgrad: transposed descriptor");
+    WgradArgs a;
+    a.x = (const unsigned char*)x;
+    a.dy = (const unsigned char*)dy;
+    a.dw = dw_packed;
+    a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.R = d->R; a.S = d->S;
+    a.stride = d->stride; a.pad = d->pad; a.Ho = d->Ho; a.Wo = d->Wo;
+    a.x_cs = d->x_cs; a.dy_cs = d->y_cs;
+    const long long M = (long long)d->N * d->Ho * d->Wo;
+    a.M = (int)M; a.HoWo = d->Ho * d->Wo;
+    const int tiles_co = (d->Cout + BCH - 1) / BCH;
+    a.tiles_ci = (d->Cin + BCH - 1) / BCH;
+    const int taps = d->R * d->S;
+    const long long other = (long long)tiles_co * a.tiles_ci * taps;
+    long long slabs = (2048 + other - 1) / other;              // aim for ~2k blocks
+    const long long max_slabs = (M + 4 * KC - 1) / (4 * KC);   // at least 4 chunks per block
+    if (slabs > max_slabs) slabs = max_slabs;
+    if (slabs < 1) slabs = 1;
+    long long slab = (M + slabs - 1) / slabs;
+    slab = (slab + KC - 1) / KC * KC;
+    a.slab = slab;
+    dim3 grid((unsigned)((M + slab - 1) / slab), (unsigned)(tiles_co * a.tiles_ci), (unsigned)taps);
+    if (d->dtype == FS_F32) hipLaunchKernelGGL((wgrad_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((wgrad_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("fs_conv2d_wgrad");
+}

@@ -1,0 +1,445 @@
+"""torch.autograd.Function layer: the seam between the reference's operator semantics and the HIP kernels.
+
+Each Function is one fused unit of the hot path (forward and backward both run on libfasterseg_hip kernels):
+  conv_bn_act      nn.Conv2d/USConv2d -> BatchNorm2d (train or eval) -> [ReLU]     operations.py:125-128,196-200
+  conv_bias        Head's biased 1x1 classifier                                     seg_oprs.py:245,273
+  factorized_reduce  cat[conv1x1_s2(x), conv1x1_s2(x[:,:,1:,1:])] -> BN -> ReLU     operations.py:521-526
+  interpolate      F.interpolate(bilinear, align_corners=True) [+ReLU], NHWC or final NCHW logits
+  batch_norm / conv2d  the un-fused forms behind fasterseg_amd.nn.{BatchNorm2d,Conv2d}
+  scale_accumulate  acc + coef * x with a device-resident scalar coef               model_search.py:76-78,330-333
+There is no eager/ATen fallback: inputs that are not NHWC views are converted with fs_nchw_to_nhwc.
+"""
+import torch
+
+from . import kernels as K
+
+_compute_dtype = torch.float32
+
+
+def set_compute_dtype(dtype):
+    """Storage/compute dtype used when an operator receives a plain NCHW fp32 tensor (float32 or bfloat16)."""
+    global _compute_dtype
+    K.dtype_code(dtype)
+    _compute_dtype = dtype
+
+
+def get_compute_dtype():
+    return _compute_dtype
+
+
+def as_nhwc(x, dtype=None):
+    if K.is_nhwc(x) and (dtype is None or x.dtype == dtype):
+        return x
+    return K.to_nhwc(x, dtype or (x.dtype if x.dtype in (torch.float32, torch.bfloat16) and K.is_nhwc(x) else _compute_dtype))
+
+
+# ---------------------------------------------------------------------------------------------------
+# packed-filter cache: re-pack only when the parameter changed (optimizer steps bump Tensor._version)
+# ---------------------------------------------------------------------------------------------------
+_pack_cache = {}
+
+
+def packed_weight(weight, dtype, cout=None, cin=None, flip=False, rows=None):
+    key = (weight.data_ptr(), weight._version, tuple(weight.shape), dtype, cout, cin, flip, rows)
+    hit = _pack_cache.get(key)
+    if hit is None:
+        if len(_pack_cache) > 8192:
+            _pack_cache.clear()
+        hit = K.pack_weight(weight.detach(), dtype, cout, cin, flip, rows)
+        _pack_cache[key] = hit
+    return hit
+
+
+def fold_bn(gamma, beta, running_mean, running_var, eps):
+    """eval-mode BatchNorm as per-channel scale/shift (C-length vectors; plumbing, not on the pixel path)."""
+    scale = gamma.detach().float() * torch.rsqrt(running_var.float() + eps)
+    shift = beta.detach().float() - running_mean.float() * scale
+    return scale.contiguous(), shift.contiguous()
+
+
+def _zero_stats(c, device):
+    return torch.zeros(2 * c, dtype=torch.float32, device=device)
+
+
+def _weight_grad(weight, dw_packed, cout, cin):
+    g = torch.zeros_like(weight, dtype=torch.float32)
+    K.unpack_weight_grad(dw_packed, g, cout, cin)
+    return g
+
+
+def _dgrad(dz, weight, cin, R, S, stride, pad, in_hw, rows=None):
+    """data gradient: conv of dz with the 180-degree-rotated, IO-transposed filter (zero insertion for stride 2)."""
+    cout = dz.shape[1]
+    wf = packed_weight(weight, dz.dtype, cout if rows is None else min(cout, weight.shape[0]), cin, flip=True)
+    if rows is not None and rows != wf.shape[-1]:          # channel-padded dz (classifier): pad the contraction dim
+        wfp = torch.zeros(wf.shape[:-1] + (rows,), dtype=wf.dtype, device=wf.device)
+        wfp[..., :wf.shape[-1]] = wf
+        wf = wfp
+    return K.conv2d(dz, wf, cin, R, S, 1, R - 1 - pad, transposed=(stride == 2), out_hw=in_hw)
+
+
+class _ConvBNAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, cfg):
+        stride, pad, relu, training, momentum, eps, cout, cin = cfg
+        R, S = weight.shape[2], weight.shape[3]
+        assert x.shape[1] == cin, "input has %d channels, conv expects %d" % (x.shape[1], cin)
+        wp = packed_weight(weight, x.dtype, cout, cin)
+        if not training:
+            scale, shift = fold_bn(gamma, beta, running_mean, running_var, eps)
+            y = K.conv2d(x, wp, cout, R, S, stride, pad, scale, shift, relu)
+            ctx.eval_mode = True
+            ctx.mark_non_differentiable(y)
+            return y
+        stats = _zero_stats(cout, x.device)
+        z = K.conv2d(x, wp, cout, R, S, stride, pad, stats=stats)
+        count = z.shape[0] * z.shape[2] * z.shape[3]
+        mean, invstd, scale, shift = K.bn_finalize(stats, count, gamma.detach(), beta.detach(), eps, momentum,
+                                                   running_mean, running_var)
+        y = K.affine_act(z, scale, shift, relu)
+        ctx.eval_mode = False
+        ctx.cfg = cfg
+        ctx.save_for_backward(x, weight, gamma, z, y if relu else None, mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if ctx.eval_mode:
+            raise RuntimeError("fasterseg_amd: backward through eval-mode conv+BN is not part of the hot path")
+        x, weight, gamma, z, y, mean, invstd = ctx.saved_tensors
+        stride, pad, relu, training, momentum, eps, cout, cin = ctx.cfg
+        R, S = weight.shape[2], weight.shape[3]
+        dy = as_nhwc(dy, z.dtype)
+        dz, dgamma, dbeta = K.bn_backward(z, dy, y, mean, invstd, gamma.detach(), relu)
+        gw = gx = None
+        if ctx.needs_input_grad[1]:
+            gw = _weight_grad(weight, K.conv2d_wgrad(x, dz, R, S, stride, pad), cout, cin)
+        if ctx.needs_input_grad[0]:
+            gx = _dgrad(dz, weight, cin, R, S, stride, pad, (x.shape[2], x.shape[3]))
+        return gx, gw, dgamma, dbeta, None, None, None
+
+
+def conv_bn_act(x, weight, gamma, beta, running_mean, running_var, stride, pad, relu, training, momentum=0.1, eps=1e-5,
+                cout=None, cin=None):
+    x = as_nhwc(x)
+    cout = weight.shape[0] if cout is None else cout
+    cin = weight.shape[1] if cin is None else cin
+    cfg = (stride, pad, relu, training, momentum, eps, cout, cin)
+    return _ConvBNAct.apply(x, weight, gamma, beta, running_mean, running_var, cfg)
+
+
+class _StemConvBNAct(torch.autograd.Function):
+    """ConvNorm(3, C, 3, stride 2) on the NCHW fp32 image (model_seg.py:193)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, cfg):
+        relu, training, momentum, eps, dtype = cfg
+        cout = weight.shape[0]
+        wp = packed_weight(weight, torch.float32)
+        xc = x.detach().float().contiguous()
+        if not training:
+            scale, shift = fold_bn(gamma, beta, running_mean, running_var, eps)
+            y = K.conv_stem(xc, wp, cout, scale, shift, relu, dtype)
+            ctx.eval_mode = True
+            ctx.mark_non_differentiable(y)
+            return y
+        z = K.conv_stem(xc, wp, cout, None, None, False, dtype)
+        stats = K.channel_stats(z)
+        count = z.shape[0] * z.shape[2] * z.shape[3]
+        mean, invstd, scale, shift = K.bn_finalize(stats, count, gamma.detach(), beta.detach(), eps, momentum,
+                                                   running_mean, running_var)
+        y = K.affine_act(z, scale, shift, relu)
+        ctx.eval_mode = False
+        ctx.cfg = cfg
+        ctx.save_for_backward(xc, weight, gamma, z, y if relu else None, mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if ctx.eval_mode:
+            raise RuntimeError("fasterseg_amd: backward through eval-mode conv+BN is not part of the hot path")
+        xc, weight, gamma, z, y, mean, invstd = ctx.saved_tensors
+        relu = ctx.cfg[0]
+        dy = as_nhwc(dy, z.dtype)
+        dz, dgamma, dbeta = K.bn_backward(z, dy, y, mean, invstd, gamma.detach(), relu)
+        gw = gx = None
+        vec = K.vec_of(z.dtype)
+        if ctx.needs_input_grad[1]:
+            xp = K.to_nhwc(xc, z.dtype)                       # 3 channels zero-padded to one vector
+            xp_full = xp.as_strided((xp.shape[0], vec, xp.shape[2], xp.shape[3]), xp.stride(), xp.storage_offset())
+            dw = K.conv2d_wgrad(xp_full, dz, 3, 3, 2, 1)      # [cout][3][3][vec]
+            gpad = torch.zeros((weight.shape[0], vec, 3, 3), dtype=torch.float32, device=weight.device)
+            K.unpack_weight_grad(dw, gpad, weight.shape[0], vec)
+            gw = gpad[:, :3].contiguous()
+        if ctx.needs_input_grad[0]:
+            wpad = torch.zeros((vec, 3, 3, 3), dtype=torch.float32, device=weight.device).permute(0, 3, 1, 2)
+            # data gradient with Cout(dgrad)=3: generic transposed conv, output channel-padded then repacked to NCHW
+            wf = K.pack_weight(weight.detach(), z.dtype, flip=True)          # [3][3][3][cout]
+            dx = K.conv2d(dz, wf, 3, 3, 3, 1, 1, transposed=True, out_hw=(xc.shape[2], xc.shape[3]))
+            gx = K.to_nchw(dx)
+            del wpad
+        return gx, gw, dgamma, dbeta, None, None, None
+
+
+def stem_conv_bn_act(x, weight, gamma, beta, running_mean, running_var, relu, training, momentum=0.1, eps=1e-5, dtype=None):
+    cfg = (relu, training, momentum, eps, dtype or _compute_dtype)
+    return _StemConvBNAct.apply(x, weight, gamma, beta, running_mean, running_var, cfg)
+
+
+CLS_PAD = 32   # classifier logits live in a 32-channel NHWC buffer (19 valid, pad lanes zero)
+
+
+class _ConvBias(torch.autograd.Function):
+    """Biased 1x1 (or 3x3) conv without BN: Head.conv_1x1 (seg_oprs.py:245) and plain nn.Conv2d."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad):
+        cout, cin, R, S = weight.shape
+        vec = K.vec_of(x.dtype)
+        cpad = cout if cout % vec == 0 else K.round_up(cout, CLS_PAD)
+        wp = packed_weight(weight, x.dtype)
+        N, _, H, W = x.shape
+        Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
+        buf = K.empty_nhwc(N, cpad, Ho, Wo, x.dtype, x.device, zero=(cpad != cout))
+        y = buf[:, :cout]
+        shift = bias.detach().float().contiguous() if bias is not None else None
+        K.conv2d(x, wp, cout, R, S, stride, pad, None, shift, False, out=y)
+        ctx.save_for_backward(x, weight)
+        ctx.meta = (stride, pad, cpad, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        stride, pad, cpad, has_bias = ctx.meta
+        cout, cin, R, S = weight.shape
+        N, _, Ho, Wo = dy.shape
+        if cpad != cout:        # widen the gradient to the padded channel count (pad lanes zero)
+            dyp = K.empty_nhwc(N, cpad, Ho, Wo, x.dtype, x.device, zero=True)
+            if K.is_nhwc(dy, x.dtype) and K.channel_stride(dy) == cpad:
+                dyp = dy.as_strided((N, cpad, Ho, Wo), dy.stride(), dy.storage_offset())   # already the padded buffer
+            else:
+                dyp[:, :cout].copy_(dy)
+        else:
+            dyp = as_nhwc(dy, x.dtype)
+        gw = gb = gx = None
+        if ctx.needs_input_grad[1]:
+            dw = K.conv2d_wgrad(x, dyp, R, S, stride, pad)
+            gfull = torch.zeros((cpad, cin, R, S), dtype=torch.float32, device=x.device)
+            K.unpack_weight_grad(dw, gfull, cpad, cin)
+            gw = gfull[:cout].contiguous()
+        if has_bias and ctx.needs_input_grad[2]:
+            gb = K.channel_stats(dyp)[:cout].clone()
+        if ctx.needs_input_grad[0]:
+            gx = _dgrad(dyp, weight, cin, R, S, stride, pad, (x.shape[2], x.shape[3]), rows=cpad)
+        return gx, gw, gb, None, None
+
+
+def conv_bias(x, weight, bias, stride=1, pad=0):
+    return _ConvBias.apply(as_nhwc(x), weight, bias, stride, pad)
+
+
+class _FactorizedReduce(torch.autograd.Function):
+    """stride-2 'skip': two 1x1 stride-2 convs (the second on x[:,:,1:,1:], expressed as pad=-1) written into the two
+    channel halves of one buffer, BN statistics from the conv epilogues, then BN+ReLU (operations.py:521-526)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, w2, gamma, beta, running_mean, running_var, cfg):
+        training, momentum, eps, half, cin = cfg
+        N, _, H, W = x.shape
+        assert H % 2 == 0 and W % 2 == 0, "FactorizedReduce needs even spatial dims (reference torch.cat would fail too)"
+        Ho, Wo = H // 2, W // 2
+        p1, p2 = packed_weight(w1, x.dtype, half, cin), packed_weight(w2, x.dtype, half, cin)
+        out_hw = (Ho, Wo)
+        if not training:
+            scale, shift = fold_bn(gamma, beta, running_mean, running_var, eps)
+            y = K.empty_nhwc(N, 2 * half, Ho, Wo, x.dtype, x.device)
+            K.conv2d(x, p1, half, 1, 1, 2, 0, scale[:half].contiguous(), shift[:half].contiguous(), True, out=y[:, :half],
+                     out_hw=out_hw)
+            K.conv2d(x, p2, half, 1, 1, 2, -1, scale[half:].contiguous(), shift[half:].contiguous(), True, out=y[:, half:],
+                     out_hw=out_hw)
+            ctx.eval_mode = True
+            ctx.mark_non_differentiable(y)
+            return y
+        z = K.empty_nhwc(N, 2 * half, Ho, Wo, x.dtype, x.device)
+        s1, s2 = _zero_stats(half, x.device), _zero_stats(half, x.device)
+        K.conv2d(x, p1, half, 1, 1, 2, 0, out=z[:, :half], stats=s1, out_hw=out_hw)
+        K.conv2d(x, p2, half, 1, 1, 2, -1, out=z[:, half:], stats=s2, out_hw=out_hw)
+        stats = torch.cat([s1[:half], s2[:half], s1[half:], s2[half:]])
+        mean, invstd, scale, shift = K.bn_finalize(stats, N * Ho * Wo, gamma.detach(), beta.detach(), eps, momentum,
+                                                   running_mean, running_var)
+        y = K.affine_act(z, scale, shift, True)
+        ctx.eval_mode = False
+        ctx.cfg = cfg
+        ctx.save_for_backward(x, w1, w2, gamma, z, y, mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if ctx.eval_mode:
+            raise RuntimeError("fasterseg_amd: backward through eval-mode conv+BN is not part of the hot path")
+        x, w1, w2, gamma, z, y, mean, invstd = ctx.saved_tensors
+        training, momentum, eps, half, cin = ctx.cfg
+        dy = as_nhwc(dy, z.dtype)
+        dz, dgamma, dbeta = K.bn_backward(z, dy, y, mean, invstd, gamma.detach(), True)
+        da, db = dz[:, :half], dz[:, half:]
+        g1 = g2 = gx = None
+        if ctx.needs_input_grad[1]:
+            g1 = _weight_grad(w1, K.conv2d_wgrad(x, da, 1, 1, 2, 0), half, cin)
+        if ctx.needs_input_grad[2]:
+            g2 = _weight_grad(w2, K.conv2d_wgrad(x, db, 1, 1, 2, -1), half, cin)
+        if ctx.needs_input_grad[0]:
+            hw = (x.shape[2], x.shape[3])
+            gx = _dgrad(da, w1, cin, 1, 1, 2, 0, hw)
+            g_odd = _dgrad(db, w2, cin, 1, 1, 2, -1, hw)      # touches only odd (h,w); disjoint from gx's even taps
+            K.axpy(g_odd, _one(x.device), gx, True)
+        return gx, g1, g2, dgamma, dbeta, None, None, None
+
+
+_ones = {}
+
+
+def _one(device):
+    key = str(device)
+    if key not in _ones:
+        _ones[key] = torch.ones(1, dtype=torch.float32, device=device)
+    return _ones[key]
+
+
+def factorized_reduce(x, w1, w2, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, half=None,
+                      cin=None):
+    x = as_nhwc(x)
+    half = w1.shape[0] if half is None else half
+    cin = w1.shape[1] if cin is None else cin
+    return _FactorizedReduce.apply(x, w1, w2, gamma, beta, running_mean, running_var, (training, momentum, eps, half, cin))
+
+
+class _Interpolate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, size, relu, out_nchw):
+        if out_nchw:
+            cs = K.channel_stride(x)
+            y = K.bilinear(x, size, out_nchw=out_nchw, channels=x.shape[1])
+            ctx.meta = (tuple(x.shape), False, x.dtype, out_nchw, cs)
+            return y
+        y = K.bilinear(x, size, relu=relu)
+        ctx.meta = (tuple(x.shape), relu, x.dtype, 0, None)
+        if relu:
+            ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        in_shape, relu, dtype, out_nchw, cs = ctx.meta
+        if out_nchw:
+            dyc = dy.float().contiguous()
+            return K.bilinear_bwd(dyc, None, in_shape, False, dtype, out_nchw=1, dx_cs=cs), None, None, None
+        y = ctx.saved_tensors[0] if relu else None
+        dy = as_nhwc(dy, dtype)
+        if relu and K.channel_stride(dy) != K.channel_stride(y):
+            dy = K.copy_channels(dy, K.empty_nhwc(*y.shape, dtype, dy.device, cs=K.channel_stride(y)))
+        return K.bilinear_bwd(dy, y, in_shape, relu, dtype), None, None, None
+
+
+def interpolate(x, size=None, scale_factor=None, relu=False, out_nchw=0):
+    """F.interpolate(x, size|scale_factor, mode='bilinear', align_corners=True) on the HIP kernel.
+    out_nchw=1 returns a contiguous NCHW fp32 tensor (final logits, model_seg.py:359-365)."""
+    if size is None:
+        size = (int(x.shape[2] * scale_factor), int(x.shape[3] * scale_factor))
+    x = as_nhwc(x)
+    if out_nchw and K.channel_stride(x) < K.round_up(x.shape[1], 4):
+        raise ValueError("NCHW-output resize needs a channel-padded input buffer")
+    return _Interpolate.apply(x, (int(size[0]), int(size[1])), relu, out_nchw)
+
+
+class _BatchNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu):
+        if not training:
+            scale, shift = fold_bn(gamma, beta, running_mean, running_var, eps)
+            y = K.affine_act(x, scale, shift, relu)
+            ctx.eval_mode = True
+            ctx.mark_non_differentiable(y)
+            return y
+        stats = K.channel_stats(x)
+        count = x.shape[0] * x.shape[2] * x.shape[3]
+        mean, invstd, scale, shift = K.bn_finalize(stats, count, gamma.detach(), beta.detach(), eps, momentum, running_mean,
+                                                   running_var)
+        y = K.affine_act(x, scale, shift, relu)
+        ctx.eval_mode = False
+        ctx.relu = relu
+        ctx.save_for_backward(x, gamma, y if relu else None, mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if ctx.eval_mode:
+            raise RuntimeError("fasterseg_amd: backward through eval-mode BN is not part of the hot path")
+        x, gamma, y, mean, invstd = ctx.saved_tensors
+        dz, dgamma, dbeta = K.bn_backward(x, as_nhwc(dy, x.dtype), y, mean, invstd, gamma.detach(), ctx.relu)
+        return dz, dgamma, dbeta, None, None, None, None, None, None
+
+
+def batch_norm(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, relu=False):
+    return _BatchNorm.apply(as_nhwc(x), gamma, beta, running_mean, running_var, training, momentum, eps, relu)
+
+
+class _ScaleAccumulate(torch.autograd.Function):
+    """out = acc + coef * x   (acc may be None).  coef is a 0-dim/1-element device tensor, so architecture weights
+    never leave the GPU; its gradient is the full-tensor dot <dy, x> (fs_dot)."""
+
+    @staticmethod
+    def forward(ctx, acc, x, coef):
+        c = coef.detach().float().reshape(1).contiguous()
+        out = K.empty_nhwc(*x.shape, x.dtype, x.device)
+        if acc is None:
+            K.axpy(x, c, out, False)
+        else:
+            K.copy_channels(acc, out)
+            K.axpy(x, c, out, True)
+        ctx.has_acc = acc is not None
+        ctx.save_for_backward(x, c)
+        ctx.coef_shape = coef.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, c = ctx.saved_tensors
+        dy = as_nhwc(dy, x.dtype)
+        gacc = dy if (ctx.has_acc and ctx.needs_input_grad[0]) else None
+        gx = gc = None
+        if ctx.needs_input_grad[1]:
+            gx = K.axpy(dy, c, K.empty_nhwc(*x.shape, x.dtype, x.device), False)
+        if ctx.needs_input_grad[2]:
+            gc = K.dot(dy, x).reshape(ctx.coef_shape)
+        return gacc, gx, gc
+
+
+def scale_accumulate(acc, x, coef):
+    x = as_nhwc(x)
+    if acc is not None:
+        acc = as_nhwc(acc, x.dtype)
+    if not torch.is_tensor(coef):
+        coef = torch.tensor(float(coef), dtype=torch.float32, device=x.device)
+    return _ScaleAccumulate.apply(acc, x, coef)
+
+
+def cat(tensors):
+    """torch.cat(dim=1) of NHWC feature maps via fs_copy_channels; autograd by slicing."""
+    return _Cat.apply(*[as_nhwc(t) for t in tensors])
+
+
+class _Cat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, *tensors):
+        ctx.sizes = [t.shape[1] for t in tensors]
+        return K.cat_channels(list(tensors))
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = as_nhwc(dy)
+        outs, off = [], 0
+        for c in ctx.sizes:
+            outs.append(dy[:, off:off + c])
+            off += c
+        return tuple(outs)

@@ -1,0 +1,302 @@
+"""Tensor-level wrappers over the C ABI: torch tensors in, raw pointers + sizes out.
+
+Activation convention: a feature map is a torch tensor of logical shape (N, C, H, W) whose memory is NHWC with a
+channel stride cs >= C (strides (H*W*cs, 1, W*cs, cs)); channel slices of a wider buffer are therefore valid
+operands and torch.cat becomes "write into a slice".  torch is used only for memory, streams and autograd plumbing.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import FS_BF16, FS_CONV_RELU, FS_CONV_TRANSPOSED, FS_F32, ConvDesc, ResizeDesc, call
+
+_DT = {torch.float32: FS_F32, torch.bfloat16: FS_BF16}
+
+
+def dtype_code(dt):
+    try:
+        return _DT[dt]
+    except KeyError:
+        raise TypeError("fasterseg_amd kernels support float32 and bfloat16, got %s" % dt)
+
+
+def vec_of(dt):
+    return 4 if dt == torch.float32 else 8
+
+
+def round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def empty_nhwc(N, C, H, W, dtype, device, cs=None, zero=False):
+    """(N,C,H,W) view over a fresh NHWC buffer with channel stride cs (default: C rounded up to the vector width)."""
+    cs = cs or round_up(C, vec_of(dtype))
+    make = torch.zeros if zero else torch.empty
+    buf = make((N, H, W, cs), dtype=dtype, device=device)
+    return buf.permute(0, 3, 1, 2)[:, :C]
+
+
+def channel_stride(t):
+    """Channel stride of an NHWC view, or None if `t` is not laid out that way."""
+    if t.dim() != 4:
+        return None
+    N, C, H, W = t.shape
+    sN, sC, sH, sW = t.stride()
+    cs = sW
+    if C > 1 and sC != 1:
+        return None
+    if cs < C:
+        return None
+    if (H > 1 and sH != W * cs) or (N > 1 and sN != H * W * cs):
+        return None
+    return cs
+
+
+def is_nhwc(t, dtype=None):
+    if not t.is_cuda or t.dtype not in _DT or (dtype is not None and t.dtype != dtype):
+        return False
+    cs = channel_stride(t)
+    if cs is None:
+        return False
+    v = vec_of(t.dtype)
+    return cs % v == 0 and t.data_ptr() % 16 == 0
+
+
+def require_nhwc(t, what="tensor"):
+    if not is_nhwc(t):
+        raise ValueError("%s must be an NHWC-strided CUDA tensor (shape %s, strides %s, dtype %s)" %
+                         (what, tuple(t.shape), t.stride(), t.dtype))
+    return channel_stride(t)
+
+
+def to_nhwc(x, dtype):
+    """Any (N,C,H,W) CUDA tensor -> NHWC view of `dtype` (fs_nchw_to_nhwc for contiguous fp32 NCHW inputs)."""
+    if is_nhwc(x, dtype):
+        return x
+    N, C, H, W = x.shape
+    if is_nhwc(x):            # NHWC but other dtype: widen/narrow through NCHW fp32
+        x = to_nchw(x)
+    src = x.detach().to(torch.float32).contiguous()
+    cpad = round_up(C, vec_of(dtype))
+    out = empty_nhwc(N, C, H, W, dtype, x.device, cs=cpad)
+    call("fs_nchw_to_nhwc", _stream(), N, C, H, W, _p(src), _p(out), cpad, cpad, dtype_code(dtype))
+    return out
+
+
+def to_nchw(x):
+    """NHWC view -> contiguous NCHW fp32."""
+    cs = require_nhwc(x, "x")
+    N, C, H, W = x.shape
+    out = torch.empty((N, C, H, W), dtype=torch.float32, device=x.device)
+    call("fs_nhwc_to_nchw", _stream(), N, C, H, W, _p(x), cs, dtype_code(x.dtype), _p(out))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# filters
+# ---------------------------------------------------------------------------------------------------
+def pack_weight(w, dtype, cout=None, cin=None, flip=False, rows=None):
+    """OIHW fp32 (optionally the leading [:cout,:cin] slice, slimmable_ops.py:42) -> packed [Cout][R][S][Cin] `dtype`.
+    flip=True gives the data-gradient filter [Cin][R][S][Cout] rotated by 180 degrees.  `rows` zero-pads the leading
+    dimension (used for the 19-class classifier)."""
+    O, I, R, S = w.shape
+    cout = O if cout is None else cout
+    cin = I if cin is None else cin
+    assert w.dtype == torch.float32 and w.stride(3) == 1 and w.stride(2) == S, "filter must be fp32 with contiguous taps"
+    lead, inner = (cin, cout) if flip else (cout, cin)
+    nrows = lead if rows is None else rows
+    make = torch.zeros if nrows != lead else torch.empty
+    out = make((nrows, R, S, inner), dtype=dtype, device=w.device)
+    call("fs_pack_weight", _stream(), _p(w), w.stride(0), w.stride(1), cout, cin, R, S, dtype_code(dtype), int(flip), _p(out))
+    return out
+
+
+def unpack_weight_grad(dw_packed, grad, cout, cin, accumulate=False):
+    """packed fp32 [cout][R][S][cin] -> grad[:cout,:cin] of an OIHW fp32 tensor."""
+    R, S = grad.shape[2], grad.shape[3]
+    call("fs_unpack_weight_grad", _stream(), _p(dw_packed), cout, cin, R, S, _p(grad), grad.stride(0), grad.stride(1),
+         int(accumulate))
+
+
+# ---------------------------------------------------------------------------------------------------
+# convolution
+# ---------------------------------------------------------------------------------------------------
+def conv_desc(x_shape, x_cs, cout, R, S, stride, pad, y_cs, dtype, flags=0, out_hw=None):
+    N, Cin, H, W = x_shape
+    if out_hw is None:
+        Ho = (H + 2 * pad - R) // stride + 1
+        Wo = (W + 2 * pad - S) // stride + 1
+    else:
+        Ho, Wo = out_hw
+    return ConvDesc(N, H, W, Cin, cout, R, S, stride, pad, Ho, Wo, x_cs, y_cs, dtype_code(dtype), flags)
+
+
+def conv2d(x, w_packed, cout, R, S, stride, pad, scale=None, shift=None, relu=False, out=None, stats=None,
+           transposed=False, out_hw=None):
+    """y = relu?(conv(x, w) * scale + shift); `out` may be a channel slice of a wider NHWC buffer."""
+    x_cs = require_nhwc(x, "x")
+    N, Cin, H, W = x.shape
+    flags = (FS_CONV_RELU if relu else 0) | (FS_CONV_TRANSPOSED if transposed else 0)
+    d = conv_desc(x.shape, x_cs, cout, R, S, stride, pad, 0, x.dtype, flags, out_hw)
+    if out is None:
+        out = empty_nhwc(N, cout, d.Ho, d.Wo, x.dtype, x.device)
+    else:
+        assert tuple(out.shape) == (N, cout, d.Ho, d.Wo) and out.dtype == x.dtype, (tuple(out.shape), (N, cout, d.Ho, d.Wo))
+    d.y_cs = channel_stride(out)
+    assert d.y_cs is not None
+    call("fs_conv2d_fwd", _stream(), ctypes.byref(d), _p(x), _p(w_packed), _p(scale), _p(shift), _p(out), _p(stats))
+    return out
+
+
+def conv2d_wgrad(x, dy, R, S, stride, pad, cout=None):
+    """fp32 packed weight gradient [Cout][R][S][Cin] of conv(x) w.r.t. its filter."""
+    x_cs = require_nhwc(x, "x")
+    dy_cs = require_nhwc(dy, "dy")
+    N, Cin, H, W = x.shape
+    cout = dy.shape[1] if cout is None else cout
+    d = conv_desc(x.shape, x_cs, cout, R, S, stride, pad, dy_cs, x.dtype, 0, (dy.shape[2], dy.shape[3]))
+    dw = torch.zeros((cout, R, S, Cin), dtype=torch.float32, device=x.device)
+    call("fs_conv2d_wgrad", _stream(), ctypes.byref(d), _p(x), _p(dy), _p(dw))
+    return dw
+
+
+def conv_stem(x_nchw, w_packed, cout, scale, shift, relu, dtype, out=None):
+    N, C, H, W = x_nchw.shape
+    assert C == 3 and x_nchw.dtype == torch.float32 and x_nchw.is_contiguous()
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    if out is None:
+        out = empty_nhwc(N, cout, Ho, Wo, dtype, x_nchw.device)
+    call("fs_conv_stem_fwd", _stream(), N, H, W, cout, _p(x_nchw), _p(w_packed), _p(scale), _p(shift), _p(out),
+         channel_stride(out), dtype_code(dtype), int(relu))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# bilinear (align_corners=True)
+# ---------------------------------------------------------------------------------------------------
+def bilinear(x, size, relu=False, out=None, out_nchw=0, channels=None):
+    """out_nchw: 0 -> NHWC view; 1 -> contiguous NCHW fp32; 2 -> contiguous NCHW in x.dtype.
+    `channels` overrides C (reading the first C channels of a padded buffer)."""
+    x_cs = channel_stride(x)
+    N, C, Hi, Wi = x.shape
+    C = C if channels is None else channels
+    Ho, Wo = int(size[0]), int(size[1])
+    if out_nchw:
+        odt = torch.float32 if out_nchw == 1 else x.dtype
+        if out is None:
+            out = torch.empty((N, C, Ho, Wo), dtype=odt, device=x.device)
+        y_cs = 0
+    else:
+        require_nhwc(x, "x")
+        if out is None:
+            out = empty_nhwc(N, C, Ho, Wo, x.dtype, x.device)
+        y_cs = channel_stride(out)
+    d = ResizeDesc(N, Hi, Wi, Ho, Wo, C, x_cs, y_cs, dtype_code(x.dtype), int(relu), int(out_nchw))
+    call("fs_bilinear_fwd", _stream(), ctypes.byref(d), _p(x), _p(out))
+    return out
+
+
+def bilinear_bwd(dy, y_out, in_shape, relu, dtype, out_nchw=0, dx_cs=None):
+    """Gradient w.r.t. the input of `bilinear`; dy NHWC (or contiguous NCHW fp32 when out_nchw)."""
+    N, C, Hi, Wi = in_shape
+    Ho, Wo = dy.shape[2], dy.shape[3]
+    dx = empty_nhwc(N, C, Hi, Wi, dtype, dy.device, cs=dx_cs, zero=bool(out_nchw))
+    if out_nchw:
+        assert dy.is_contiguous() and dy.dtype == torch.float32
+        y_cs = 0
+    else:
+        y_cs = require_nhwc(dy, "dy")
+        if relu:
+            assert channel_stride(y_out) == y_cs, "y_out and dy must share a channel stride"
+    d = ResizeDesc(N, Hi, Wi, Ho, Wo, C, channel_stride(dx), y_cs, dtype_code(dtype), int(relu), int(out_nchw))
+    call("fs_bilinear_bwd", _stream(), ctypes.byref(d), _p(dy), _p(y_out) if relu else None, _p(dx))
+    return dx
+
+
+# ---------------------------------------------------------------------------------------------------
+# batch norm / elementwise
+# ---------------------------------------------------------------------------------------------------
+def _pix(t):
+    return t.shape[0] * t.shape[2] * t.shape[3]
+
+
+def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean, running_var):
+    C = stats.numel() // 2
+    mean = torch.empty(C, dtype=torch.float32, device=stats.device)
+    invstd, scale, shift = torch.empty_like(mean), torch.empty_like(mean), torch.empty_like(mean)
+    call("fs_bn_finalize", _stream(), C, int(count), _p(stats), _p(gamma), _p(beta), float(eps), float(momentum),
+         _p(running_mean), _p(running_var), _p(mean), _p(invstd), _p(scale), _p(shift))
+    return mean, invstd, scale, shift
+
+
+def affine_act(x, scale, shift, relu, out=None):
+    x_cs = require_nhwc(x, "x")
+    if out is None:
+        out = empty_nhwc(*x.shape[:1], x.shape[1], x.shape[2], x.shape[3], x.dtype, x.device)
+    call("fs_affine_act", _stream(), _pix(x), x.shape[1], _p(x), x_cs, _p(scale), _p(shift), _p(out), channel_stride(out),
+         dtype_code(x.dtype), int(relu))
+    return out
+
+
+def channel_stats(x, stats=None):
+    x_cs = require_nhwc(x, "x")
+    if stats is None:
+        stats = torch.zeros(2 * x.shape[1], dtype=torch.float32, device=x.device)
+    call("fs_channel_stats", _stream(), _pix(x), x.shape[1], _p(x), x_cs, dtype_code(x.dtype), _p(stats))
+    return stats
+
+
+def bn_backward(z, dy, y_out, mean, invstd, gamma, relu):
+    """Returns (dz, dgamma, dbeta) for y = relu?(gamma*(z-mean)*invstd + beta)."""
+    z_cs, dy_cs = require_nhwc(z, "z"), require_nhwc(dy, "dy")
+    C = z.shape[1]
+    y_cs = require_nhwc(y_out, "y_out") if relu else 0
+    red = torch.zeros(2 * C, dtype=torch.float32, device=z.device)
+    dt = dtype_code(z.dtype)
+    call("fs_bn_bwd_reduce", _stream(), _pix(z), C, _p(z), z_cs, _p(dy), dy_cs, _p(y_out) if relu else None, y_cs, _p(mean),
+         _p(invstd), dt, int(relu), _p(red))
+    dz = empty_nhwc(z.shape[0], C, z.shape[2], z.shape[3], z.dtype, z.device)
+    call("fs_bn_bwd_apply", _stream(), _pix(z), C, _p(z), z_cs, _p(dy), dy_cs, _p(y_out) if relu else None, y_cs, _p(mean),
+         _p(invstd), _p(gamma), _p(red), _pix(z), dt, int(relu), _p(dz), channel_stride(dz))
+    return dz, red[C:], red[:C]
+
+
+def copy_channels(x, out):
+    call("fs_copy_channels", _stream(), _pix(x), x.shape[1], _p(x), require_nhwc(x, "x"), _p(out), require_nhwc(out, "out"),
+         dtype_code(x.dtype))
+    return out
+
+
+def axpy(x, alpha, out, accumulate):
+    """out (+)= alpha * x, alpha a 1-element fp32 device tensor."""
+    call("fs_axpy_channels", _stream(), _pix(x), x.shape[1], _p(x), require_nhwc(x, "x"), _p(alpha), _p(out),
+         require_nhwc(out, "out"), dtype_code(x.dtype), int(accumulate))
+    return out
+
+
+def dot(x, y):
+    out = torch.zeros(1, dtype=torch.float32, device=x.device)
+    call("fs_dot", _stream(), _pix(x), x.shape[1], _p(x), require_nhwc(x, "x"), _p(y), require_nhwc(y, "y"),
+         dtype_code(x.dtype), _p(out))
+    return out
+
+
+def cat_channels(tensors):
+    """torch.cat(dim=1) for NHWC views (model_seg.py:307-331): one fs_copy_channels per operand."""
+    N, _, H, W = tensors[0].shape
+    total = sum(t.shape[1] for t in tensors)
+    out = empty_nhwc(N, total, H, W, tensors[0].dtype, tensors[0].device)
+    off = 0
+    for t in tensors:
+        copy_channels(t, out[:, off:off + t.shape[1]])
+        off += t.shape[1]
+    return out

@@ -1,0 +1,143 @@
+/*
+ * fasterseg_hip.h — C ABI of libfasterseg_hip.so: the MI355X (gfx950) kernels behind FasterSeg's
+ * multi-resolution conv hot path.
+ *
+ * The reference has no FFI: its operator library (search/operations.py, slimmable_ops.py, seg_oprs.py)
+ * calls torch.nn.Conv2d / F.conv2d / nn.BatchNorm2d / F.interpolate / torch.cat, i.e. cuDNN/ATen kernels
+ * (SURVEY.md §2 "implicit device-kernel inventory").  Each entry point below replaces one of those
+ * library calls; the "replaces" note cites the reference call sites.  The Python side
+ * (fasterseg_amd/_lib.py) binds these with ctypes; see INTEGRATION.md for the stub a reference
+ * maintainer would add.
+ *
+ * Conventions
+ *  - Plain C: pointers are raw device pointers, sizes are ints, no torch types.
+ *  - Activations are NHWC.  Every activation argument is (pointer, channel-stride): the pointer is
+ *    already offset to the first channel of the slice and `*_cs` is the number of elements between
+ *    consecutive pixels, so an operand can be a channel slice of a wider buffer (torch.cat fused away).
+ *    All slices must start on a 16-byte boundary and have C % FS_VEC == 0 unless stated otherwise.
+ *  - dtype: FS_F32 (fp32 storage, exact-fp32 MFMA) or FS_BF16 (bf16 storage, fp32 accumulate).
+ *    scale/shift/bias/statistics are always fp32.
+ *  - Every call only enqueues work on `stream` (a hipStream_t passed as void*) and returns; no
+ *    allocation, no synchronisation, safe under hipGraph capture.
+ *  - Return value: FS_OK or an error code; fs_last_error() gives a thread-local message.  Nothing
+ *    aborts the process (the reference evaluator runs models in spawned workers, evaluator.py:128-157).
+ */
+#ifndef FASTERSEG_HIP_H
+#define FASTERSEG_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { FS_OK = 0, FS_ERR_INVALID = 1, FS_ERR_UNSUPPORTED = 2, FS_ERR_LAUNCH = 3 } fs_status;
+typedef enum { FS_F32 = 0, FS_BF16 = 1 } fs_dtype;
+
+/* flags for fs_conv_desc.flags */
+#define FS_CONV_RELU        1   /* y = max(y, 0) after scale/shift            (nn.ReLU, operations.py:74,147) */
+#define FS_CONV_TRANSPOSED  2   /* gather for the data gradient of a stride-2 conv (conv2d backward-input)   */
+#define FS_CONV_ACCUM       4   /* y += result (fp32 only), used by split accumulations                       */
+
+typedef struct fs_conv_desc {
+    int N, H, W, Cin;       /* input  (N,H,W,Cin)                                        */
+    int Cout, R, S;         /* filter (Cout,R,S,Cin), R,S in {1,3}                       */
+    int stride, pad;        /* stride in {1,2}                                           */
+    int Ho, Wo;             /* output spatial size                                       */
+    int x_cs, y_cs;         /* channel strides (elements per pixel) of x and y buffers   */
+    int dtype;              /* fs_dtype of x, w, y                                       */
+    int flags;              /* FS_CONV_*                                                 */
+} fs_conv_desc;
+
+typedef struct fs_resize_desc {
+    int N, Hi, Wi, Ho, Wo, C;
+    int x_cs, y_cs;
+    int dtype;
+    int relu;               /* fuse ReLU after the interpolation (operations.py:275-276,444-445) */
+    int out_nchw;           /* 1: y is a contiguous NCHW tensor (final logits, model_seg.py:365); C arbitrary */
+} fs_resize_desc;
+
+const char* fs_last_error(void);
+int fs_version(void);
+/* number of elements of a packed filter bank for (Cout,R,S,Cin) */
+long long fs_packed_weight_elems(int Cout, int R, int S, int Cin);
+
+/* --- weights ---------------------------------------------------------------------------------- */
+/* Pack an OIHW fp32 filter (nn.Conv2d.weight, possibly a USConv2d slice weight[:Cout,:Cin] —
+ * slimmable_ops.py:42 — addressed by its element strides o_stride/i_stride; the R*S taps are
+ * contiguous) into the kernel's [Cout][R][S][Cin] layout in `dtype`.
+ * transpose_flip=1 produces the filter of the data-gradient convolution:
+ * out[ci][R-1-r][S-1-s][co] = w[co][ci][r][s]. */
+fs_status fs_pack_weight(void* stream, const float* w_oihw, long long o_stride, long long i_stride,
+                         int Cout, int Cin, int R, int S, int dtype, int transpose_flip, void* w_packed);
+/* inverse for gradients: dW packed fp32 [Cout][R][S][Cin] -> OIHW fp32 (strided), dst (+)= src */
+fs_status fs_unpack_weight_grad(void* stream, const float* dw_packed, int Cout, int Cin, int R, int S,
+                                float* dw_oihw, long long o_stride, long long i_stride, int accumulate);
+
+/* --- convolution ------------------------------------------------------------------------------ */
+/* Replaces nn.Conv2d / F.conv2d forward (operations.py:78,149-152,221-224,298-306,380-388,461-473;
+ * slimmable_ops.py:47; seg_oprs.py:22,245) with the eval-mode BatchNorm affine, classifier bias and
+ * ReLU fused into the epilogue: y = relu?(conv(x,w) * scale[c] + shift[c]).
+ * scale/shift may be NULL (identity / zero).  If `stats` is non-NULL (train-mode BN), the kernel also
+ * accumulates per-channel sum and sum-of-squares of the *pre-scale* conv output into
+ * stats[0..Cout) and stats[Cout..2*Cout) with atomics (caller zeroes it). */
+fs_status fs_conv2d_fwd(void* stream, const fs_conv_desc* d, const void* x, const void* w_packed,
+                        const float* scale, const float* shift, void* y, float* stats);
+
+/* Replaces conv2d backward-weight: dw[co][r][s][ci] = sum_pixels dy[p][co] * x[p@(r,s)][ci], fp32 packed
+ * output (caller zeroes; split-K atomics).  `d` is the forward descriptor. */
+fs_status fs_conv2d_wgrad(void* stream, const fs_conv_desc* d, const void* x, const void* dy, float* dw_packed);
+
+/* Stem convolution (model_seg.py:193): NCHW fp32 image (Cin=3) -> NHWC `dtype`, 3x3 stride 2 pad 1, fused
+ * scale/shift/ReLU.  w_packed is [Cout][3][3][3] fp32. */
+fs_status fs_conv_stem_fwd(void* stream, int N, int H, int W, int Cout, const float* x_nchw, const float* w_packed,
+                           const float* scale, const float* shift, void* y, int y_cs, int dtype, int relu);
+
+/* --- bilinear resize, align_corners=True -------------------------------------------------------- */
+/* Replaces F.interpolate(mode='bilinear', align_corners=True) (operations.py:271,275,437,444;
+ * model_seg.py:305,310,317,359-365; model_search.py:339-357). */
+fs_status fs_bilinear_fwd(void* stream, const fs_resize_desc* d, const void* x, void* y);
+/* backward: dx (+)= transpose-of-interpolation(dy); relu mask taken from y_out when d->relu. dx is zeroed by the
+ * kernel's gather formulation (no atomics). `y_out` may be NULL when relu==0. */
+fs_status fs_bilinear_bwd(void* stream, const fs_resize_desc* d, const void* dy, const void* y_out, void* dx);
+
+/* --- batch norm (train mode) and elementwise ------------------------------------------------------ */
+/* Replaces nn.BatchNorm2d in training mode (operations.py:39,80; slimmable_ops.py:58-70).
+ * fs_bn_finalize turns (sum,sumsq) over `count` elements per channel into mean/invstd, the folded
+ * scale = gamma*invstd, shift = beta-mean*scale, and updates running stats with `momentum`
+ * (unbiased variance, as torch). */
+fs_status fs_bn_finalize(void* stream, int C, long long count, const float* stats, const float* gamma,
+                         const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                         float* mean, float* invstd, float* scale, float* shift);
+/* y = relu?(x*scale[c]+shift[c]) over an NHWC tensor (in place allowed). */
+fs_status fs_affine_act(void* stream, long long pixels, int C, const void* x, int x_cs, const float* scale,
+                        const float* shift, void* y, int y_cs, int dtype, int relu);
+/* per-channel sum / sumsq of an NHWC tensor (for BN after an op that is not a conv, e.g. the channel
+ * concat of FactorizedReduce, operations.py:523-524). stats is accumulated (caller zeroes). */
+fs_status fs_channel_stats(void* stream, long long pixels, int C, const void* x, int x_cs, int dtype, float* stats);
+/* BN(+ReLU) backward, two passes.
+ * pass 1: red[0..C)=sum(dz), red[C..2C)=sum(dz*xhat) where dz = dy * (y>0 if relu) and xhat=(x-mean)*invstd.
+ * pass 2: dx = gamma*invstd*(dz - red0/count - xhat*red1/count). */
+fs_status fs_bn_bwd_reduce(void* stream, long long pixels, int C, const void* x, int x_cs, const void* dy, int dy_cs,
+                           const void* y_out, int y_cs, const float* mean, const float* invstd, int dtype, int relu,
+                           float* red);
+fs_status fs_bn_bwd_apply(void* stream, long long pixels, int C, const void* x, int x_cs, const void* dy, int dy_cs,
+                          const void* y_out, int y_cs, const float* mean, const float* invstd, const float* gamma,
+                          const float* red, long long count, int dtype, int relu, void* dx, int dx_cs);
+
+/* --- layout / copies ------------------------------------------------------------------------------ */
+/* NCHW contiguous fp32 <-> NHWC (dtype) with channel stride; C arbitrary (zero-fills up to c_pad on the way in). */
+fs_status fs_nchw_to_nhwc(void* stream, int N, int C, int H, int W, const float* x, void* y, int y_cs, int c_pad, int dtype);
+fs_status fs_nhwc_to_nchw(void* stream, int N, int C, int H, int W, const void* x, int x_cs, int dtype, float* y);
+/* copy a channel slice (torch.cat, model_seg.py:307-331; operations.py:523): y[p][0..C) = x[p][0..C) */
+fs_status fs_copy_channels(void* stream, long long pixels, int C, const void* x, int x_cs, void* y, int y_cs, int dtype);
+/* y[p][c] (+)= alpha * x[p][c]  (MixedOp / beta weighted sums, model_search.py:76-78,330-333). alpha is a device
+ * pointer to one float (keeps arch params on device); accumulate=0 overwrites. */
+fs_status fs_axpy_channels(void* stream, long long pixels, int C, const void* x, int x_cs, const float* alpha,
+                           void* y, int y_cs, int dtype, int accumulate);
+/* full-tensor dot product sum(x*y) -> out[0] (+=), the gradient of a scalar architecture weight. */
+fs_status fs_dot(void* stream, long long pixels, int C, const void* x, int x_cs, const void* y, int y_cs, int dtype,
+                 float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FASTERSEG_HIP_H */
