@@ -9,6 +9,8 @@ Each Function is one fused unit of the hot path (forward and backward both run o
   scale_accumulate  acc + coef * x with a device-resident scalar coef               model_search.py:76-78,330-333
 There is no eager/ATen fallback: inputs that are not NHWC views are converted with fs_nchw_to_nhwc.
 """
+import weakref
+
 import torch
 
 from . import kernels as K
@@ -27,26 +29,60 @@ def get_compute_dtype():
     return _compute_dtype
 
 
+class _ToNHWC(torch.autograd.Function):
+    """Layout change at the boundary (fs_nchw_to_nhwc); the gradient flows back unchanged (same logical shape)."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.in_dtype = x.dtype
+        return K.to_nhwc(x, dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return (dy if dy.dtype == ctx.in_dtype else dy.to(ctx.in_dtype)), None
+
+
 def as_nhwc(x, dtype=None):
-    if K.is_nhwc(x) and (dtype is None or x.dtype == dtype):
+    """`x` as an NHWC view of `dtype` (default: keep an NHWC operand's dtype, else the compute dtype)."""
+    if dtype is None:
+        dtype = x.dtype if K.is_nhwc(x) else _compute_dtype
+    if K.is_nhwc(x, dtype):
         return x
-    return K.to_nhwc(x, dtype or (x.dtype if x.dtype in (torch.float32, torch.bfloat16) and K.is_nhwc(x) else _compute_dtype))
+    if x.requires_grad and torch.is_grad_enabled():
+        return _ToNHWC.apply(x, dtype)
+    return K.to_nhwc(x, dtype)
 
 
 # ---------------------------------------------------------------------------------------------------
 # packed-filter cache: re-pack only when the parameter changed (optimizer steps bump Tensor._version)
 # ---------------------------------------------------------------------------------------------------
-_pack_cache = {}
+_pack_cache = {}     # id(parameter) -> (weakref to it, {"stamp": (ptr, version), key: packed})
+
+
+def _pack_entry(weight):
+    """Cache record of one parameter *object* (identity, not value: tensors do not compare as keys).  A cache keyed on
+    data_ptr alone would alias freed-and-reused memory; the weakref both validates identity and evicts on death."""
+    k = id(weight)
+    rec = _pack_cache.get(k)
+    if rec is None or rec[0]() is not weight:
+        rec = (weakref.ref(weight, lambda _, k=k: _pack_cache.pop(k, None)), {"stamp": None})
+        _pack_cache[k] = rec
+    return rec[1]
 
 
 def packed_weight(weight, dtype, cout=None, cin=None, flip=False, rows=None):
-    key = (weight.data_ptr(), weight._version, tuple(weight.shape), dtype, cout, cin, flip, rows)
-    hit = _pack_cache.get(key)
+    """Packed copy of (a leading block of) an OIHW parameter; re-packed only when the parameter's storage or version
+    counter changed (optimizer steps bump Tensor._version)."""
+    entry = _pack_entry(weight)
+    stamp = (weight.data_ptr(), weight._version)
+    if entry["stamp"] != stamp:
+        entry.clear()
+        entry["stamp"] = stamp
+    key = (dtype, cout, cin, flip, rows)
+    hit = entry.get(key)
     if hit is None:
-        if len(_pack_cache) > 8192:
-            _pack_cache.clear()
         hit = K.pack_weight(weight.detach(), dtype, cout, cin, flip, rows)
-        _pack_cache[key] = hit
+        entry[key] = hit
     return hit
 
 
@@ -69,8 +105,8 @@ def _weight_grad(weight, dw_packed, cout, cin):
 
 def _dgrad(dz, weight, cin, R, S, stride, pad, in_hw, rows=None):
     """data gradient: conv of dz with the 180-degree-rotated, IO-transposed filter (zero insertion for stride 2)."""
-    cout = dz.shape[1]
-    wf = packed_weight(weight, dz.dtype, cout if rows is None else min(cout, weight.shape[0]), cin, flip=True)
+    cout = dz.shape[1] if rows is None else min(dz.shape[1], weight.shape[0])
+    wf = packed_weight(weight, dz.dtype, cout, cin, flip=True)
     if rows is not None and rows != wf.shape[-1]:          # channel-padded dz (classifier): pad the contraction dim
         wfp = torch.zeros(wf.shape[:-1] + (rows,), dtype=wf.dtype, device=wf.device)
         wfp[..., :wf.shape[-1]] = wf
@@ -172,12 +208,10 @@ class _StemConvBNAct(torch.autograd.Function):
             K.unpack_weight_grad(dw, gpad, weight.shape[0], vec)
             gw = gpad[:, :3].contiguous()
         if ctx.needs_input_grad[0]:
-            wpad = torch.zeros((vec, 3, 3, 3), dtype=torch.float32, device=weight.device).permute(0, 3, 1, 2)
-            # data gradient with Cout(dgrad)=3: generic transposed conv, output channel-padded then repacked to NCHW
-            wf = K.pack_weight(weight.detach(), z.dtype, flip=True)          # [3][3][3][cout]
+            # data gradient with 3 output channels: generic transposed conv into a channel-padded buffer, then NCHW
+            wf = packed_weight(weight, z.dtype, flip=True)                    # [3][3][3][cout]
             dx = K.conv2d(dz, wf, 3, 3, 3, 1, 1, transposed=True, out_hw=(xc.shape[2], xc.shape[3]))
             gx = K.to_nchw(dx)
-            del wpad
         return gx, gw, dgamma, dbeta, None, None, None
 
 
@@ -190,53 +224,66 @@ CLS_PAD = 32   # classifier logits live in a 32-channel NHWC buffer (19 valid, p
 
 
 class _ConvBias(torch.autograd.Function):
-    """Biased 1x1 (or 3x3) conv without BN: Head.conv_1x1 (seg_oprs.py:245) and plain nn.Conv2d."""
+    """Conv without BN, optional bias: Head.conv_1x1 (seg_oprs.py:245), plain nn.Conv2d and a bare USConv2d slice."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad):
-        cout, cin, R, S = weight.shape
+    def forward(ctx, x, weight, bias, cfg):
+        stride, pad, cout, cin = cfg
+        R, S = weight.shape[2], weight.shape[3]
+        assert x.shape[1] == cin, "input has %d channels, conv expects %d" % (x.shape[1], cin)
         vec = K.vec_of(x.dtype)
         cpad = cout if cout % vec == 0 else K.round_up(cout, CLS_PAD)
-        wp = packed_weight(weight, x.dtype)
+        wp = packed_weight(weight, x.dtype, cout, cin)
         N, _, H, W = x.shape
         Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
         buf = K.empty_nhwc(N, cpad, Ho, Wo, x.dtype, x.device, zero=(cpad != cout))
         y = buf[:, :cout]
-        shift = bias.detach().float().contiguous() if bias is not None else None
+        shift = bias.detach().float()[:cout].contiguous() if bias is not None else None
         K.conv2d(x, wp, cout, R, S, stride, pad, None, shift, False, out=y)
         ctx.save_for_backward(x, weight)
-        ctx.meta = (stride, pad, cpad, bias is not None)
+        ctx.meta = (stride, pad, cpad, bias is not None, cout, cin)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
-        stride, pad, cpad, has_bias = ctx.meta
-        cout, cin, R, S = weight.shape
+        stride, pad, cpad, has_bias, cout, cin = ctx.meta
+        R, S = weight.shape[2], weight.shape[3]
         N, _, Ho, Wo = dy.shape
         if cpad != cout:        # widen the gradient to the padded channel count (pad lanes zero)
-            dyp = K.empty_nhwc(N, cpad, Ho, Wo, x.dtype, x.device, zero=True)
-            if K.is_nhwc(dy, x.dtype) and K.channel_stride(dy) == cpad:
-                dyp = dy.as_strided((N, cpad, Ho, Wo), dy.stride(), dy.storage_offset())   # already the padded buffer
+            if K.is_nhwc(dy, x.dtype) and K.channel_stride(dy) == cpad and dy.storage_offset() * dy.element_size() % 16 == 0:
+                dyp = dy.as_strided((N, cpad, Ho, Wo), dy.stride(), dy.storage_offset())   # already a padded buffer
             else:
+                dyp = K.empty_nhwc(N, cpad, Ho, Wo, x.dtype, x.device, zero=True)
                 dyp[:, :cout].copy_(dy)
         else:
             dyp = as_nhwc(dy, x.dtype)
         gw = gb = gx = None
         if ctx.needs_input_grad[1]:
             dw = K.conv2d_wgrad(x, dyp, R, S, stride, pad)
-            gfull = torch.zeros((cpad, cin, R, S), dtype=torch.float32, device=x.device)
-            K.unpack_weight_grad(dw, gfull, cpad, cin)
-            gw = gfull[:cout].contiguous()
+            if cpad != cout:
+                gfull = torch.zeros((cpad, cin, R, S), dtype=torch.float32, device=x.device)
+                K.unpack_weight_grad(dw, gfull, cpad, cin)
+                gw = torch.zeros_like(weight, dtype=torch.float32)
+                gw[:cout, :cin] = gfull[:cout]
+            else:
+                gw = _weight_grad(weight, dw, cout, cin)
         if has_bias and ctx.needs_input_grad[2]:
             gb = K.channel_stats(dyp)[:cout].clone()
         if ctx.needs_input_grad[0]:
             gx = _dgrad(dyp, weight, cin, R, S, stride, pad, (x.shape[2], x.shape[3]), rows=cpad)
-        return gx, gw, gb, None, None
+        return gx, gw, gb, None
 
 
-def conv_bias(x, weight, bias, stride=1, pad=0):
-    return _ConvBias.apply(as_nhwc(x), weight, bias, stride, pad)
+def conv_bias(x, weight, bias, stride=1, pad=0, cout=None, cin=None):
+    cout = weight.shape[0] if cout is None else cout
+    cin = weight.shape[1] if cin is None else cin
+    return _ConvBias.apply(as_nhwc(x), weight, bias, (stride, pad, cout, cin))
+
+
+def conv_slice(x, weight, cout, cin, stride, pad):
+    """Bias-free conv on the leading [:cout,:cin] block of `weight` (USConv2d.forward, slimmable_ops.py:42-47)."""
+    return conv_bias(x, weight, None, stride, pad, cout, cin)
 
 
 class _FactorizedReduce(torch.autograd.Function):

@@ -264,29 +264,34 @@ def gen_nets():
                                                          float(y.double().sum())])
             store["arch%d_eval/argmax_sub" % idx] = _np(y.argmax(1)[:, ::2, ::2]).astype(np.uint8)
             print("arch%d eval logits" % idx, tuple(y.shape), store["arch%d_eval/stats" % idx])
-        # student train-mode forward/backward (3 heads) at a small crop
+        # student train-mode forward/backward (3 heads) at a small crop.  Run in fp32 (what the reference does) AND
+        # in fp64 with the same reference modules: batch-statistics BN on maps as small as 1x2 makes individual
+        # gradient elements sensitive to 1e-7 rounding (ReLU-mask flips), so the fp64 run is the pin for gradients.
         state = torch.load(os.path.join(wd, "fasterseg", "arch_1.pt"), map_location="cpu", weights_only=False)
-        net = build_ref_net(model_seg, state, 1, [2, 1], True)
-        _load_seeded(net, 12345)
-        net.train()
-        x = seeded_input((2, 3, 64, 128), 6).requires_grad_(True)
-        p8, p16, p32 = net(x)
-        loss = (p8 * seeded_input(tuple(p8.shape), 7)).sum() + 0.2 * (p16 * seeded_input(tuple(p16.shape), 8)).sum() \
-            + 0.2 * (p32 * seeded_input(tuple(p32.shape), 9)).sum()
-        loss.backward()
-        store["arch1_train/p8_sub"] = _np(p8[:, :, ::4, ::4])
-        store["arch1_train/p16_sub"] = _np(p16[:, :, ::4, ::4])
-        store["arch1_train/p32_sub"] = _np(p32[:, :, ::4, ::4])
-        store["arch1_train/loss"] = np.array([float(loss)])
-        store["arch1_train/gx"] = _np(x.grad)
-        norms = {k: float(p.grad.norm()) for k, p in net.named_parameters() if p.grad is not None}
-        for k in ("stem.0.conv.0.weight", "cells.3-0._op._op.conv1.weight", "heads8.conv_1x1.weight",
-                  "heads8.conv_1x1.bias", "cells.9-0._op._op.bn2.weight", "refines32.0.conv.0.weight",
-                  "ffm.conv_1x1.bn.bias"):
-            store["arch1_train/g/" + k] = _np(dict(net.named_parameters())[k].grad)
-        with open(os.path.join(GOLD, "arch1_train_gradnorms.json"), "w") as f:
-            json.dump(norms, f)
-        print("arch1 train loss", float(loss))
+        for tag, dt in (("arch1_train", torch.float32), ("arch1_train64", torch.float64)):
+            net = build_ref_net(model_seg, state, 1, [2, 1], True)
+            _load_seeded(net, 12345)
+            net = net.to(dt)
+            net.train()
+            x = seeded_input((2, 3, 128, 256), 6).to(dt).requires_grad_(True)
+            p8, p16, p32 = net(x)
+            loss = (p8 * seeded_input(tuple(p8.shape), 7).to(dt)).sum() \
+                + 0.2 * (p16 * seeded_input(tuple(p16.shape), 8).to(dt)).sum() \
+                + 0.2 * (p32 * seeded_input(tuple(p32.shape), 9).to(dt)).sum()
+            loss.backward()
+            store[tag + "/p8_sub"] = _np(p8[:, :, ::4, ::4]).astype(np.float32)
+            store[tag + "/p16_sub"] = _np(p16[:, :, ::4, ::4]).astype(np.float32)
+            store[tag + "/p32_sub"] = _np(p32[:, :, ::4, ::4]).astype(np.float32)
+            store[tag + "/loss"] = np.array([float(loss.detach())])
+            _put(store, tag + "/gx", x.grad.float())
+            norms = {k: float(p.grad.norm()) for k, p in net.named_parameters() if p.grad is not None}
+            for k in ("stem.0.conv.0.weight", "cells.3-0._op._op.conv1.weight", "heads8.conv_1x1.weight",
+                      "heads8.conv_1x1.bias", "cells.9-0._op._op.bn2.weight", "refines32.0.conv.0.weight",
+                      "ffm.conv_1x1.bn.bias", "heads16.conv_3x3.bn.bias", "stem.2.bn2.weight"):
+                _put(store, tag + "/g/" + k, dict(net.named_parameters())[k].grad.float())
+            with open(os.path.join(GOLD, tag + "_gradnorms.json"), "w") as f:
+                json.dump(norms, f)
+            print(tag, "loss", float(loss.detach()))
     np.savez_compressed(os.path.join(GOLD, "nets.npz"), **store)
 
 

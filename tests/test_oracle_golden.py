@@ -76,14 +76,15 @@ def test_oracle_student_train_step():
     store = load_npz("nets.npz")
     params = resolve_aliases(seeded_state(shapes_template(meta["state_shapes"]), 12345), meta)
     params = {k: v.requires_grad_(v.is_floating_point() and "running" not in k) for k, v in params.items()}
-    x = seeded_input((2, 3, 64, 128), 6).requires_grad_(True)
+    x = seeded_input((2, 3, 128, 256), 6).requires_grad_(True)
     p8, p16, p32 = ref_ops.derived_forward(params, meta, x, training=True)
     loss = (p8 * seeded_input(tuple(p8.shape), 7)).sum() + 0.2 * (p16 * seeded_input(tuple(p16.shape), 8)).sum() \
         + 0.2 * (p32 * seeded_input(tuple(p32.shape), 9)).sum()
     loss.backward()
     assert abs(float(loss) - float(store["arch1_train/loss"][0])) < 2e-2
     assert_close_golden(p8[:, :, ::4, ::4], store, "arch1_train/p8_sub", 1e-3, 1e-3)
-    assert_close_golden(x.grad, store, "arch1_train/gx", 2e-3, 2e-3)
+    assert_close_golden(x.grad, store, "arch1_train/gx", 2e-3 * float(x.grad.abs().max()), 2e-3)
     for k in store:
         if k.startswith("arch1_train/g/"):
-            assert_close_golden(params[k[len("arch1_train/g/"):]].grad, store, k, 5e-3, 5e-3)
+            pname = k[len("arch1_train/g/"):].split("@")[0]
+            assert_close_golden(params[pname].grad, store, "arch1_train/g/" + pname, 5e-3, 5e-3)
