@@ -1,0 +1,204 @@
+"""bench.py — headline benchmark of the FasterSeg hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|fp32] [--workload student_infer|student_train]
+
+Default workload = BASELINE.json configs[1]: searched student (arch_1) inference at 1x3x1024x2048, bf16 storage /
+fp32 accumulate, one frame per step, input already resident in HBM, whole forward replayed from one hipGraph
+(fasterseg_amd.engine).  N>1 (launched by torch.distributed.run, one rank per GPU) runs one replica per GPU — inference
+does not shard, so there is no data-path collective; value = frames of all ranks / max-over-ranks time ("weak").
+`--workload student_train` runs BASELINE configs[3]-shaped student KL-distillation steps (teacher eval forward + student
+train forward/backward + RCCL gradient all-reduce + SGD) and reports images/s.
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel family of the step, from per-launch HIP-event
+timings taken live on the launch stream (engine.profile()); `cpu_baseline` is the CPU oracle (oracle/ref_ops.py, a
+port of the reference's module code on torch-CPU kernels) timed on this host on a bounded number of frames.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}      # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+PUBLISHED_STUDENT_FPS = 163.9                        # BASELINE.md §1 (GTX 1080Ti + TensorRT fp32, latency/ variant)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--workload", default="student_infer", choices=["student_infer", "student_train"])
+    ap.add_argument("--height", type=int, default=1024)
+    ap.add_argument("--width", type=int, default=2048)
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 1 for inference, 12 for training)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU budget of the cpu_baseline sample")
+    ap.add_argument("--dump-plan", default=None, help="write the per-launch table (json) here")
+    return ap.parse_args()
+
+
+def dist_setup(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    else:
+        torch.cuda.set_device(0)
+    assert world == args.gpus or world == 1, "WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
+    return world, rank, local
+
+
+def barrier(world):
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.zeros(1, device="cuda")
+        dist.all_reduce(t)
+    torch.cuda.synchronize()
+
+
+def max_over_ranks(value, world):
+    if world == 1:
+        return value
+    import torch.distributed as dist
+    t = torch.tensor([value], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def roofline_from_profile(rows, dtype):
+    fam = {}
+    for r in rows:
+        f = fam.setdefault(r["family"], dict(ms=0.0, flops=0.0, bytes=0.0, n=0))
+        f["ms"] += r["ms"]; f["flops"] += r["flops"]; f["bytes"] += r["bytes"]; f["n"] += 1
+    total_ms = sum(f["ms"] for f in fam.values())
+    name, dom = max(fam.items(), key=lambda kv: kv[1]["ms"])
+    avg_ms = dom["ms"] / dom["n"]
+    out = {"kernel": name, "launches_per_step": dom["n"], "avg_launch_us": round(avg_ms * 1e3, 3),
+           "share_of_kernel_time": round(dom["ms"] / total_ms, 4), "traffic": None}
+    if name.startswith("conv"):
+        ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        out.update(bound="mfma", achieved=round(ach, 2), peak=PEAK_TFLOPS[dtype], unit="TFLOP/s", frac=round(ach / PEAK_TFLOPS[dtype], 4),
+                   alg_flops_per_launch=dom["flops"] / dom["n"], alg_bytes_per_launch=dom["bytes"] / dom["n"],
+                   achieved_GBps=round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9, 1))
+    else:
+        ach = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
+        out.update(bound="hbm", achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(ach / PEAK_HBM_GBS, 4),
+                   alg_bytes_per_launch=dom["bytes"] / dom["n"])
+    traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # HBM bytes/launch from rocprofv3 --pmc passes
+    if os.path.exists(traffic_file):
+        try:
+            with open(traffic_file) as f:
+                t = json.load(f)
+            out["traffic"] = t.get(dtype, {}).get(name)
+        except Exception:
+            pass
+    families = {k: {"ms": round(v["ms"], 4), "launches": v["n"], "TFLOPs": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else 0.0,
+                    "GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)} for k, v in fam.items()}
+    return out, families, total_ms
+
+
+def cpu_baseline_infer(shape, budget_s):
+    """The CPU oracle (port of the reference modules on torch-CPU kernels) on the same workload, bounded sample."""
+    from oracle import ref_ops
+    from oracle.seeded import resolve_aliases, seeded_state
+    with open(os.path.join(ROOT, "tests", "golden", "arch_1.json")) as f:
+        meta = json.load(f)["eval_21"]
+    params = resolve_aliases(seeded_state({k: torch.empty(v) for k, v in meta["state_shapes"].items()}, 12345), meta)
+    x = torch.randn(*shape)
+    cores = torch.get_num_threads()
+    with torch.no_grad():
+        ref_ops.derived_forward(params, meta, x)           # warm-up
+        n, t0 = 0, time.perf_counter()
+        while True:
+            ref_ops.derived_forward(params, meta, x)
+            n += 1
+            el = time.perf_counter() - t0
+            if el >= budget_s or n >= 50:
+                break
+    return {"value": round(n / el, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "%d frames of %dx3x%dx%d fp32, oracle/ref_ops.derived_forward (arch_1 eval build), %.1f s" % (
+                n, shape[0], shape[2], shape[3], el)}
+
+
+def run_student_infer(args, world, rank):
+    from fasterseg_amd import archs, engine
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    batch = args.batch or 1
+    shape = (batch, 3, args.height, args.width)
+    net = archs.build_derived(1, training=False)          # eval build, branches chosen by objective_acc_lat -> [2, 1]
+    archs.init_weight(net, seed=12345)
+    net = net.cuda().eval()
+    eng = engine.InferenceEngine(net, shape, dtype=dtype, logits_dtype=torch.float32)
+    eng.input.copy_(torch.randn(shape, generator=torch.Generator().manual_seed(rank)).cuda())
+    for _ in range(args.warmup):
+        eng.run()
+    barrier(world)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.run()
+    barrier(world)
+    elapsed = max_over_ranks(time.perf_counter() - t0, world)
+    fps = world * batch * args.steps / elapsed
+    line = {
+        "metric": "supernet train-step images/sec @1024x2048 (1/2/4/8 GPU) + student fps",
+        "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": round(fps / world / PUBLISHED_STUDENT_FPS, 3) if (args.height, args.width, batch) == (1024, 2048, 1) else None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "student fps: searched arch_1 (eval build, branches 1/32+1/16) inference %dx3x%dx%d, 19 classes, "
+                               "fp32 logits at input resolution" % (shape[0], shape[2], shape[3]),
+                   "weights": "random kaiming init, seed 12345", "parallelism": "replicas x%d (no collective)" % world,
+                   "engine": "static plan of %d launches in one hipGraph" % len(eng.calls),
+                   "vs_baseline_note": "per-GPU fps / 163.9 FPS published on GTX 1080Ti+TensorRT fp32 (nearest-resample "
+                                       "latency/ variant); this run is the bilinear train/ network"},
+        "alg_gflop_per_frame": round(eng.total_flops / batch / 1e9, 3), "alg_mb_per_frame": round(eng.total_bytes / batch / 1e6, 1),
+    }
+    if rank == 0 and not args.no_roofline:
+        rows = eng.profile()
+        roof, families, total_ms = roofline_from_profile(rows, args.dtype)
+        line["roofline"] = roof
+        line["kernel_families"] = families
+        line["sum_kernel_ms"] = round(total_ms, 4)
+        if args.dump_plan:
+            with open(args.dump_plan, "w") as f:
+                json.dump(rows, f, indent=1)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline_infer(shape, args.cpu_seconds)
+    return line
+
+
+def run_student_train(args, world, rank):
+    from fasterseg_amd import train_step
+    return train_step.bench_student_train(args, world, rank, barrier, max_over_ranks)
+
+
+def main():
+    args = parse()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
+    world, rank, _ = dist_setup(args)
+    line = run_student_infer(args, world, rank) if args.workload == "student_infer" else run_student_train(args, world, rank)
+    if rank == 0:
+        print(json.dumps(line))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -50,6 +50,7 @@ _SPECIAL = {
     "fs_last_error": ([], ctypes.c_char_p),
     "fs_version": ([], c_int),
     "fs_packed_weight_elems": ([c_int, c_int, c_int, c_int], c_ll),
+    "fs_debug_force_conv_cfg": ([c_int], None),
 }
 ALL_SYMBOLS = sorted(list(SIGNATURES) + list(_SPECIAL))
 

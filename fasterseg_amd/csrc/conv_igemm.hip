@@ -4,15 +4,18 @@
 //               m = output pixel (n,oh,ow)   n = output channel   k = (r,s,cin) flattened, cin fastest
 //   A is gathered on the fly from the NHWC input (zero for padding), B is the packed filter bank.
 //
-// Block = 256 threads = 4 wave64.  Each K-chunk is 64 bytes of K per row (16 fp32 / 32 bf16), staged
-// global -> registers -> LDS (issue-early / write-late, guide T14): the loads of chunk t+1 are in flight
-// while the MFMAs of chunk t run.  LDS rows are 64 data bytes + 16 pad bytes (80 B) so that the
-// ds_read_b128 fragment reads of 16 distinct rows land on 16 distinct 16-byte slots (conflict-free).
-// fp32 uses v_mfma_f32_32x32x2_f32 (exact fp32, k order permuted inside a 16-byte vector, which is
-// legal because A and B use the same permutation); bf16 uses v_mfma_f32_32x32x16_bf16.
-// Epilogue fuses: per-channel sum/sumsq for train-mode BN (wave shuffle + one atomic per channel per
-// wave), scale/shift (eval BN or bias), ReLU, and the store into a channel slice of a wider NHWC
-// buffer (torch.cat fused away).
+// Block = 256 threads = 4 wave64, arranged WAVES_M x WAVES_N x WAVES_K.  One iteration stages NSUB = WAVES_K*KSUB
+// "sub-chunks" of 64 bytes of K per tile row (16 fp32 / 32 bf16 each) global -> registers -> LDS (issue-early /
+// write-late: the loads of iteration t+1 are in flight while the MFMAs of iteration t run).  Wave (wm,wn,wk) owns a
+// WM_T x WN_T grid of 32x32 MFMA tiles and consumes sub-chunks [wk*KSUB, (wk+1)*KSUB): WAVES_K > 1 is an in-block
+// split of the K loop for the launch-latency-sized layers (maps as small as 16x32 with K = 2304) — it shortens the
+// serial K loop 4x and lets 32x32 output tiles fill the 256 CUs; the partial accumulators meet in LDS.
+// LDS rows are NSUB*64 data bytes + 16 pad bytes so the ds_read_b128 fragment reads of 16 distinct rows land on 16
+// distinct 16-byte slots.  fp32 uses v_mfma_f32_32x32x2_f32 (exact fp32; the k order inside a 16-byte vector is
+// permuted identically for A and B), bf16 uses v_mfma_f32_32x32x16_bf16.
+// Epilogue: per-channel sum/sumsq for train-mode BN (wave shuffle + one atomic per channel per wave), scale/shift
+// (eval BN or bias), ReLU, then the tile is transposed through LDS so every lane stores 16 contiguous bytes into a
+// channel slice of a (possibly wider) NHWC buffer — torch.cat fused away.
 //
 // Replaces: nn.Conv2d/F.conv2d at reference search/operations.py:78,149-152,221-224,298-306,380-388,
 // 461-473, slimmable_ops.py:47, seg_oprs.py:22,245 (+BatchNorm2d/ReLU that follow them).
@@ -34,8 +37,6 @@ struct ConvArgs {
     int tiles_n;
 };
 
-constexpr int ROWB = 80;  // LDS row pitch in bytes
-
 template <typename T> struct Mma;
 template <> struct Mma<float> {
     static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) {
@@ -51,40 +52,57 @@ template <> struct Mma<bf16_t> {
     }
 };
 
-template <typename T, int WAVES_M, int WAVES_N, int WM_T, int WN_T>
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+constexpr int CONV_SCALAR_STORE = 0x100;   // internal flag: output slice not 16-byte aligned -> element-wise epilogue
+
+template <typename T, int WAVES_M, int WAVES_N, int WAVES_K, int WM_T, int WN_T, int KSUB>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     constexpr int BM = WAVES_M * WM_T * 32;
     constexpr int BN = WAVES_N * WN_T * 32;
     constexpr int VEC = Elem<T>::VEC;
-    constexpr int BK = 4 * VEC;
-    constexpr int A_PASS = BM / 64;
-    constexpr int B_PASS = (BN + 63) / 64;
-    static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
-    static_assert(BM % 64 == 0, "BM multiple of 64");
+    constexpr int BK64 = 4 * VEC;                 // elements per 64-byte sub-chunk
+    constexpr int NSUB = WAVES_K * KSUB;
+    constexpr int BKT = NSUB * BK64;              // K elements staged per iteration
+    constexpr int PITCH = NSUB * 64 + 16;         // LDS row pitch in bytes
+    // staging map: 4 lanes per row (one 16-byte vector of each sub-chunk), 64 row slots per pass
+    constexpr int A_RPP = BM < 64 ? BM : 64, A_GROUPS = 64 / A_RPP, A_PASS = BM / A_RPP, A_SUBS = NSUB / A_GROUPS;
+    constexpr int B_RPP = BN < 64 ? BN : 64, B_GROUPS = 64 / B_RPP, B_PASS = BN / B_RPP, B_SUBS = NSUB / B_GROUPS;
+    static_assert(WAVES_M * WAVES_N * WAVES_K == 4, "4 waves per block");
+    static_assert(NSUB % A_GROUPS == 0 && NSUB % B_GROUPS == 0, "sub-chunks must divide over row groups");
+    constexpr int TILES = WM_T * WN_T;
+    constexpr int STAGE_BYTES = (BM + BN) * PITCH;
+    constexpr int RED_BYTES = (WAVES_K - 1) * WAVES_M * WAVES_N * TILES * 16 * 64 * 4;   // split-K partials
+    constexpr int OUT_PITCH = 32 * (int)sizeof(T) + 16;
+    constexpr int OUT_BYTES = WAVES_M * WAVES_N * 32 * OUT_PITCH;                         // epilogue transpose
+    constexpr int SMEM = cmax(STAGE_BYTES, RED_BYTES + OUT_BYTES);
 
-    __shared__ __attribute__((aligned(16))) unsigned char smem[(BM + BN) * ROWB];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
     unsigned char* sA = smem;
-    unsigned char* sB = smem + BM * ROWB;
+    unsigned char* sB = smem + BM * PITCH;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave / WAVES_N;
-    const int wn = wave % WAVES_N;
+    const int wk = wave / (WAVES_M * WAVES_N);
+    const int wmn = wave % (WAVES_M * WAVES_N);
+    const int wm = wmn / WAVES_N;
+    const int wn = wmn % WAVES_N;
     const int tile_n = blockIdx.x % p.tiles_n;
     const int tile_m = blockIdx.x / p.tiles_n;
     const int m0 = tile_m * BM;
     const int n0 = tile_n * BN;
-    const int lrow = tid >> 2;
+    const int slot = tid >> 2;
     const int lvec = tid & 3;
     const bool transposed = (p.flags & FS_CONV_TRANSPOSED) != 0;
 
-    // ---- per-thread gather bookkeeping for the A rows this thread stages -------------------------
+    // ---- gather bookkeeping -------------------------------------------------------------------------
+    const int a_row = slot % A_RPP, a_grp = slot / A_RPP;
+    const int b_row = slot % B_RPP, b_grp = slot / B_RPP;
     int a_ih0[A_PASS], a_iw0[A_PASS];
     long long a_base[A_PASS];
 #pragma unroll
     for (int ps = 0; ps < A_PASS; ++ps) {
-        const int m = m0 + ps * 64 + lrow;
+        const int m = m0 + ps * A_RPP + a_row;
         if (m < p.M) {
             const int n = m / p.HoWo;
             const int rem = m - n * p.HoWo;
@@ -99,68 +117,80 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
             a_base[ps] = 0;
         }
     }
-    // flattened-K position of this thread's vector slot
-    int k0 = lvec * VEC;
-    int kr, ks, kc;
-    {
-        const int rs = k0 / p.Cin;
-        kc = k0 - rs * p.Cin;
-        kr = rs / p.S;
-        ks = rs - kr * p.S;
+    // flattened-K position (k, and its (r, s, c) decomposition) of each A vector this thread stages
+    int ak[A_SUBS], akr[A_SUBS], aks[A_SUBS], akc[A_SUBS];
+#pragma unroll
+    for (int j = 0; j < A_SUBS; ++j) {
+        ak[j] = (a_grp + A_GROUPS * j) * BK64 + lvec * VEC;
+        const int rs = ak[j] / p.Cin;
+        akc[j] = ak[j] - rs * p.Cin;
+        akr[j] = rs / p.S;
+        aks[j] = rs - akr[j] * p.S;
     }
     const unsigned char* b_ptr[B_PASS];
     bool b_ok[B_PASS];
 #pragma unroll
     for (int ps = 0; ps < B_PASS; ++ps) {
-        const int row = ps * 64 + lrow;
-        const int n = n0 + row;
-        b_ok[ps] = (row < BN) && (n < p.Cout);
+        const int n = n0 + ps * B_RPP + b_row;
+        b_ok[ps] = n < p.Cout;
         b_ptr[ps] = p.w + ((long long)(b_ok[ps] ? n : 0) * p.K) * sizeof(T);
     }
+    int bk[B_SUBS];
+#pragma unroll
+    for (int j = 0; j < B_SUBS; ++j) bk[j] = (b_grp + B_GROUPS * j) * BK64 + lvec * VEC;
 
-    u32x4 a_reg[A_PASS], b_reg[B_PASS];
+    u32x4 a_reg[A_PASS][A_SUBS], b_reg[B_PASS][B_SUBS];
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
     auto load_chunk = [&]() {
-        const bool kvalid = k0 < p.K;
 #pragma unroll
-        for (int ps = 0; ps < A_PASS; ++ps) {
-            int ih = a_ih0[ps] + kr;
-            int iw = a_iw0[ps] + ks;
-            bool ok = kvalid;
-            if (transposed) {
-                ok = ok && (((ih | iw) & 1) == 0);
-                ih >>= 1;
-                iw >>= 1;
+        for (int j = 0; j < A_SUBS; ++j) {
+            const bool kvalid = ak[j] < p.K;
+#pragma unroll
+            for (int ps = 0; ps < A_PASS; ++ps) {
+                int ih = a_ih0[ps] + akr[j];
+                int iw = a_iw0[ps] + aks[j];
+                bool ok = kvalid;
+                if (transposed) {
+                    ok = ok && (((ih | iw) & 1) == 0);
+                    ih >>= 1;
+                    iw >>= 1;
+                }
+                ok = ok && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
+                const long long pix = a_base[ps] + (long long)ih * p.W + iw;
+                const unsigned char* src = p.x + (pix * p.x_cs + akc[j]) * (long long)sizeof(T);
+                a_reg[ps][j] = ok ? ldg16(src) : zero4;
             }
-            ok = ok && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
-            const long long pix = a_base[ps] + (long long)ih * p.W + iw;
-            const unsigned char* src = p.x + (pix * p.x_cs + kc) * (long long)sizeof(T);
-            a_reg[ps] = ok ? ldg16(src) : zero4;
+            ak[j] += BKT;
+            akc[j] += BKT;
+            while (akc[j] >= p.Cin) {
+                akc[j] -= p.Cin;
+                if (++aks[j] == p.S) {
+                    aks[j] = 0;
+                    ++akr[j];
+                }
+            }
         }
 #pragma unroll
-        for (int ps = 0; ps < B_PASS; ++ps) {
-            const bool ok = kvalid && b_ok[ps];
-            b_reg[ps] = ok ? ldg16(b_ptr[ps] + (long long)k0 * sizeof(T)) : zero4;
-        }
-        // advance to the next chunk
-        k0 += BK;
-        kc += BK;
-        while (kc >= p.Cin) {
-            kc -= p.Cin;
-            if (++ks == p.S) {
-                ks = 0;
-                ++kr;
-            }
+        for (int j = 0; j < B_SUBS; ++j) {
+            const bool kvalid = bk[j] < p.K;
+#pragma unroll
+            for (int ps = 0; ps < B_PASS; ++ps)
+                b_reg[ps][j] = (kvalid && b_ok[ps]) ? ldg16(b_ptr[ps] + (long long)bk[j] * sizeof(T)) : zero4;
+            bk[j] += BKT;
         }
     };
     auto store_chunk = [&]() {
 #pragma unroll
         for (int ps = 0; ps < A_PASS; ++ps)
-            *reinterpret_cast<u32x4*>(sA + (ps * 64 + lrow) * ROWB + lvec * 16) = a_reg[ps];
+#pragma unroll
+            for (int j = 0; j < A_SUBS; ++j)
+                *reinterpret_cast<u32x4*>(sA + (ps * A_RPP + a_row) * PITCH + (a_grp + A_GROUPS * j) * 64 + lvec * 16) = a_reg[ps][j];
 #pragma unroll
         for (int ps = 0; ps < B_PASS; ++ps)
-            if (ps * 64 + lrow < BN) *reinterpret_cast<u32x4*>(sB + (ps * 64 + lrow) * ROWB + lvec * 16) = b_reg[ps];
+#pragma unroll
+            for (int j = 0; j < B_SUBS; ++j)
+                *reinterpret_cast<u32x4*>(sB + (ps * B_RPP + b_row) * PITCH + (b_grp + B_GROUPS * j) * 64 + lvec * 16) = b_reg[ps][j];
     };
 
     f32x16 acc[WM_T][WN_T];
@@ -171,22 +201,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nchunks = (p.K + BK - 1) / BK;
-    const unsigned char* fragA = sA + (wm * WM_T * 32 + (lane & 31)) * ROWB + (lane >> 5) * 16;
-    const unsigned char* fragB = sB + (wn * WN_T * 32 + (lane & 31)) * ROWB + (lane >> 5) * 16;
+    const int niter = (p.K + BKT - 1) / BKT;
+    const unsigned char* fragA = sA + (wm * WM_T * 32 + (lane & 31)) * PITCH + wk * KSUB * 64 + (lane >> 5) * 16;
+    const unsigned char* fragB = sB + (wn * WN_T * 32 + (lane & 31)) * PITCH + wk * KSUB * 64 + (lane >> 5) * 16;
 
     load_chunk();
-    for (int t = 0; t < nchunks; ++t) {
+    for (int t = 0; t < niter; ++t) {
         store_chunk();
         __syncthreads();
-        if (t + 1 < nchunks) load_chunk();
+        if (t + 1 < niter) load_chunk();
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < 2 * KSUB; ++kk) {
             u32x4 af[WM_T], bfr[WN_T];
 #pragma unroll
-            for (int i = 0; i < WM_T; ++i) af[i] = *reinterpret_cast<const u32x4*>(fragA + i * 32 * ROWB + kk * 32);
+            for (int i = 0; i < WM_T; ++i) af[i] = *reinterpret_cast<const u32x4*>(fragA + i * 32 * PITCH + kk * 32);
 #pragma unroll
-            for (int j = 0; j < WN_T; ++j) bfr[j] = *reinterpret_cast<const u32x4*>(fragB + j * 32 * ROWB + kk * 32);
+            for (int j = 0; j < WN_T; ++j) bfr[j] = *reinterpret_cast<const u32x4*>(fragB + j * 32 * PITCH + kk * 32);
 #pragma unroll
             for (int i = 0; i < WM_T; ++i)
 #pragma unroll
@@ -195,32 +225,90 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
         __syncthreads();
     }
 
-    // ---- epilogue ---------------------------------------------------------------------------------
+    // ---- in-block split-K reduction ------------------------------------------------------------------
+    if (WAVES_K > 1) {
+        float* red = reinterpret_cast<float*>(smem);
+        if (wk > 0) {
+#pragma unroll
+            for (int i = 0; i < WM_T; ++i)
+#pragma unroll
+                for (int j = 0; j < WN_T; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        red[((((wk - 1) * WAVES_M * WAVES_N + wmn) * TILES + i * WN_T + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (wk == 0) {
+#pragma unroll
+            for (int q = 0; q < WAVES_K - 1; ++q)
+#pragma unroll
+                for (int i = 0; i < WM_T; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN_T; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            acc[i][j][r] += red[(((q * WAVES_M * WAVES_N + wmn) * TILES + i * WN_T + j) * 16 + r) * 64 + lane];
+        }
+    }
+    if (wk != 0) return;
+
+    // ---- epilogue --------------------------------------------------------------------------------------
     const bool relu = (p.flags & FS_CONV_RELU) != 0;
     const bool accum = (p.flags & FS_CONV_ACCUM) != 0;
     T* y = reinterpret_cast<T*>(p.y);
+    unsigned char* sOut = smem + RED_BYTES + wmn * 32 * OUT_PITCH;
+    constexpr int LPR = 32 * (int)sizeof(T) / 16;          // lanes (16-byte vectors) per output row: 4 bf16 / 8 fp32
+    constexpr int RPP = 64 / LPR;                          // rows per store pass
 #pragma unroll
     for (int j = 0; j < WN_T; ++j) {
-        const int co = n0 + (wn * WN_T + j) * 32 + (lane & 31);
+        const int cbase = n0 + (wn * WN_T + j) * 32;
+        const int co = cbase + (lane & 31);
         const bool cvalid = co < p.Cout;
         const float sc = (p.scale && cvalid) ? p.scale[co] : 1.f;
         const float sh = (p.shift && cvalid) ? p.shift[co] : 0.f;
+        const bool full_n = (cbase + 32 <= p.Cout) && !accum && !(p.flags & CONV_SCALAR_STORE);
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < WM_T; ++i) {
+            const int mbase = m0 + (wm * WM_T + i) * 32;
+            if (full_n) {
+                // registers -> LDS (row = pixel, col = channel) -> 16-byte global stores
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int m = m0 + (wm * WM_T + i) * 32 + row;
-                const float v = acc[i][j][r];
-                s1 += v;
-                s2 += v * v;
-                if (m < p.M && cvalid) {
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const float v = acc[i][j][r];
+                    s1 += v;
+                    s2 += v * v;
                     float o = v * sc + sh;
-                    T* dst = y + (long long)m * p.y_cs + co;
-                    if (accum) o += Elem<T>::load(dst);
                     if (relu) o = fmaxf(o, 0.f);
-                    Elem<T>::store(dst, o);
+                    Elem<T>::store(reinterpret_cast<T*>(sOut + row * OUT_PITCH) + (lane & 31), o);
+                }
+                __builtin_amdgcn_wave_barrier();           // DS ops of one wave execute in order; keep the compiler from reordering
+#pragma unroll
+                for (int ps = 0; ps < 32 / RPP; ++ps) {
+                    const int row = ps * RPP + lane / LPR;
+                    const int seg = lane % LPR;
+                    const int m = mbase + row;
+                    if (m < p.M)
+                        stg16(y + (long long)m * p.y_cs + cbase + seg * (16 / (int)sizeof(T)),
+                              *reinterpret_cast<const u32x4*>(sOut + row * OUT_PITCH + seg * 16));
+                }
+                __builtin_amdgcn_wave_barrier();
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const int m = mbase + row;
+                    const float v = acc[i][j][r];
+                    s1 += v;
+                    s2 += v * v;
+                    if (m < p.M && cvalid) {
+                        float o = v * sc + sh;
+                        T* dst = y + (long long)m * p.y_cs + co;
+                        if (accum) o += Elem<T>::load(dst);
+                        if (relu) o = fmaxf(o, 0.f);
+                        Elem<T>::store(dst, o);
+                    }
                 }
             }
         }
@@ -235,36 +323,49 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     }
 }
 
-template <typename T, int WAVES_M, int WAVES_N, int WM_T, int WN_T>
+template <typename T, int WAVES_M, int WAVES_N, int WAVES_K, int WM_T, int WN_T, int KSUB>
 static void launch_cfg(hipStream_t st, ConvArgs& a) {
     constexpr int BM = WAVES_M * WM_T * 32;
     constexpr int BN = WAVES_N * WN_T * 32;
     a.tiles_n = (a.Cout + BN - 1) / BN;
     const int tiles_m = (a.M + BM - 1) / BM;
-    hipLaunchKernelGGL((conv_igemm_kernel<T, WAVES_M, WAVES_N, WM_T, WN_T>), dim3((unsigned)(tiles_m * a.tiles_n)),
-                       dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, WAVES_M, WAVES_N, WAVES_K, WM_T, WN_T, KSUB>),
+                       dim3((unsigned)(tiles_m * a.tiles_n)), dim3(256), 0, st, a);
 }
 
-template <typename T> static void dispatch(hipStream_t st, ConvArgs& a) {
-    // Tile choice: narrow-N tiles for thin layers; smaller M tiles when the layer would not fill 256 CUs.
-    const long long blocks128 = (long long)((a.M + 127) / 128);
-    if (a.Cout <= 32) {
-        if (blocks128 >= 512) launch_cfg<T, 4, 1, 1, 1>(st, a);   // 128 x 32
-        else launch_cfg<T, 2, 2, 1, 1>(st, a);                   // 64 x 64 (N padded)
-    } else if (a.Cout <= 64) {
-        if (blocks128 >= 384) launch_cfg<T, 2, 2, 2, 1>(st, a);   // 128 x 64
-        else launch_cfg<T, 2, 2, 1, 1>(st, a);                   // 64 x 64
-    } else {
-        const long long b = blocks128 * ((a.Cout + 127) / 128);
-        if (b >= 384) launch_cfg<T, 2, 2, 2, 2>(st, a);           // 128 x 128
-        else if (a.Cout % 128 != 0 && a.Cout % 128 <= 64) launch_cfg<T, 2, 2, 1, 1>(st, a);
-        else launch_cfg<T, 2, 2, 1, 2>(st, a);                   // 64 x 128
+static inline long long nblocks(const ConvArgs& a, int bm, int bn) {
+    return (long long)((a.M + bm - 1) / bm) * ((a.Cout + bn - 1) / bn);
+}
+
+// Tile choice: the largest tile that still gives every CU at least one block; otherwise 32-wide tiles with the K
+// loop split over the four waves of the block (launch-latency-sized layers).
+template <typename T> static void dispatch(hipStream_t st, ConvArgs& a, int force) {
+    const long long FILL = 256;
+    int cfg;
+    if (force >= 0) cfg = force;
+    else if (a.Cout > 64 && nblocks(a, 128, 128) >= FILL) cfg = 0;
+    else if (a.Cout > 32 && nblocks(a, 128, 64) >= FILL) cfg = 1;
+    else if (a.Cout <= 32 && nblocks(a, 128, 32) >= FILL) cfg = 2;
+    else if (a.Cout > 32 && nblocks(a, 64, 64) >= FILL) cfg = 3;
+    else if (nblocks(a, 64, 32) >= FILL) cfg = 4;
+    else cfg = 5;
+    switch (cfg) {
+        case 0: launch_cfg<T, 2, 2, 1, 2, 2, 2>(st, a); break;   // 128 x 128
+        case 1: launch_cfg<T, 2, 2, 1, 2, 1, 2>(st, a); break;   // 128 x 64
+        case 2: launch_cfg<T, 4, 1, 1, 1, 1, 2>(st, a); break;   // 128 x 32
+        case 3: launch_cfg<T, 2, 2, 1, 1, 1, 2>(st, a); break;   // 64 x 64
+        case 4: launch_cfg<T, 2, 1, 2, 1, 1, 2>(st, a); break;   // 64 x 32, K split 2
+        default: launch_cfg<T, 1, 1, 4, 1, 1, 2>(st, a); break;  // 32 x 32, K split 4
     }
 }
 
 }  // namespace fs
 
 using namespace fs;
+
+static int g_force_cfg = -1;
+/* test hook: force a tile configuration (0..5), -1 = heuristic */
+extern "C" void fs_debug_force_conv_cfg(int cfg) { g_force_cfg = cfg; }
 
 extern "C" fs_status fs_conv2d_fwd(void* stream, const fs_conv_desc* d, const void* x, const void* w_packed,
                                    const float* scale, const float* shift, void* y, float* stats) {
@@ -301,7 +402,9 @@ extern "C" fs_status fs_conv2d_fwd(void* stream, const fs_conv_desc* d, const vo
     a.M = (int)M; a.K = d->R * d->S * d->Cin; a.HoWo = d->Ho * d->Wo;
     a.flags = d->flags;
     a.tiles_n = 1;
-    if (d->dtype == FS_F32) dispatch<float>((hipStream_t)stream, a);
-    else dispatch<bf16_t>((hipStream_t)stream, a);
+    // 16-byte epilogue stores need an aligned slice; otherwise every tile takes the element-wise path
+    if (!(aligned16(y) && (d->y_cs % vec == 0))) a.flags |= CONV_SCALAR_STORE;
+    if (d->dtype == FS_F32) dispatch<float>((hipStream_t)stream, a, g_force_cfg);
+    else dispatch<bf16_t>((hipStream_t)stream, a, g_force_cfg);
     return check_launch("fs_conv2d_fwd");
 }

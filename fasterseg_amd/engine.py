@@ -1,0 +1,305 @@
+"""Static inference engine: lowers a built network (eval mode) to a flat plan of HIP kernel launches and replays it
+from a hipGraph.
+
+This is what replaces the reference's TensorRT path for the derived network (latency/run_latency.py:54-81,
+tools/utils/darts_utils.py:113-177: ONNX export -> TensorRT engine -> timed execute loop): the network's own
+forward() is traced once with shape-only tensors, BatchNorm is folded into per-channel scale/shift, filters are
+packed once, every feature map gets a fixed NHWC buffer, torch.cat disappears (producers write straight into channel
+slices of the consumer's buffer), and the resulting ~90 launches are captured into one hipGraph so a frame costs one
+graph launch.  Nothing here runs on the CPU per pixel and there is no fallback: every op is a libfasterseg_hip call.
+
+The plan also carries the algorithmic FLOPs / bytes of every launch (SURVEY.md §8d conventions) and can time each
+launch with HIP events on the launch stream (`profile()`), which is what bench.py's roofline block is computed from.
+"""
+import ctypes
+
+import torch
+
+from . import functional as FN
+from . import kernels as K
+from ._lib import FS_CONV_RELU, ConvDesc, ResizeDesc, call
+
+
+class _Tracer:
+    def __init__(self, dtype):
+        self.dtype = dtype
+        self.ops = []
+
+    def _emit(self, kind, out_shape, nchw=False, **kw):
+        out = FN.SymTensor(out_shape, self.dtype, nchw)
+        out.producer = len(self.ops)
+        self.ops.append(dict(kind=kind, out=out, **kw))
+        return out
+
+    @staticmethod
+    def _conv_hw(H, W, k, stride, pad):
+        return (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+
+    def stem(self, x, weight, bn, relu, training):
+        assert not training, "the engine lowers eval-mode networks only"
+        N, C, H, W = x.shape
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        return self._emit("stem", (N, weight.shape[0], Ho, Wo), x=x, weight=weight, bn=bn, relu=relu)
+
+    def conv(self, x, weight, bn, bias, stride, pad, relu, training, cout, cin):
+        assert not training, "the engine lowers eval-mode networks only"
+        N, C, H, W = x.shape
+        assert C == cin, (C, cin)
+        k = weight.shape[2]
+        Ho, Wo = self._conv_hw(H, W, k, stride, pad)
+        return self._emit("conv", (N, cout, Ho, Wo), x=x, weight=weight, bn=bn, bias=bias, stride=stride, pad=pad, relu=relu,
+                          cout=cout, cin=cin, k=k)
+
+    def factorized_reduce(self, x, w1, w2, bn, training, half, cin):
+        assert not training
+        N, C, H, W = x.shape
+        return self._emit("fr", (N, 2 * half, H // 2, W // 2), x=x, w1=w1, w2=w2, bn=bn, half=half, cin=cin)
+
+    def resize(self, x, size, relu, out_nchw):
+        N, C, H, W = x.shape
+        return self._emit("resize", (N, C, size[0], size[1]), nchw=bool(out_nchw), x=x, relu=relu, out_nchw=out_nchw)
+
+    def cat(self, tensors):
+        N, _, H, W = tensors[0].shape
+        return self._emit("cat", (N, sum(t.shape[1] for t in tensors), H, W), inputs=list(tensors))
+
+
+class InferenceEngine:
+    def __init__(self, net, input_shape, dtype=torch.bfloat16, logits_dtype=torch.float32, device="cuda", use_graph=True):
+        assert not net.training, "call net.eval() first"
+        self.dtype = dtype
+        self.device = torch.device(device)
+        self.input_shape = tuple(input_shape)
+        self.logits_dtype = logits_dtype
+        self.vec = K.vec_of(dtype)
+        self.input = torch.zeros(self.input_shape, dtype=torch.float32, device=self.device)
+        self._keep = []            # tensors referenced by raw pointers in the plan
+        self._trace(net)
+        self._assign_buffers()
+        self._lower()
+        self.graph = None
+        if use_graph:
+            self._capture()
+
+    # ---- 1. trace ----------------------------------------------------------------------------------
+    def _trace(self, net):
+        tracer = _Tracer(self.dtype)
+        x = FN.SymTensor(self.input_shape, torch.float32, nchw=True)
+        x.storage = ("input", 0)
+        FN._tracer = tracer
+        try:
+            with torch.no_grad():
+                out = net(x)
+        finally:
+            FN._tracer = None
+        assert isinstance(out, FN.SymTensor) and out.nchw, "network must end in the NCHW logits up-sample"
+        self.ops = tracer.ops
+        self.out_sym = out
+
+    # ---- 2. buffers: one NHWC buffer per feature map; cat operands alias slices of the cat buffer ------
+    def _new_buffer(self, N, H, W, cs, zero=False):
+        make = torch.zeros if zero else torch.empty
+        buf = make((N, H, W, cs), dtype=self.dtype, device=self.device)
+        self._keep.append(buf)
+        return buf
+
+    def _assign_buffers(self):
+        self.buffers = {}
+        self.copies = {}           # cat op index -> [(src sym, channel offset)] that could not be aliased
+        for idx, op in enumerate(self.ops):
+            if op["kind"] != "cat":
+                continue
+            out = op["out"]
+            N, C, H, W = out.shape
+            bid = "cat%d" % idx
+            self.buffers[bid] = self._new_buffer(N, H, W, K.round_up(C, self.vec))
+            out.storage = (bid, 0)
+            off = 0
+            for s in op["inputs"]:
+                can_alias = (s.storage is None and s.producer is not None and off % self.vec == 0
+                             and self.ops[s.producer]["kind"] in ("conv", "resize", "stem", "fr") and not s.nchw)
+                if can_alias:
+                    s.storage = (bid, off)
+                else:
+                    self.copies.setdefault(idx, []).append((s, off))
+                off += s.shape[1]
+        for idx, op in enumerate(self.ops):
+            out = op["out"]
+            if out.storage is not None:
+                continue
+            N, C, H, W = out.shape
+            if out.nchw:
+                t = torch.empty((N, C, H, W), dtype=self.logits_dtype, device=self.device)
+                self._keep.append(t)
+                self.buffers["out%d" % idx] = t
+                out.storage = ("out%d" % idx, 0)
+                continue
+            pad_to = 32 if C % self.vec else self.vec       # classifier logits: 19 -> 32 channel stride
+            bid = "buf%d" % idx
+            self.buffers[bid] = self._new_buffer(N, H, W, K.round_up(C, pad_to), zero=(C % self.vec != 0))
+            out.storage = (bid, 0)
+        self.output = self.buffers[self.out_sym.storage[0]]
+
+    def _ptr(self, sym):
+        bid, off = sym.storage
+        if bid == "input":
+            return self.input.data_ptr(), 0
+        buf = self.buffers[bid]
+        if sym.nchw:
+            return buf.data_ptr(), 0
+        return buf.data_ptr() + off * buf.element_size(), buf.shape[3]
+
+    # ---- 3. lower to ctypes call records --------------------------------------------------------------
+    def _fold(self, bn, bias, cout, lo=0):
+        if bn is not None:
+            gamma, beta, rm, rv, eps = bn
+            scale, shift = FN.fold_bn(gamma, beta, rm, rv, eps)
+            scale, shift = scale[lo:lo + cout].contiguous().to(self.device), shift[lo:lo + cout].contiguous().to(self.device)
+        else:
+            scale = None
+            shift = bias.detach().float()[:cout].contiguous().to(self.device) if bias is not None else None
+        self._keep += [scale, shift]
+        return scale, shift
+
+    def _add_conv(self, x, out, weight, scale, shift, k, stride, pad, relu, cout, cin, out_off=0, label="conv"):
+        N, _, H, W = x.shape
+        _, _, Ho, Wo = out.shape
+        wp = K.pack_weight(weight.detach().to(self.device), self.dtype, cout, cin)
+        self._keep.append(wp)
+        xp, x_cs = self._ptr(x)
+        yp, y_cs = self._ptr(out)
+        yp += out_off * (2 if self.dtype == torch.bfloat16 else 4)
+        d = ConvDesc(N, H, W, cin, cout, k, k, stride, pad, Ho, Wo, x_cs, y_cs, K.dtype_code(self.dtype), FS_CONV_RELU if relu else 0)
+        self._keep.append(d)
+        es = 2 if self.dtype == torch.bfloat16 else 4
+        flops = 2.0 * N * Ho * Wo * cout * cin * k * k
+        nbytes = es * (N * H * W * cin + cout * cin * k * k + N * Ho * Wo * cout)
+        args = (ctypes.byref(d), ctypes.c_void_p(xp), ctypes.c_void_p(wp.data_ptr()), K._p(scale), K._p(shift), ctypes.c_void_p(yp), None)
+        self.calls.append(dict(fn="fs_conv2d_fwd", args=args, family="conv%dx%d" % (k, k), flops=flops, bytes=nbytes,
+                               label="%s %dx%d s%d %d->%d @%dx%d" % (label, k, k, stride, cin, cout, H, W)))
+
+    def _lower(self):
+        self.calls = []
+        es = 2 if self.dtype == torch.bfloat16 else 4
+        for idx, op in enumerate(self.ops):
+            kind, out = op["kind"], op["out"]
+            if kind == "stem":
+                N, _, H, W = op["x"].shape
+                cout = out.shape[1]
+                scale, shift = self._fold(op["bn"], None, cout)
+                wp = K.pack_weight(op["weight"].detach().to(self.device), torch.float32)
+                self._keep.append(wp)
+                yp, y_cs = self._ptr(out)
+                args = (N, H, W, cout, ctypes.c_void_p(self.input.data_ptr()), ctypes.c_void_p(wp.data_ptr()), K._p(scale), K._p(shift),
+                        ctypes.c_void_p(yp), y_cs, K.dtype_code(self.dtype), int(op["relu"]))
+                Ho, Wo = out.shape[2], out.shape[3]
+                self.calls.append(dict(fn="fs_conv_stem_fwd", args=args, family="stem", flops=2.0 * N * Ho * Wo * cout * 27,
+                                       bytes=4 * N * 3 * H * W + es * N * Ho * Wo * cout,
+                                       label="stem 3x3 s2 3->%d @%dx%d" % (cout, H, W)))
+            elif kind == "conv":
+                scale, shift = self._fold(op["bn"], op["bias"], op["cout"])
+                self._add_conv(op["x"], out, op["weight"], scale, shift, op["k"], op["stride"], op["pad"], op["relu"], op["cout"],
+                               op["cin"])
+            elif kind == "fr":
+                half = op["half"]
+                for j, (w, pad) in enumerate(((op["w1"], 0), (op["w2"], -1))):
+                    scale, shift = self._fold(op["bn"], None, half, lo=j * half)
+                    self._add_conv(op["x"], out, w, scale, shift, 1, 2, pad, True, half, op["cin"], out_off=j * half, label="fr")
+            elif kind == "resize":
+                x = op["x"]
+                N, C, Hi, Wi = x.shape
+                Ho, Wo = out.shape[2], out.shape[3]
+                xp, x_cs = self._ptr(x)
+                yp, y_cs = self._ptr(out)
+                onchw = 0
+                out_es = es
+                if op["out_nchw"]:
+                    onchw = 1 if self.logits_dtype == torch.float32 else 2
+                    out_es = 4 if onchw == 1 else es
+                d = ResizeDesc(N, Hi, Wi, Ho, Wo, C, x_cs, y_cs, K.dtype_code(self.dtype), int(op["relu"]), onchw)
+                self._keep.append(d)
+                args = (ctypes.byref(d), ctypes.c_void_p(xp), ctypes.c_void_p(yp))
+                self.calls.append(dict(fn="fs_bilinear_fwd", args=args, family="resize_nchw" if onchw else "resize", flops=0.0,
+                                       bytes=es * N * Hi * Wi * C + out_es * N * Ho * Wo * C,
+                                       label="resize %dx%d->%dx%d C%d%s" % (Hi, Wi, Ho, Wo, C, " nchw" if onchw else "")))
+            elif kind == "cat":
+                for s, off in self.copies.get(idx, []):
+                    N, C, H, W = s.shape
+                    sp, s_cs = self._ptr(s)
+                    yp, y_cs = self._ptr(out)
+                    args = (N * H * W, C, ctypes.c_void_p(sp), s_cs, ctypes.c_void_p(yp + off * es), y_cs, K.dtype_code(self.dtype))
+                    self.calls.append(dict(fn="fs_copy_channels", args=args, family="copy", flops=0.0, bytes=2 * es * N * H * W * C,
+                                           label="copy C%d @%dx%d" % (C, H, W)))
+            else:
+                raise RuntimeError("unknown op kind " + kind)
+        self.total_flops = sum(c["flops"] for c in self.calls)
+        self.total_bytes = sum(c["bytes"] for c in self.calls)
+
+    # ---- 4. run ----------------------------------------------------------------------------------------
+    def _launch_all(self):
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for c in self.calls:
+            call(c["fn"], st, *c["args"])
+
+    def _capture(self):
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self._launch_all()                     # warm-up outside capture
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                self._launch_all()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = g
+
+    def run(self):
+        """One forward on the current contents of `self.input`; result in `self.output` (contiguous NCHW logits)."""
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._launch_all()
+        return self.output
+
+    def __call__(self, x):
+        self.input.copy_(x)
+        return self.run()
+
+    def profile(self, repeats=20, rounds=3):
+        """Device time of every launch of the plan, measured with HIP events on the launch stream.
+
+        Each launch is captured `repeats` times back-to-back into its own small hipGraph and the replay is bracketed by
+        two events (median of `rounds`), so the figure is kernel duration + one dependent-kernel boundary (~1.5 us) and
+        is free of Python launch overhead; rocprofv3 --kernel-trace durations of the same kernels (profiles/) are the
+        cross-check.  Returns [dict(label, family, ms, flops, bytes)] in plan order."""
+        out = []
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            st = ctypes.c_void_p(side.cuda_stream)
+            self._launch_all_on(st)
+            side.synchronize()
+            for c in self.calls:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side):
+                    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+                    for _ in range(repeats):
+                        call(c["fn"], st, *c["args"])
+                g.replay()
+                times = []
+                for _ in range(rounds):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    g.replay()
+                    e1.record()
+                    e1.synchronize()
+                    times.append(e0.elapsed_time(e1) / repeats)
+                times.sort()
+                out.append(dict(label=c["label"], family=c["family"], ms=times[len(times) // 2], flops=c["flops"], bytes=c["bytes"]))
+        torch.cuda.current_stream().wait_stream(side)
+        return out
+
+    def _launch_all_on(self, st):
+        for c in self.calls:
+            call(c["fn"], st, *c["args"])

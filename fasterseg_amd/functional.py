@@ -16,6 +16,27 @@ import torch
 from . import kernels as K
 
 _compute_dtype = torch.float32
+_tracer = None      # set by fasterseg_amd.engine while a network is being lowered to a static kernel plan
+
+
+class SymTensor:
+    """Shape-only stand-in for a feature map while engine.InferenceEngine traces a network's forward()."""
+    _next = 0
+
+    def __init__(self, shape, dtype, nchw=False):
+        self.shape = tuple(int(v) for v in shape)
+        self.dtype = dtype
+        self.nchw = nchw
+        self.storage = None          # (buffer id, channel offset), assigned by the planner
+        self.producer = None
+        self.id = SymTensor._next
+        SymTensor._next += 1
+
+    def size(self, dim=None):
+        return self.shape if dim is None else self.shape[dim]
+
+    def dim(self):
+        return len(self.shape)
 
 
 def set_compute_dtype(dtype):
@@ -44,6 +65,8 @@ class _ToNHWC(torch.autograd.Function):
 
 def as_nhwc(x, dtype=None):
     """`x` as an NHWC view of `dtype` (default: keep an NHWC operand's dtype, else the compute dtype)."""
+    if isinstance(x, SymTensor):
+        return x
     if dtype is None:
         dtype = x.dtype if K.is_nhwc(x) else _compute_dtype
     if K.is_nhwc(x, dtype):
@@ -160,6 +183,8 @@ def conv_bn_act(x, weight, gamma, beta, running_mean, running_var, stride, pad, 
     x = as_nhwc(x)
     cout = weight.shape[0] if cout is None else cout
     cin = weight.shape[1] if cin is None else cin
+    if _tracer is not None:
+        return _tracer.conv(x, weight, (gamma, beta, running_mean, running_var, eps), None, stride, pad, relu, training, cout, cin)
     cfg = (stride, pad, relu, training, momentum, eps, cout, cin)
     return _ConvBNAct.apply(x, weight, gamma, beta, running_mean, running_var, cfg)
 
@@ -216,6 +241,8 @@ class _StemConvBNAct(torch.autograd.Function):
 
 
 def stem_conv_bn_act(x, weight, gamma, beta, running_mean, running_var, relu, training, momentum=0.1, eps=1e-5, dtype=None):
+    if _tracer is not None:
+        return _tracer.stem(x, weight, (gamma, beta, running_mean, running_var, eps), relu, training)
     cfg = (relu, training, momentum, eps, dtype or _compute_dtype)
     return _StemConvBNAct.apply(x, weight, gamma, beta, running_mean, running_var, cfg)
 
@@ -278,6 +305,8 @@ class _ConvBias(torch.autograd.Function):
 def conv_bias(x, weight, bias, stride=1, pad=0, cout=None, cin=None):
     cout = weight.shape[0] if cout is None else cout
     cin = weight.shape[1] if cin is None else cin
+    if _tracer is not None:
+        return _tracer.conv(x, weight, None, bias, stride, pad, False, False, cout, cin)
     return _ConvBias.apply(as_nhwc(x), weight, bias, (stride, pad, cout, cin))
 
 
@@ -358,6 +387,8 @@ def factorized_reduce(x, w1, w2, gamma, beta, running_mean, running_var, trainin
     x = as_nhwc(x)
     half = w1.shape[0] if half is None else half
     cin = w1.shape[1] if cin is None else cin
+    if _tracer is not None:
+        return _tracer.factorized_reduce(x, w1, w2, (gamma, beta, running_mean, running_var, eps), training, half, cin)
     return _FactorizedReduce.apply(x, w1, w2, gamma, beta, running_mean, running_var, (training, momentum, eps, half, cin))
 
 
@@ -393,6 +424,8 @@ def interpolate(x, size=None, scale_factor=None, relu=False, out_nchw=0):
     out_nchw=1 returns a contiguous NCHW fp32 tensor (final logits, model_seg.py:359-365)."""
     if size is None:
         size = (int(x.shape[2] * scale_factor), int(x.shape[3] * scale_factor))
+    if _tracer is not None:
+        return _tracer.resize(x, (int(size[0]), int(size[1])), relu, out_nchw)
     x = as_nhwc(x)
     if out_nchw and K.channel_stride(x) < K.round_up(x.shape[1], 4):
         raise ValueError("NCHW-output resize needs a channel-padded input buffer")
@@ -473,6 +506,8 @@ def scale_accumulate(acc, x, coef):
 
 def cat(tensors):
     """torch.cat(dim=1) of NHWC feature maps via fs_copy_channels; autograd by slicing."""
+    if _tracer is not None:
+        return _tracer.cat(list(tensors))
     return _Cat.apply(*[as_nhwc(t) for t in tensors])
 
 

@@ -94,6 +94,11 @@ def gen_arch():
             for k, v in state.items():
                 raw[k] = _np(v) if torch.is_tensor(v) else np.asarray(v)
             np.savez_compressed(os.path.join(GOLD, "arch_%d.npz" % idx), **raw)
+            # the searched architectures are data the reference ships (train/fasterseg/arch_{0,1}.pt); the package
+            # carries the same numbers as .npz so the derived networks can be built without the reference tree
+            pkg = os.path.join(os.path.dirname(GOLD), "..", "fasterseg_amd", "fasterseg")
+            os.makedirs(pkg, exist_ok=True)
+            np.savez_compressed(os.path.join(pkg, "arch_%d.npz" % idx), **raw)
             lat = lambda k: float(state[k])
             meta = {"objective02": float(objective_acc_lat(float(state["mIoU02"]), lat("latency02"))),
                     "objective12": float(objective_acc_lat(float(state["mIoU12"]), lat("latency12")))}

@@ -55,6 +55,8 @@ CONV_CASES = [
     (1, 16, 40, 36, 144, 3, 1, 1),
     (3, 384, 4, 8, 384, 3, 1, 1),
     (1, 8, 5, 7, 8, 3, 1, 1),
+    (1, 32, 192, 256, 128, 3, 1, 1),   # M = 49152: the large-tile configurations under the heuristic
+    (2, 16, 128, 160, 32, 3, 1, 1),
 ]
 
 
@@ -64,9 +66,19 @@ def ref_conv(x, w, stride, pad):
     return F.conv2d(x, w, None, stride, pad)
 
 
+@pytest.fixture
+def force_cfg(request):
+    """Every tile configuration of fs_conv2d_fwd must give the same answer; -1 is the production heuristic."""
+    from fasterseg_amd import _lib
+    _lib.lib().fs_debug_force_conv_cfg(request.param)
+    yield request.param
+    _lib.lib().fs_debug_force_conv_cfg(-1)
+
+
+@pytest.mark.parametrize("force_cfg", [-1, 0, 1, 2, 3, 4, 5], indirect=True, ids=lambda c: "cfg%d" % c)
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=[str(c) for c in CONV_CASES])
-def test_conv2d_fwd(case, dtype):
+def test_conv2d_fwd(case, dtype, force_cfg):
     k = K()
     N, Cin, H, W, Cout, ks, stride, pad = case
     x = q(rnd(N, Cin, H, W, seed=1), dtype)
