@@ -35,6 +35,7 @@ struct ConvArgs {
     int M, K, HoWo;
     int flags;
     int tiles_n;
+    unsigned cin_magic;   // ceil(2^32 / Cin): k / Cin == umulhi(k, cin_magic) for k < 2^16
 };
 
 template <typename T> struct Mma;
@@ -117,16 +118,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
             a_base[ps] = 0;
         }
     }
-    // flattened-K position (k, and its (r, s, c) decomposition) of each A vector this thread stages
-    int ak[A_SUBS], akr[A_SUBS], aks[A_SUBS], akc[A_SUBS];
+    // flattened-K position of each A vector this thread stages; (r, s, c) are re-derived from k with a multiply-high
+    // (straight-line code: a data-dependent carry loop here makes hipcc emit exec-masked loops with vmcnt(0) joins)
+    int ak[A_SUBS];
 #pragma unroll
-    for (int j = 0; j < A_SUBS; ++j) {
-        ak[j] = (a_grp + A_GROUPS * j) * BK64 + lvec * VEC;
-        const int rs = ak[j] / p.Cin;
-        akc[j] = ak[j] - rs * p.Cin;
-        akr[j] = rs / p.S;
-        aks[j] = rs - akr[j] * p.S;
-    }
+    for (int j = 0; j < A_SUBS; ++j) ak[j] = (a_grp + A_GROUPS * j) * BK64 + lvec * VEC;
+    const int tshift = transposed ? 1 : 0;
     const unsigned char* b_ptr[B_PASS];
     bool b_ok[B_PASS];
 #pragma unroll
@@ -140,43 +137,42 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     for (int j = 0; j < B_SUBS; ++j) bk[j] = (b_grp + B_GROUPS * j) * BK64 + lvec * VEC;
 
     u32x4 a_reg[A_PASS][A_SUBS], b_reg[B_PASS][B_SUBS];
-    const u32x4 zero4 = {0u, 0u, 0u, 0u};
-
+    uint32_t a_keep[A_PASS][A_SUBS], b_keep[B_PASS][B_SUBS];   // zero-masks, applied when the data is consumed (store_chunk)
     auto load_chunk = [&]() {
 #pragma unroll
         for (int j = 0; j < A_SUBS; ++j) {
-            const bool kvalid = ak[j] < p.K;
+            const int k = ak[j];
+            const bool kvalid = k < p.K;
+            const int rs = (int)__umulhi((unsigned)k, p.cin_magic);
+            const int kc = k - rs * p.Cin;
+            const int kr = (p.S == 3) ? ((rs * 11) >> 5) : rs;     // rs / 3 for rs < 9
+            const int ks = rs - kr * p.S;
 #pragma unroll
             for (int ps = 0; ps < A_PASS; ++ps) {
-                int ih = a_ih0[ps] + akr[j];
-                int iw = a_iw0[ps] + aks[j];
-                bool ok = kvalid;
-                if (transposed) {
-                    ok = ok && (((ih | iw) & 1) == 0);
-                    ih >>= 1;
-                    iw >>= 1;
-                }
+                int ih = a_ih0[ps] + kr;
+                int iw = a_iw0[ps] + ks;
+                bool ok = kvalid && (((ih | iw) & tshift) == 0);   // transposed: only even positions carry data
+                ih >>= tshift;
+                iw >>= tshift;
                 ok = ok && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
+                // branch-free: invalid lanes read the (always valid) tensor base and are masked to zero afterwards, so
+                // all gathers of an iteration are in flight together
                 const long long pix = a_base[ps] + (long long)ih * p.W + iw;
-                const unsigned char* src = p.x + (pix * p.x_cs + akc[j]) * (long long)sizeof(T);
-                a_reg[ps][j] = ok ? ldg16(src) : zero4;
+                const long long off = ok ? (pix * p.x_cs + kc) * (long long)sizeof(T) : 0ll;
+                a_keep[ps][j] = ok ? 0xffffffffu : 0u;
+                a_reg[ps][j] = ldg16(p.x + off);
             }
-            ak[j] += BKT;
-            akc[j] += BKT;
-            while (akc[j] >= p.Cin) {
-                akc[j] -= p.Cin;
-                if (++aks[j] == p.S) {
-                    aks[j] = 0;
-                    ++akr[j];
-                }
-            }
+            ak[j] = k + BKT;
         }
 #pragma unroll
         for (int j = 0; j < B_SUBS; ++j) {
             const bool kvalid = bk[j] < p.K;
 #pragma unroll
-            for (int ps = 0; ps < B_PASS; ++ps)
-                b_reg[ps][j] = (kvalid && b_ok[ps]) ? ldg16(b_ptr[ps] + (long long)bk[j] * sizeof(T)) : zero4;
+            for (int ps = 0; ps < B_PASS; ++ps) {
+                const bool ok = kvalid && b_ok[ps];
+                b_keep[ps][j] = ok ? 0xffffffffu : 0u;
+                b_reg[ps][j] = ldg16(ok ? b_ptr[ps] + (long long)bk[j] * sizeof(T) : p.w);
+            }
             bk[j] += BKT;
         }
     };
@@ -185,12 +181,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
         for (int ps = 0; ps < A_PASS; ++ps)
 #pragma unroll
             for (int j = 0; j < A_SUBS; ++j)
-                *reinterpret_cast<u32x4*>(sA + (ps * A_RPP + a_row) * PITCH + (a_grp + A_GROUPS * j) * 64 + lvec * 16) = a_reg[ps][j];
+            {
+                u32x4 v = a_reg[ps][j];
+                const uint32_t keep = a_keep[ps][j];
+                v[0] &= keep; v[1] &= keep; v[2] &= keep; v[3] &= keep;
+                *reinterpret_cast<u32x4*>(sA + (ps * A_RPP + a_row) * PITCH + (a_grp + A_GROUPS * j) * 64 + lvec * 16) = v;
+            }
 #pragma unroll
         for (int ps = 0; ps < B_PASS; ++ps)
 #pragma unroll
             for (int j = 0; j < B_SUBS; ++j)
-                *reinterpret_cast<u32x4*>(sB + (ps * B_RPP + b_row) * PITCH + (b_grp + B_GROUPS * j) * 64 + lvec * 16) = b_reg[ps][j];
+            {
+                u32x4 v = b_reg[ps][j];
+                const uint32_t keep = b_keep[ps][j];
+                v[0] &= keep; v[1] &= keep; v[2] &= keep; v[3] &= keep;
+                *reinterpret_cast<u32x4*>(sB + (ps * B_RPP + b_row) * PITCH + (b_grp + B_GROUPS * j) * 64 + lvec * 16) = v;
+            }
     };
 
     f32x16 acc[WM_T][WN_T];
@@ -200,6 +206,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
         for (int j = 0; j < WN_T; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // epilogue operands are fetched up front so their latency hides under the K loop
+    float ep_sc[WN_T], ep_sh[WN_T];
+#pragma unroll
+    for (int j = 0; j < WN_T; ++j) {
+        const int co = n0 + (wn * WN_T + j) * 32 + (lane & 31);
+        const bool cvalid = co < p.Cout;
+        ep_sc[j] = (p.scale && cvalid) ? p.scale[co] : 1.f;
+        ep_sh[j] = (p.shift && cvalid) ? p.shift[co] : 0.f;
+    }
 
     const int niter = (p.K + BKT - 1) / BKT;
     const unsigned char* fragA = sA + (wm * WM_T * 32 + (lane & 31)) * PITCH + wk * KSUB * 64 + (lane >> 5) * 16;
@@ -264,8 +280,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
         const int cbase = n0 + (wn * WN_T + j) * 32;
         const int co = cbase + (lane & 31);
         const bool cvalid = co < p.Cout;
-        const float sc = (p.scale && cvalid) ? p.scale[co] : 1.f;
-        const float sh = (p.shift && cvalid) ? p.shift[co] : 0.f;
+        const float sc = ep_sc[j];
+        const float sh = ep_sh[j];
         const bool full_n = (cbase + 32 <= p.Cout) && !accum && !(p.flags & CONV_SCALAR_STORE);
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -348,14 +364,15 @@ template <typename T> static void dispatch(hipStream_t st, ConvArgs& a, int forc
     else if (a.Cout <= 32 && nblocks(a, 128, 32) >= FILL) cfg = 2;
     else if (a.Cout > 32 && nblocks(a, 64, 64) >= FILL) cfg = 3;
     else if (nblocks(a, 64, 32) >= FILL) cfg = 4;
-    else cfg = 5;
+    else cfg = (a.K > 8 * 64 / (int)sizeof(T)) ? 6 : 5;      // long K: stage 16 sub-chunks per iteration
     switch (cfg) {
         case 0: launch_cfg<T, 2, 2, 1, 2, 2, 2>(st, a); break;   // 128 x 128
         case 1: launch_cfg<T, 2, 2, 1, 2, 1, 2>(st, a); break;   // 128 x 64
         case 2: launch_cfg<T, 4, 1, 1, 1, 1, 2>(st, a); break;   // 128 x 32
         case 3: launch_cfg<T, 2, 2, 1, 1, 1, 2>(st, a); break;   // 64 x 64
         case 4: launch_cfg<T, 2, 1, 2, 1, 1, 2>(st, a); break;   // 64 x 32, K split 2
-        default: launch_cfg<T, 1, 1, 4, 1, 1, 2>(st, a); break;  // 32 x 32, K split 4
+        case 5: launch_cfg<T, 1, 1, 4, 1, 1, 2>(st, a); break;   // 32 x 32, K split 4, 8 sub-chunks / iteration
+        default: launch_cfg<T, 1, 1, 4, 1, 1, 4>(st, a); break;  // 32 x 32, K split 4, 16 sub-chunks / iteration
     }
 }
 
@@ -364,7 +381,7 @@ template <typename T> static void dispatch(hipStream_t st, ConvArgs& a, int forc
 using namespace fs;
 
 static int g_force_cfg = -1;
-/* test hook: force a tile configuration (0..5), -1 = heuristic */
+/* test hook: force a tile configuration (0..6), -1 = heuristic */
 extern "C" void fs_debug_force_conv_cfg(int cfg) { g_force_cfg = cfg; }
 
 extern "C" fs_status fs_conv2d_fwd(void* stream, const fs_conv_desc* d, const void* x, const void* w_packed,
@@ -387,6 +404,7 @@ extern "C" fs_status fs_conv2d_fwd(void* stream, const fs_conv_desc* d, const vo
     FS_REQUIRE(!((d->flags & FS_CONV_TRANSPOSED) && d->stride != 1), FS_ERR_INVALID,
                "fs_conv2d_fwd: FS_CONV_TRANSPOSED expects stride=1 (the zero-insertion is implicit)");
     const long long M = (long long)d->N * d->Ho * d->Wo;
+    FS_REQUIRE(d->R * d->S * d->Cin < (1 << 16), FS_ERR_UNSUPPORTED, "fs_conv2d_fwd: K = R*S*Cin too large");
     FS_REQUIRE(M < (1ll << 31) && (long long)d->N * d->H * d->W * d->x_cs < (1ll << 40), FS_ERR_UNSUPPORTED,
                "fs_conv2d_fwd: tensor too large");
     ConvArgs a;
@@ -402,6 +420,7 @@ extern "C" fs_status fs_conv2d_fwd(void* stream, const fs_conv_desc* d, const vo
     a.M = (int)M; a.K = d->R * d->S * d->Cin; a.HoWo = d->Ho * d->Wo;
     a.flags = d->flags;
     a.tiles_n = 1;
+    a.cin_magic = (unsigned)(((1ull << 32) + (unsigned)d->Cin - 1) / (unsigned)d->Cin);
     // 16-byte epilogue stores need an aligned slice; otherwise every tile takes the element-wise path
     if (!(aligned16(y) && (d->y_cs % vec == 0))) a.flags |= CONV_SCALAR_STORE;
     if (d->dtype == FS_F32) dispatch<float>((hipStream_t)stream, a, g_force_cfg);

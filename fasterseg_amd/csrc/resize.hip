@@ -55,10 +55,37 @@ __global__ void bilinear_fwd_kernel(int N, int Hi, int Wi, int Ho, int Wo, int c
     }
 }
 
-// NHWC (channel stride padded to a multiple of 4, pad lanes readable) -> NCHW.  One lane: 4 consecutive ow, 4 channels.
+// NHWC (channel stride padded to a multiple of 4, pad lanes readable) -> NCHW.  One lane: 4 consecutive ow x 4 channels.
+// Each tap is ONE vector load of 4 channels (8 B bf16 / 16 B fp32); the low-resolution logits are L2-resident, the
+// kernel is bound by the NCHW write (16-byte stores per channel plane).
+template <typename T> struct Quad;     // 4 consecutive channels
+template <> struct Quad<float> {
+    static __device__ __forceinline__ void load(const float* p, float* o) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+        o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+    }
+};
+template <> struct Quad<bf16_t> {
+    static __device__ __forceinline__ void load(const bf16_t* p, float* o) {
+        const uint2 v = *reinterpret_cast<const uint2*>(p);
+        o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+        o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+    }
+};
+template <typename TO> __device__ __forceinline__ void store4(TO* dst, const float* v);
+template <> __device__ __forceinline__ void store4<float>(float* dst, const float* v) {
+    *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+}
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* dst, const float* v) {
+    uint2 o;
+    o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+    o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+    *reinterpret_cast<uint2*>(dst) = o;
+}
+
 template <typename T, typename TO>
-__global__ void bilinear_fwd_nchw_kernel(int N, int Hi, int Wi, int Ho, int Wo, int C, float rh, float rw,
-                                         const T* __restrict__ x, int x_cs, TO* __restrict__ y) {
+__global__ __launch_bounds__(256) void bilinear_fwd_nchw_kernel(int N, int Hi, int Wi, int Ho, int Wo, int C, float rh, float rw,
+                                                                const T* __restrict__ x, int x_cs, TO* __restrict__ y) {
     const int wq = Wo >> 2;
     const int cg = (C + 3) >> 2;
     const long long total = (long long)N * cg * Ho * wq;
@@ -76,23 +103,18 @@ __global__ void bilinear_fwd_nchw_kernel(int N, int Hi, int Wi, int Ho, int Wo, 
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const Tap tw = make_tap(rw, ow0 + q, Wi);
+            float p00[4], p01[4], p10[4], p11[4];
+            Quad<T>::load(r0 + (long long)tw.i0 * x_cs, p00);
+            Quad<T>::load(r0 + (long long)tw.i1 * x_cs, p01);
+            Quad<T>::load(r1 + (long long)tw.i0 * x_cs, p10);
+            Quad<T>::load(r1 + (long long)tw.i1 * x_cs, p11);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float p00 = Elem<T>::load(r0 + (long long)tw.i0 * x_cs + k);
-                const float p01 = Elem<T>::load(r0 + (long long)tw.i1 * x_cs + k);
-                const float p10 = Elem<T>::load(r1 + (long long)tw.i0 * x_cs + k);
-                const float p11 = Elem<T>::load(r1 + (long long)tw.i1 * x_cs + k);
-                out[k][q] = th.l0 * (tw.l0 * p00 + tw.l1 * p01) + th.l1 * (tw.l0 * p10 + tw.l1 * p11);
-            }
+            for (int k = 0; k < 4; ++k)
+                out[k][q] = th.l0 * (tw.l0 * p00[k] + tw.l1 * p01[k]) + th.l1 * (tw.l0 * p10[k] + tw.l1 * p11[k]);
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (c0 + k < C) {
-                TO* dst = y + (((long long)n * C + c0 + k) * Ho + oh) * Wo + ow0;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) Elem<TO>::store(dst + q, out[k][q]);
-            }
-        }
+        for (int k = 0; k < 4; ++k)
+            if (c0 + k < C) store4<TO>(y + (((long long)n * C + c0 + k) * Ho + oh) * Wo + ow0, out[k]);
     }
 }
 
@@ -235,7 +257,7 @@ static fs_status check_resize(const char* fn, const fs_resize_desc* d) {
         FS_REQUIRE(d->C % vec == 0 && d->x_cs % vec == 0 && d->y_cs % vec == 0 && d->x_cs >= d->C && d->y_cs >= d->C,
                    FS_ERR_UNSUPPORTED, "%s: C=%d / strides (%d,%d) must be multiples of %d", fn, d->C, d->x_cs, d->y_cs, vec);
     } else {
-        FS_REQUIRE(d->x_cs >= ((d->C + 3) / 4) * 4, FS_ERR_INVALID,
+        FS_REQUIRE(d->x_cs >= ((d->C + 3) / 4) * 4 && d->x_cs % 4 == 0, FS_ERR_INVALID,
                    "%s: NCHW output needs the input channel stride padded to a multiple of 4 (got %d for C=%d)", fn, d->x_cs,
                    d->C);
         FS_REQUIRE(!d->relu, FS_ERR_UNSUPPORTED, "%s: relu not supported with NCHW output", fn);
@@ -249,8 +271,8 @@ extern "C" fs_status fs_bilinear_fwd(void* stream, const fs_resize_desc* d, cons
     FS_REQUIRE(x && y, FS_ERR_INVALID, "fs_bilinear_fwd: null pointer");
     const float rh = host_scale(d->Hi, d->Ho), rw = host_scale(d->Wi, d->Wo);
     hipStream_t st = (hipStream_t)stream;
+    FS_REQUIRE(aligned16(x) && aligned16(y), FS_ERR_INVALID, "fs_bilinear_fwd: operands must be 16-byte aligned");
     if (!d->out_nchw) {
-        FS_REQUIRE(aligned16(x) && aligned16(y), FS_ERR_INVALID, "fs_bilinear_fwd: operands must be 16-byte aligned");
         const int cv = d->C / vec_elems(d->dtype);
         const long long total = (long long)d->N * d->Ho * d->Wo * cv;
         if (d->dtype == FS_F32)

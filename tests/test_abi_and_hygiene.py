@@ -1,0 +1,79 @@
+"""CPU-side checks of the boundary: the shared library loads and exports every symbol include/fasterseg_hip.h declares
+(no compute is launched), the ctypes descriptors mirror the C structs, and the product never touches the oracle."""
+import ctypes
+import os
+import re
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "fasterseg_hip.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(fs_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from fasterseg_amd import _lib, build
+    build.build(verbose=False)
+    handle = _lib.lib()
+    names = declared_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(handle, n), "libfasterseg_hip.so does not export " + n
+    assert sorted(_lib.ALL_SYMBOLS) == names, "ctypes binding table and header disagree"
+    assert handle.fs_version() >= 100
+    assert handle.fs_packed_weight_elems(19, 1, 1, 128) == 19 * 128
+
+
+def test_descriptor_layouts_match_header():
+    from fasterseg_amd._lib import ConvDesc, ResizeDesc
+    text = open(HEADER).read()
+    conv = re.search(r"typedef struct fs_conv_desc \{(.*?)\} fs_conv_desc;", text, re.S).group(1)
+    conv = re.sub(r"/\*.*?\*/", "", conv, flags=re.S)
+    fields = [f.strip() for decl in re.findall(r"int ([^;]+);", conv) for f in decl.split(",")]
+    assert fields == [n for n, _ in ConvDesc._fields_]
+    rs = re.search(r"typedef struct fs_resize_desc \{(.*?)\} fs_resize_desc;", text, re.S).group(1)
+    rs = re.sub(r"/\*.*?\*/", "", rs, flags=re.S)
+    fields = [f.strip() for decl in re.findall(r"int ([^;]+);", rs) for f in decl.split(",")]
+    assert fields == [n for n, _ in ResizeDesc._fields_]
+    assert ctypes.sizeof(ConvDesc) == 4 * len(ConvDesc._fields_)
+
+
+def test_invalid_arguments_return_status_not_abort():
+    """Error convention of the boundary: status code + message, never a crash (validated before any launch)."""
+    from fasterseg_amd import _lib
+    handle = _lib.lib()
+    d = _lib.ConvDesc(1, 8, 8, 8, 8, 5, 5, 1, 2, 8, 8, 8, 8, 0, 0)         # 5x5 filter
+    buf = (ctypes.c_char * 64)()
+    status = handle.fs_conv2d_fwd(None, ctypes.byref(d), buf, buf, None, None, buf, None)
+    assert status != 0 and b"5x5" in handle.fs_last_error()
+    assert handle.fs_conv2d_fwd(None, None, None, None, None, None, None, None) == 1
+
+
+def test_product_does_not_import_the_oracle():
+    """The oracle is test infrastructure: nothing under fasterseg_amd/ may import, call or read oracle/ or tests/."""
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "fasterseg_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                if re.search(r"^\s*(from|import)\s+(oracle|tests)\b", src, re.M) or "oracle/" in src.replace("the oracle", ""):
+                    bad.append(os.path.join(dirpath, f))
+    assert not bad, bad
+
+
+def test_no_compat_layers_in_kernels():
+    for f in os.listdir(os.path.join(ROOT, "fasterseg_amd", "csrc")):
+        if f.endswith((".hip", ".h", ".cpp")):
+            src = open(os.path.join(ROOT, "fasterseg_amd", "csrc", f)).read()
+            assert "__HIP_PLATFORM" not in src and "cuda_runtime" not in src and "hipify" not in src.lower(), f
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    code = ("import fasterseg_amd._lib as L, sys; L.LIB_PATH='/nonexistent/libfasterseg_hip.so'; L._lib=None\n"
+            "try:\n    L.lib()\nexcept ImportError as e:\n    print('LOUD', e)\n")
+    out = subprocess.run(["python", "-c", code], capture_output=True, text=True, cwd=ROOT)
+    assert "LOUD" in out.stdout and "no CPU/eager fallback" in out.stdout

@@ -75,7 +75,7 @@ def force_cfg(request):
     _lib.lib().fs_debug_force_conv_cfg(-1)
 
 
-@pytest.mark.parametrize("force_cfg", [-1, 0, 1, 2, 3, 4, 5], indirect=True, ids=lambda c: "cfg%d" % c)
+@pytest.mark.parametrize("force_cfg", [-1, 0, 1, 2, 3, 4, 5, 6], indirect=True, ids=lambda c: "cfg%d" % c)
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=[str(c) for c in CONV_CASES])
 def test_conv2d_fwd(case, dtype, force_cfg):
