@@ -1,0 +1,99 @@
+"""Data parallelism for the train steps: one process per GPU, gradients of all parameters live in ONE flat fp32 buffer
+(param.grad are views into it), all-reduced over RCCL (torch.distributed backend "nccl" on ROCm) in a few large
+buckets that are launched asynchronously as soon as backward has produced them.
+
+The reference is single-GPU (no DataParallel/DDP/SyncBN anywhere); this is the one strategy the build
+adds (§8e).  Semantics kept: BatchNorm statistics stay per rank; parameters that receive no gradient in a step (unused
+USBatchNorm2d widths, USBN's dead affine, FeatureFusion.channel_attention) contribute zeros to the buffer and are
+hidden from the optimizer for that step (grad=None), exactly as autograd leaves them in the reference, so weight decay
+and momentum do not touch them.  xGMI is point-to-point (7 links/GPU): large buckets let RCCL use its
+all-links reduce-scatter/all-gather schedule instead of paying per-message latency; the student's 17.6 MB of gradients
+go out as a single bucket.
+"""
+import torch
+import torch.distributed as dist
+
+
+class FlatGradientSync:
+    def __init__(self, params, bucket_mb=256, group=None, average=True):
+        self.params = [p for p in params if p.requires_grad]
+        self.group = group
+        self.average = average
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        dev = self.params[0].device
+        sizes = [p.numel() for p in self.params]
+        self.flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        self.views, self.bucket_of = [], []
+        # buckets follow reverse registration order (gradients of the last layers are ready first)
+        order = list(range(len(self.params)))[::-1]
+        limit = max(1, int(bucket_mb * (1 << 20) / 4))
+        off, start, nb = 0, 0, 0
+        self.offsets = [0] * len(self.params)
+        self.buckets = []            # (begin, end) element ranges of self.flat
+        for i in order:
+            self.offsets[i] = off
+            off += sizes[i]
+            if off - start >= limit:
+                self.buckets.append((start, off)); start = off
+        if off > start or not self.buckets:
+            self.buckets.append((start, off))
+        self.bucket_id = [next(b for b, (s, e) in enumerate(self.buckets) if s <= self.offsets[i] < e) for i in range(len(self.params))]
+        self.pending = [0] * len(self.buckets)
+        self.count = [sum(1 for i in range(len(self.params)) if self.bucket_id[i] == b) for b in range(len(self.buckets))]
+        self.handles = {}
+        self.touched = [False] * len(self.params)
+        for i, p in enumerate(self.params):
+            v = self.flat[self.offsets[i]:self.offsets[i] + sizes[i]].view_as(p)
+            self.views.append(v)
+            if hasattr(p, "register_post_accumulate_grad_hook"):
+                p.register_post_accumulate_grad_hook(self._make_hook(i))
+        self.prepare()
+
+    def _make_hook(self, i):
+        def hook(param):
+            if not self.touched[i]:
+                self.touched[i] = True
+                b = self.bucket_id[i]
+                self.pending[b] += 1
+                if self.pending[b] == self.count[b]:
+                    self._launch(b)
+        return hook
+
+    def _launch(self, b):
+        if self.world > 1 and b not in self.handles:
+            s, e = self.buckets[b]
+            self.handles[b] = dist.all_reduce(self.flat[s:e], group=self.group, async_op=True)
+
+    def prepare(self):
+        """Call before each backward: zero the buffer and point every .grad at its slice."""
+        self.flat.zero_()
+        self.handles = {}
+        self.pending = [0] * len(self.buckets)
+        self.touched = [False] * len(self.params)
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+
+    def sync(self):
+        """Call after backward: finish the all-reduce of every bucket, average, hide untouched parameters from the
+        optimizer (grad=None, as autograd leaves them in a single-GPU run)."""
+        for b in range(len(self.buckets)):
+            self._launch(b)
+        for h in self.handles.values():
+            h.wait()
+        if self.world > 1 and self.average:
+            self.flat.div_(self.world)
+        if hasattr(self.params[0], "register_post_accumulate_grad_hook"):
+            for p, t in zip(self.params, self.touched):
+                if not t:
+                    p.grad = None
+
+    def grad_norm(self):
+        return self.flat.norm()
+
+
+def broadcast_parameters(module, src=0, group=None):
+    """Identical replicas at step 0 (parameters and BN buffers)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src, group=group)

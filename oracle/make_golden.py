@@ -311,12 +311,41 @@ def gen_lut():
     print("LUT entries:", len(table))
 
 
+# ------------------------------------------------------------------------------------------------
+# 6. step glue: OHEM cross-entropy (tools/seg_opr/loss_opr.py) on seeded logits
+# ------------------------------------------------------------------------------------------------
+def gen_loss():
+    store = {}
+    with ref_loader.reference("train") as wd:
+        tools = os.path.join(os.path.dirname(wd), "tools")       # train/train.py reaches it through config's add_path
+        sys.path.insert(0, tools)
+        for m in [k for k in sys.modules if k.split(".")[0] in ("seg_opr", "engine")]:
+            sys.modules.pop(m)
+        from seg_opr.loss_opr import ProbOhemCrossEntropy2d
+        for i, (shape, thresh, min_kept) in enumerate((((2, 19, 16, 24), 0.7, 48), ((1, 19, 12, 20), 0.7, 200),
+                                                       ((2, 19, 8, 8), 0.3, 16), ((1, 19, 8, 8), 0.7, 1000))):
+            g = torch.Generator().manual_seed(50 + i)
+            pred = (torch.randn(shape, generator=g) * 2).requires_grad_(True)
+            target = torch.randint(0, 19, (shape[0], shape[2], shape[3]), generator=g)
+            target[torch.rand(target.shape, generator=g) < 0.1] = 255
+            crit = ProbOhemCrossEntropy2d(ignore_label=255, thresh=thresh, min_kept=min_kept, use_weight=False)
+            loss = crit(pred, target.clone())
+            loss.backward()
+            store["ohem%d/pred" % i] = _np(pred)
+            store["ohem%d/target" % i] = _np(target).astype(np.int64)
+            store["ohem%d/cfg" % i] = np.array([thresh, min_kept])
+            store["ohem%d/loss" % i] = np.array([float(loss.detach())])
+            store["ohem%d/grad" % i] = _np(pred.grad)
+    np.savez_compressed(os.path.join(GOLD, "loss.npz"), **store)
+    print("loss cases:", [float(store["ohem%d/loss" % i][0]) for i in range(4)])
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(max(1, os.cpu_count() or 1))
-    which = sys.argv[1:] or ["arch", "decode", "ops", "nets", "lut"]
+    which = sys.argv[1:] or ["arch", "decode", "ops", "nets", "lut", "loss"]
     for w in which:
-        {"arch": gen_arch, "decode": gen_decode_cases, "ops": gen_ops, "nets": gen_nets, "lut": gen_lut}[w]()
+        {"arch": gen_arch, "decode": gen_decode_cases, "ops": gen_ops, "nets": gen_nets, "lut": gen_lut, "loss": gen_loss}[w]()
 
 
 if __name__ == "__main__":
