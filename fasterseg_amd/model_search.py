@@ -1,0 +1,388 @@
+"""Supernet for architecture search (drop-in for the reference's search/model_search.py).
+
+`Network_Multi_Path(num_classes, layers, criterion, Fch, width_mult_list, prun_modes, stem_head_width)` keeps the
+reference's module tree (`stem.<i>`, `cells.<l>.<s>.{_op,downsample}._ops.<k>`, `refine32/refine16`, `head*`), its
+architecture parameters (`alpha_<i>_<s>`, `beta_<i>_<s>`, `ratio_<i>_<s>`, `_arch_parameters`, `_arch_names`) and the
+methods the search driver calls (`forward`, `_loss`, `forward_latency`, `sample_prun_ratio`, `arch_idx`, `prun_mode`).
+
+What differs underneath: every primitive is a chain of fused HIP kernels (operations.py); the MixedOp sum
+`result + op(x) * w * r0 * r1` (model_search.py:76-78) and the beta-weighted merges (:330-333) are one
+fs_axpy_channels pass per term with the scalar coefficient left on the device (its gradient is a fused full-tensor dot,
+functional.scale_accumulate), and the `betas[..] > 0` tests that make the reference synchronise the GPU once per cell
+are evaluated once per forward.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import functional as FN
+from .genotypes import PRIMITIVES
+from .operations import *            # noqa: F401,F403
+from .operations import OPS, BasicResidual2x, ConvNorm
+from .seg_oprs import Head
+
+
+# https://github.com/YongfeiYan/Gumbel_Softmax_VAE (as cited by the reference)
+def sample_gumbel(shape, eps=1e-20, device=None):
+    U = torch.rand(shape)                       # host RNG like the reference (model_search.py:15-17): ranks stay in sync
+    if device is not None:
+        U = U.to(device)
+    return -torch.log(-torch.log(U + eps) + eps)
+
+
+def gumbel_softmax_sample(logits, temperature=1):
+    y = logits + sample_gumbel(logits.size(), device=logits.device)
+    return F.softmax(y / temperature, dim=-1)
+
+
+def gumbel_softmax(logits, temperature=1, hard=False):
+    """
+    ST-gumple-softmax
+    input: [*, n_class]
+    return: flatten --> [*, n_class] an one-hot vector
+    """
+    y = gumbel_softmax_sample(logits, temperature)
+    if not hard:
+        return y
+    shape = y.size()
+    _, ind = y.max(dim=-1)
+    y_hard = torch.zeros_like(y).view(-1, shape[-1])
+    y_hard.scatter_(1, ind.view(-1, 1), 1)
+    y_hard = y_hard.view(*shape)
+    # straight-through: forward one-hot, gradient of the soft sample
+    return (y_hard - y).detach() + y
+
+
+def _width_and_score(ratio, width_mult_list):
+    """int: force #channel; tensor: arch_ratio; float(<=1): force width (reference comment, model_search.py:61)."""
+    if isinstance(ratio, torch.Tensor):
+        k = int(ratio.argmax())
+        return width_mult_list[k], ratio[k]
+    return ratio, 1.
+
+
+class MixedOp(nn.Module):
+
+    def __init__(self, C_in, C_out, stride=1, width_mult_list=[1.]):
+        super(MixedOp, self).__init__()
+        self._ops = nn.ModuleList()
+        self._width_mult_list = width_mult_list
+        for primitive in PRIMITIVES:
+            self._ops.append(OPS[primitive](C_in, C_out, stride, True, width_mult_list=width_mult_list))
+
+    def set_prun_ratio(self, ratio):
+        for op in self._ops:
+            op.set_ratio(ratio)
+
+    def forward(self, x, weights, ratios):
+        ratio0, r_score0 = _width_and_score(ratios[0], self._width_mult_list)
+        ratio1, r_score1 = _width_and_score(ratios[1], self._width_mult_list)
+        self.set_prun_ratio((ratio0, ratio1))
+        result = None
+        for w, op in zip(weights, self._ops):
+            result = FN.scale_accumulate(result, op(x), w * r_score0 * r_score1)
+        return result
+
+    def forward_latency(self, size, weights, ratios):
+        ratio0, r_score0 = _width_and_score(ratios[0], self._width_mult_list)
+        ratio1, r_score1 = _width_and_score(ratios[1], self._width_mult_list)
+        self.set_prun_ratio((ratio0, ratio1))
+        result = 0
+        for w, op in zip(weights, self._ops):
+            latency, size_out = op.forward_latency(size)
+            result = result + latency * w * r_score0 * r_score1
+        return result, size_out
+
+
+class Cell(nn.Module):
+    def __init__(self, C_in, C_out=None, down=True, width_mult_list=[1.]):
+        super(Cell, self).__init__()
+        self._C_in = C_in
+        if C_out is None: C_out = C_in
+        self._C_out = C_out
+        self._down = down
+        self._width_mult_list = width_mult_list
+        self._op = MixedOp(C_in, C_out, width_mult_list=width_mult_list)
+        if self._down:
+            self.downsample = MixedOp(C_in, C_in * 2, stride=2, width_mult_list=width_mult_list)
+
+    def forward(self, input, alphas, ratios):
+        # ratios: (in, out, down)
+        out = self._op(input, alphas, (ratios[0], ratios[1]))
+        assert (self._down and (ratios[2] is not None)) or ((not self._down) and (ratios[2] is None))
+        down = self.downsample(input, alphas, (ratios[0], ratios[2])) if self._down else None
+        return out, down
+
+    def forward_latency(self, size, alphas, ratios):
+        out = self._op.forward_latency(size, alphas, (ratios[0], ratios[1]))
+        assert (self._down and (ratios[2] is not None)) or ((not self._down) and (ratios[2] is None))
+        down = self.downsample.forward_latency(size, alphas, (ratios[0], ratios[2])) if self._down else None
+        return out, down
+
+
+def _weighted_sum(weights, tensors):
+    """sum(w * t) over the non-None tensors with device-resident scalar weights (model_search.py:331-332)."""
+    acc = None
+    for w, t in zip(weights, tensors):
+        if t is not None:
+            acc = FN.scale_accumulate(acc, t, w)
+    return 0 if acc is None else acc
+
+
+class Network_Multi_Path(nn.Module):
+    def __init__(self, num_classes=19, layers=16, criterion=nn.CrossEntropyLoss(ignore_index=-1), Fch=12, width_mult_list=[1., ],
+                 prun_modes=['arch_ratio', ], stem_head_width=[(1., 1.), ]):
+        super(Network_Multi_Path, self).__init__()
+        self._num_classes = num_classes
+        assert layers >= 3
+        self._layers = layers
+        self._criterion = criterion
+        self._Fch = Fch
+        self._width_mult_list = width_mult_list
+        self._prun_modes = prun_modes
+        self.prun_mode = None  # prun_mode is higher priority than _prun_modes
+        self._stem_head_width = stem_head_width
+        self._flops = 0
+        self._params = 0
+        nf = self.num_filters
+
+        self.stem = nn.ModuleList([
+            nn.Sequential(
+                ConvNorm(3, nf(2, sr) * 2, kernel_size=3, stride=2, padding=1, bias=False, groups=1, slimmable=False),
+                BasicResidual2x(nf(2, sr) * 2, nf(4, sr) * 2, kernel_size=3, stride=2, groups=1, slimmable=False),
+                BasicResidual2x(nf(4, sr) * 2, nf(8, sr), kernel_size=3, stride=2, groups=1, slimmable=False)
+            ) for sr, _ in self._stem_head_width])
+
+        self.cells = nn.ModuleList()
+        for l in range(layers):
+            last = (l == layers - 1)
+            scales = 1 if l == 0 else (2 if l == 1 else 3)
+            row = nn.ModuleList()
+            for s in range(scales):
+                # a cell can down-sample unless it sits on the coarsest scale or in the last layer
+                down = (not last) and s < 2
+                row.append(Cell(nf(8 * 2 ** s), down=down, width_mult_list=width_mult_list))
+            self.cells.append(row)
+
+        def cn(cin, cout, k, hr):
+            return ConvNorm(nf(cin, hr), nf(cout, hr), kernel_size=k, padding=(1 if k == 3 else None), bias=False, groups=1,
+                            slimmable=False)
+        self.refine32 = nn.ModuleList([nn.ModuleList([cn(32, 16, 1, hr), cn(32, 16, 3, hr), cn(16, 8, 1, hr), cn(16, 8, 3, hr)])
+                                       for _, hr in self._stem_head_width])
+        self.refine16 = nn.ModuleList([nn.ModuleList([cn(16, 8, 1, hr), cn(16, 8, 3, hr)]) for _, hr in self._stem_head_width])
+
+        self.head0 = nn.ModuleList([Head(nf(8, hr), num_classes, False) for _, hr in self._stem_head_width])
+        self.head1 = nn.ModuleList([Head(nf(8, hr), num_classes, False) for _, hr in self._stem_head_width])
+        self.head2 = nn.ModuleList([Head(nf(8, hr), num_classes, False) for _, hr in self._stem_head_width])
+        self.head02 = nn.ModuleList([Head(nf(8, hr) * 2, num_classes, False) for _, hr in self._stem_head_width])
+        self.head12 = nn.ModuleList([Head(nf(8, hr) * 2, num_classes, False) for _, hr in self._stem_head_width])
+
+        # contains arch_param names: {"alphas": alphas, "betas": betas, "ratios": ratios}
+        self._arch_names = []
+        self._arch_parameters = []
+        for i in range(len(self._prun_modes)):
+            arch_name, arch_param = self._build_arch_parameters(i)
+            self._arch_names.append(arch_name)
+            self._arch_parameters.append(arch_param)
+            self._reset_arch_parameters(i)
+        # switch set of arch if we have more than 1 arch
+        self.arch_idx = 0
+
+    def num_filters(self, scale, width=1.0):
+        return int(np.round(scale * self._Fch * width))
+
+    # ------------------------------------------------------------------------------------------------------
+    def sample_prun_ratio(self, mode="arch_ratio"):
+        '''
+        mode: "min"|"max"|"random"|"arch_ratio"(default)
+        '''
+        assert mode in ["min", "max", "random", "arch_ratio"]
+        counts = (self._layers - 1, self._layers - 1, self._layers - 2)
+        if mode == "arch_ratio":
+            names = self._arch_names[self.arch_idx]["ratios"]
+            return [[gumbel_softmax(F.log_softmax(getattr(self, names[s])[layer], dim=-1), hard=True) for layer in range(counts[s])]
+                    for s in range(3)]
+        if mode == "random":      # same draw order as the reference: all of scale 0, then scale 1, then scale 2
+            return [[np.random.choice(self._width_mult_list) for _ in range(counts[s])] for s in range(3)]
+        w = self._width_mult_list[0] if mode == "min" else self._width_mult_list[-1]
+        return [[w] * counts[s] for s in range(3)]
+
+    def _arch_tensors(self, alpha=True, beta=True):
+        names = self._arch_names[self.arch_idx]
+        if alpha:
+            alphas = [F.softmax(getattr(self, n), dim=-1) for n in names["alphas"]]
+        else:
+            alphas = [torch.ones_like(getattr(self, n)) * 1. / len(PRIMITIVES) for n in names["alphas"]]
+        if beta:
+            betas = [None] + [F.softmax(getattr(self, n), dim=-1) for n in names["betas"]]
+        else:
+            betas = [None] + [torch.ones_like(getattr(self, n)) * 1. / 2 for n in names["betas"]]
+        return alphas, betas
+
+    def _cell_ratio(self, i, j, ratios):
+        """(in, out, down) width spec of cell (layer i, scale j) — reference forward :300-316."""
+        shw = self._stem_head_width[self.arch_idx]
+        if i == 0 and j == 0:
+            return (shw[0], ratios[j][i - j], ratios[j + 1][i - j])
+        if i == self._layers - 1:
+            return (ratios[j][i - j - 1] if j == 0 else ratios[j][i - j], shw[1], None)
+        if j == 2:
+            return (ratios[j][i - j], ratios[j][i - j + 1], None)
+        if j == 0:
+            return (ratios[j][i - j - 1], ratios[j][i - j], ratios[j + 1][i - j])
+        return (ratios[j][i - j], ratios[j][i - j + 1], ratios[j + 1][i - j])
+
+    def forward(self, input):
+        k = self.arch_idx
+        stem, refine16, refine32 = self.stem[k], self.refine16[k], self.refine32[k]
+        alphas, betas = self._arch_tensors()
+        mode = self.prun_mode if self.prun_mode is not None else self._prun_modes[k]
+        ratios = self.sample_prun_ratio(mode=mode)
+        # one host read of the whole beta tables instead of one implicit sync per cell (reference :326-328)
+        beta_pos = [None] + [(b > 0).tolist() for b in betas[1:]]
+
+        out_prev = [[stem(input), None]]  # stem: one cell
+        # i: layer | j: scale
+        for i, cells in enumerate(self.cells):
+            out = []
+            for j, cell in enumerate(cells):
+                alpha = alphas[j][i - j]
+                ratio = self._cell_ratio(i, j, ratios)
+                # out,down -- 0: from down; 1: from keep
+                if j == 0:
+                    out.append(cell(out_prev[0][0], alpha, ratio))
+                elif i == j:
+                    out.append(cell(out_prev[j - 1][1], alpha, ratio))
+                else:
+                    out0 = down0 = out1 = down1 = None
+                    if beta_pos[j][i - j - 1][0]:
+                        out0, down0 = cell(out_prev[j - 1][1], alpha, ratio)
+                    if beta_pos[j][i - j - 1][1]:
+                        out1, down1 = cell(out_prev[j][0], alpha, ratio)
+                    b = betas[j][i - j - 1]
+                    out.append((_weighted_sum(b, [out0, out1]), _weighted_sum(b, [down0, down1])))
+            out_prev = out
+        ###################################
+        up2 = lambda t: FN.interpolate(t, scale_factor=2)
+        out0 = out[0][0]
+        out1 = refine16[1](FN.cat([up2(refine16[0](out[1][0])), out[0][0]]))
+        out2 = refine32[1](FN.cat([up2(refine32[0](out[2][0])), out[1][0]]))
+        out2 = refine32[3](FN.cat([up2(refine32[2](out2)), out[0][0]]))
+
+        preds = [self.head0[k](out0), self.head1[k](out1), self.head2[k](out2),
+                 self.head02[k](FN.cat([out0, out2])), self.head12[k](FN.cat([out1, out2]))]
+        if not self.training:
+            return tuple(FN.interpolate(p, scale_factor=8, out_nchw=1) for p in preds)
+        # train mode: 1/8-resolution logits (labels are down-sampled x8, search/dataloader.py:25); hand the loss a
+        # contiguous NCHW fp32 tensor like the reference does
+        return tuple(FN.interpolate(p, size=(p.size(2), p.size(3)), out_nchw=1) for p in preds)
+        ###################################
+
+    def forward_latency(self, size, alpha=True, beta=True, ratio=True):
+        k = self.arch_idx
+        stem = self.stem[k]
+        alphas, betas = self._arch_tensors(alpha, beta)
+        if ratio:
+            mode = self.prun_mode if self.prun_mode is not None else self._prun_modes[k]
+            ratios = self.sample_prun_ratio(mode=mode)
+        else:
+            ratios = self.sample_prun_ratio(mode='max')
+        beta_pos = [None] + [(b > 0).tolist() for b in betas[1:]]
+
+        stem_latency = 0
+        for m in stem:
+            latency, size = m.forward_latency(size)
+            stem_latency = stem_latency + latency
+        out_prev = [[size, None]]  # stem: one cell
+        latency_total = [[stem_latency, 0], [0, 0], [0, 0]]  # (out, down)
+
+        for i, cells in enumerate(self.cells):
+            out = []
+            latency = []
+            for j, cell in enumerate(cells):
+                a = alphas[j][i - j]
+                r = self._cell_ratio(i, j, ratios)
+                if j == 0 or i == j:
+                    src = out_prev[0][0] if j == 0 else out_prev[j - 1][1]
+                    o, d = cell.forward_latency(src, a, r)
+                    out.append((o[1], d[1] if d is not None else None))
+                    latency.append([o[0], d[0] if d is not None else None])
+                else:
+                    out0 = down0 = out1 = down1 = None
+                    if beta_pos[j][i - j - 1][0]:      # from down
+                        out0, down0 = cell.forward_latency(out_prev[j - 1][1], a, r)
+                    if beta_pos[j][i - j - 1][1]:      # from keep
+                        out1, down1 = cell.forward_latency(out_prev[j][0], a, r)
+                    assert (out0 is None and out1 is None) or out0[1] == out1[1]
+                    assert (down0 is None and down1 is None) or down0[1] == down1[1]
+                    out.append((out0[1], down0[1] if down0 is not None else None))
+                    b = betas[j][i - j - 1]
+                    latency.append([
+                        sum(w * o for w, o in zip(b, [out0[0], out1[0]])),
+                        sum(w * d if d is not None else 0 for w, d in zip(b, [down0[0] if down0 is not None else None,
+                                                                           down1[0] if down1 is not None else None])),
+                    ])
+            out_prev = out
+            for ii, lat in enumerate(latency):
+                # layer: i | scale: ii.  NOTE the mixing weights below use the loop variable `j` left over from the
+                # scale loop (= the last scale of this layer), exactly as the reference does (:468-469).
+                if ii == 0:
+                    if lat[0] is not None: latency_total[ii][0] = latency_total[ii][0] + lat[0]
+                    if lat[1] is not None: latency_total[ii][1] = latency_total[ii][0] + lat[1]
+                elif i == ii:
+                    if lat[0] is not None: latency_total[ii][0] = latency_total[ii - 1][1] + lat[0]
+                    if lat[1] is not None: latency_total[ii][1] = latency_total[ii - 1][1] + lat[1]
+                else:
+                    bw = betas[j][i - j - 1]
+                    if lat[0] is not None: latency_total[ii][0] = bw[1] * latency_total[ii][0] + bw[0] * latency_total[ii - 1][1] + lat[0]
+                    if lat[1] is not None: latency_total[ii][1] = bw[1] * latency_total[ii][0] + bw[0] * latency_total[ii - 1][1] + lat[1]
+        ###################################
+        return sum([latency_total[0][0], latency_total[1][0], latency_total[2][0]])
+        ###################################
+
+    def _loss(self, input, target, pretrain=False):
+        loss = 0
+        run = lambda: sum(self._criterion(logit, target) for logit in self(input))
+        if pretrain is not True:
+            # "random width": sampled by gambel softmax
+            self.prun_mode = None
+            for idx in range(len(self._arch_names)):
+                self.arch_idx = idx
+                loss = loss + run()
+        if len(self._width_mult_list) > 1:
+            for mode in (("max", "min", "random", "random") if pretrain == True else ("max", "min")):
+                self.prun_mode = mode
+                loss = loss + run()
+        elif pretrain == True and len(self._width_mult_list) == 1:
+            self.prun_mode = "max"
+            loss = loss + run()
+        return loss
+
+    # ------------------------------------------------------------------------------------------------------
+    def _arch_shapes(self, idx):
+        num_ops = len(PRIMITIVES)
+        num_widths = len(self._width_mult_list) if self._prun_modes[idx] == 'arch_ratio' else 1
+        L = self._layers
+        return {"alphas": [(L, num_ops), (L - 1, num_ops), (L - 2, num_ops)],
+                "betas": [(L - 2, 2), (L - 3, 2)],              # in-degree probs; 0: from down, 1: from keep
+                "ratios": [(L - 1, num_widths), (L - 1, num_widths), (L - 2, num_widths)]}
+
+    def _build_arch_parameters(self, idx):
+        names = {"alphas": ["alpha_" + str(idx) + "_" + str(s) for s in [0, 1, 2]],
+                 "betas": ["beta_" + str(idx) + "_" + str(s) for s in [1, 2]],
+                 "ratios": ["ratio_" + str(idx) + "_" + str(s) for s in [0, 1, 2]]}
+        shapes = self._arch_shapes(idx)
+        params = []
+        for kind in ("alphas", "betas", "ratios"):
+            for name, shape in zip(names[kind], shapes[kind]):
+                setattr(self, name, nn.Parameter(1e-3 * torch.ones(*shape), requires_grad=True))
+                params.append(getattr(self, name))
+        return names, params
+
+    def _reset_arch_parameters(self, idx):
+        shapes = self._arch_shapes(idx)
+        for kind in ("alphas", "betas", "ratios"):
+            for name, shape in zip(self._arch_names[idx][kind], shapes[kind]):
+                p = getattr(self, name)
+                p.data = 1e-3 * torch.ones(*shape, device=p.device)

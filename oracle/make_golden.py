@@ -340,12 +340,93 @@ def gen_loss():
     print("loss cases:", [float(store["ohem%d/loss" % i][0]) for i in range(4)])
 
 
+# ------------------------------------------------------------------------------------------------
+# 7. supernet (search/model_search.py): eval forward, pretrain/search losses + gradients, latency model
+# ------------------------------------------------------------------------------------------------
+SUPERNET_CFG = dict(num_classes=19, layers=6, Fch=12, width_mult_list=WML, prun_modes=['max', 'arch_ratio'],
+                    stem_head_width=[(1, 1), (8. / 12, 8. / 12)])
+
+
+def gen_supernet():
+    store, meta = {}, {}
+    with ref_loader.reference("search"):
+        import model_search
+        real_cuda = torch.Tensor.cuda
+        torch.Tensor.cuda = lambda self, *a, **k: self          # the reference hard-codes .cuda() (model_search.py:16,373-384)
+        try:
+            crit = torch.nn.CrossEntropyLoss(ignore_index=255)
+            for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+                net = model_search.Network_Multi_Path(criterion=crit, **SUPERNET_CFG)
+                sd = seeded_state(net.state_dict(), 777)
+                for k in list(sd):                              # arch params: small random logits instead of the 1e-3 init
+                    if k.split("_")[0] in ("alpha", "beta", "ratio"):
+                        sd[k] = sd[k] * 5.0
+                net.load_state_dict(sd)
+                net = net.to(dt)
+                if tag == "f32":
+                    meta["state_shapes"] = {k: list(v.shape) for k, v in net.state_dict().items()}
+                    meta["num_params"] = int(sum(p.numel() for p in net.parameters()))
+                x = seeded_input((2, 3, 128, 256), 31).to(dt)
+                g = torch.Generator().manual_seed(32)
+                target = torch.randint(0, 19, (2, 16, 32), generator=g)
+                target[torch.rand(2, 16, 32, generator=g) < 0.05] = 255
+                if tag == "f32":
+                    store["target"] = _np(target)
+                    net.eval()
+                    for idx in (0, 1):
+                        net.arch_idx = idx
+                        net.prun_mode = "max"
+                        with torch.no_grad():
+                            preds = net(x)
+                        for i, pr in enumerate(preds):
+                            store["eval_arch%d/pred%d_sub" % (idx, i)] = _np(pr[:, :, ::4, ::4]).astype(np.float32)
+                net.train()
+                for mode in ("pretrain", "search"):
+                    net.zero_grad()
+                    np.random.seed(5)
+                    torch.manual_seed(6)
+                    net.arch_idx = 0
+                    loss = net._loss(x, target, mode == "pretrain")
+                    loss.backward()
+                    store["%s_%s/loss" % (mode, tag)] = np.array([float(loss.detach())])
+                    norms = {k: float(p.grad.norm()) for k, p in net.named_parameters() if p.grad is not None}
+                    with open(os.path.join(GOLD, "supernet_%s_%s_gradnorms.json" % (mode, tag)), "w") as f:
+                        json.dump(norms, f)
+                    for k in ("alpha_0_0", "alpha_1_1", "beta_1_1", "beta_1_2", "ratio_1_0", "ratio_1_2",
+                              "cells.1.0._op._ops.3.conv1.weight", "cells.2.1.downsample._ops.0.conv2.weight",
+                              "cells.3.2._op._ops.4.bn2.bn.4.weight", "stem.0.0.conv.0.weight", "head02.0.conv_1x1.bias"):
+                        p_ = dict(net.named_parameters())[k]
+                        if p_.grad is not None:
+                            _put(store, "%s_%s/g/%s" % (mode, tag, k), p_.grad.float())
+                    print("supernet", mode, tag, float(loss.detach()), "params with grad:", len(norms))
+                if tag == "f32":
+                    # differentiable latency model (reads search/latency_lookup_table.npy = the shipped 1080Ti LUT)
+                    net.arch_idx = 1
+                    net.prun_mode = None
+                    for a, b, r in ((True, False, False), (False, True, False), (False, False, True), (True, True, True)):
+                        net.zero_grad()
+                        torch.manual_seed(9)
+                        lat = net.forward_latency((3, 1024, 2048), alpha=a, beta=b, ratio=r)
+                        lat.backward()
+                        key = "lat_%d%d%d" % (a, b, r)
+                        store[key + "/value"] = np.array([float(lat.detach())])
+                        for k in ("alpha_1_0", "alpha_1_2", "beta_1_1", "ratio_1_1"):
+                            gr = getattr(net, k).grad
+                            store[key + "/g/" + k] = _np(gr) if gr is not None else np.zeros(1, np.float32)
+                        print("supernet latency", key, float(lat.detach()))
+        finally:
+            torch.Tensor.cuda = real_cuda
+    np.savez_compressed(os.path.join(GOLD, "supernet.npz"), **store)
+    with open(os.path.join(GOLD, "supernet_meta.json"), "w") as f:
+        json.dump(meta, f)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(max(1, os.cpu_count() or 1))
-    which = sys.argv[1:] or ["arch", "decode", "ops", "nets", "lut", "loss"]
+    which = sys.argv[1:] or ["arch", "decode", "ops", "nets", "lut", "loss", "supernet"]
     for w in which:
-        {"arch": gen_arch, "decode": gen_decode_cases, "ops": gen_ops, "nets": gen_nets, "lut": gen_lut, "loss": gen_loss}[w]()
+        {"arch": gen_arch, "decode": gen_decode_cases, "ops": gen_ops, "nets": gen_nets, "lut": gen_lut, "loss": gen_loss, "supernet": gen_supernet}[w]()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,118 @@
+"""Supernet (fasterseg_amd.model_search) vs fixtures produced by the reference's search/model_search.py.
+CPU part: module tree / state_dict parity and the differentiable latency model (pure host logic over the LUT).
+GPU part: eval forward, pretrain and search losses + gradients through every primitive at every width."""
+import numpy as np
+import pytest
+import torch
+
+from oracle.seeded import seeded_input, seeded_state
+from tests._util import assert_close_golden, golden_get, load_json, load_npz
+
+WML = [4. / 12, 6. / 12, 8. / 12, 10. / 12, 1.]
+CFG = dict(num_classes=19, layers=6, Fch=12, width_mult_list=WML, prun_modes=['max', 'arch_ratio'],
+           stem_head_width=[(1, 1), (8. / 12, 8. / 12)])
+
+
+def build():
+    from fasterseg_amd import model_search
+    net = model_search.Network_Multi_Path(criterion=torch.nn.CrossEntropyLoss(ignore_index=255), **CFG)
+    sd = seeded_state(net.state_dict(), 777)
+    for k in list(sd):
+        if k.split("_")[0] in ("alpha", "beta", "ratio"):
+            sd[k] = sd[k] * 5.0
+    net.load_state_dict(sd)
+    return net
+
+
+def test_supernet_state_dict_matches_reference():
+    meta = load_json("supernet_meta.json")
+    net = build()
+    sd = net.state_dict()
+    assert list(sd.keys()) == list(meta["state_shapes"].keys())
+    assert {k: list(v.shape) for k, v in sd.items()} == meta["state_shapes"]
+    assert sum(p.numel() for p in net.parameters()) == meta["num_params"]
+
+
+def test_full_size_supernet_param_count():
+    from fasterseg_amd import model_search
+    net = model_search.Network_Multi_Path(19, 16, None, 12, WML, ['max', 'arch_ratio'], [(1, 1), (8. / 12, 8. / 12)])
+    assert sum(p.numel() for p in net.parameters()) == 252057316          # 252.06 M
+
+
+def test_forward_latency_matches_reference():
+    """The latency regulariser of the search (architect.py:66-72): LUT lookups weighted by differentiable alpha/beta/ratio
+    scores, including the reference's BasicResidual2x key quirk for zoomed 2x cells."""
+    from fasterseg_amd import operations
+    store = load_npz("supernet.npz")
+    net = build()
+    saved = dict(operations.latency_lookup_table)
+    operations.latency_lookup_table.clear()
+    operations.latency_lookup_table.update(load_json("latency_lut_1080ti.json"))
+    try:
+        net.arch_idx = 1
+        net.prun_mode = None
+        for a, b, r in ((True, False, False), (False, True, False), (False, False, True), (True, True, True)):
+            net.zero_grad()
+            torch.manual_seed(9)
+            lat = net.forward_latency((3, 1024, 2048), alpha=a, beta=b, ratio=r)
+            lat.backward()
+            key = "lat_%d%d%d" % (a, b, r)
+            assert abs(float(lat.detach()) - float(store[key + "/value"][0])) < 1e-4, key
+            for k in ("alpha_1_0", "alpha_1_2", "beta_1_1", "ratio_1_1"):
+                gr = getattr(net, k).grad
+                got = gr.numpy() if gr is not None else np.zeros(1, np.float32)
+                np.testing.assert_allclose(got, store[key + "/g/" + k], atol=1e-5, rtol=1e-4)
+    finally:
+        operations.latency_lookup_table.clear()
+        operations.latency_lookup_table.update(saved)
+
+
+def _rel_l2(got, store, key):
+    want, step = golden_get(store, key)
+    got = got.detach().float().cpu().numpy().reshape(-1)[::step]
+    return float(((got - want.reshape(-1)) ** 2).sum() ** 0.5 / ((want ** 2).sum() ** 0.5 + 1e-30))
+
+
+@pytest.mark.gpu
+def test_supernet_eval_forward():
+    store = load_npz("supernet.npz")
+    net = build().cuda().eval()
+    x = seeded_input((2, 3, 128, 256), 31).cuda()
+    for idx in (0, 1):
+        net.arch_idx = idx
+        net.prun_mode = "max"
+        with torch.no_grad():
+            preds = net(x)
+        assert len(preds) == 5
+        for i, p in enumerate(preds):
+            assert p.shape == (2, 19, 128, 256)
+            assert_close_golden(p[:, :, ::4, ::4], store, "eval_arch%d/pred%d_sub" % (idx, i), 2e-3, 1e-3, "arch%d pred%d" % (idx, i))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["pretrain", "search"])
+def test_supernet_loss_and_gradients(mode):
+    """`_loss` = 4 full supernet forwards (pretrain: max/min/random/random; search: arch0, arch1 (Gumbel widths), max, min)
+    against the reference modules run in fp64 (batch-statistics BN on small maps: relative-L2 bars, see test_ops_gpu)."""
+    store = load_npz("supernet.npz")
+    net = build().cuda().train()
+    x = seeded_input((2, 3, 128, 256), 31).cuda()
+    target = torch.tensor(store["target"]).cuda()
+    np.random.seed(5)
+    torch.manual_seed(6)
+    net.arch_idx = 0
+    loss = net._loss(x, target, mode == "pretrain")
+    loss.backward()
+    want = float(store["%s_f64/loss" % mode][0])
+    assert abs(float(loss.detach()) - want) < 2e-3 * abs(want), (float(loss.detach()), want)
+    params = dict(net.named_parameters())
+    norms = load_json("supernet_%s_f64_gradnorms.json" % mode)
+    assert set(norms) == {k for k, p in params.items() if p.grad is not None}, "same parameters receive gradients"
+    bad = [(k, float(params[k].grad.norm()), w) for k, w in norms.items()
+           if abs(float(params[k].grad.norm()) - w) > 5e-2 * w + 1e-5]
+    assert len(bad) <= len(norms) // 100, bad[:10]
+    for key in store:
+        if key.startswith("%s_f64/g/" % mode):
+            pname = key[len("%s_f64/g/" % mode):].split("@")[0]
+            rel = _rel_l2(params[pname].grad, store, "%s_f64/g/%s" % (mode, pname))
+            assert rel < 5e-2, (key, rel)
