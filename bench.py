@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--workload", default="student_infer", choices=["student_infer", "student_train"])
+    ap.add_argument("--workload", default="student_infer", choices=["student_infer", "student_train", "supernet_pretrain", "supernet_search"])
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 1 for inference, 12 for training)")
@@ -192,7 +192,13 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
     world, rank, _ = dist_setup(args)
-    line = run_student_infer(args, world, rank) if args.workload == "student_infer" else run_student_train(args, world, rank)
+    if args.workload == "student_infer":
+        line = run_student_infer(args, world, rank)
+    elif args.workload == "student_train":
+        line = run_student_train(args, world, rank)
+    else:
+        from fasterseg_amd import train_step
+        line = train_step.bench_supernet(args, world, rank, barrier, max_over_ranks, args.workload == "supernet_pretrain")
     if rank == 0:
         print(json.dumps(line))
     if world > 1:
