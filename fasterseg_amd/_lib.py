@@ -31,6 +31,8 @@ SIGNATURES = {
     "fs_unpack_weight_grad": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_ll, c_ll, c_int],
     "fs_conv2d_fwd": [c_vp, ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "fs_conv2d_wgrad": [c_vp, ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp],
+    "fs_pack_weight_frag": [c_vp, c_vp, c_ll, c_ll, c_int, c_int, c_int, c_vp],
+    "fs_conv3x3_s1_fwd": [c_vp, ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "fs_conv_stem_fwd": [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int],
     "fs_bilinear_fwd": [c_vp, ctypes.POINTER(ResizeDesc), c_vp, c_vp],
     "fs_bilinear_bwd": [c_vp, ctypes.POINTER(ResizeDesc), c_vp, c_vp, c_vp],
@@ -51,6 +53,7 @@ _SPECIAL = {
     "fs_version": ([], c_int),
     "fs_packed_weight_elems": ([c_int, c_int, c_int, c_int], c_ll),
     "fs_debug_force_conv_cfg": ([c_int], None),
+    "fs_packed_weight_frag_elems": ([c_int, c_int, c_int], c_ll),
 }
 ALL_SYMBOLS = sorted(list(SIGNATURES) + list(_SPECIAL))
 

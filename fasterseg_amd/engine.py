@@ -12,6 +12,7 @@ The plan also carries the algorithmic FLOPs / bytes of every launch (SURVEY.md Â
 launch with HIP events on the launch stream (`profile()`), which is what bench.py's roofline block is computed from.
 """
 import ctypes
+import os
 
 import torch
 
@@ -65,13 +66,16 @@ class _Tracer:
 
 
 class InferenceEngine:
-    def __init__(self, net, input_shape, dtype=torch.bfloat16, logits_dtype=torch.float32, device="cuda", use_graph=True):
+    def __init__(self, net, input_shape, dtype=torch.bfloat16, logits_dtype=torch.float32, device="cuda", use_graph=True,
+                 halo_min_pixels=16384):
         assert not net.training, "call net.eval() first"
         self.dtype = dtype
         self.device = torch.device(device)
         self.input_shape = tuple(input_shape)
         self.logits_dtype = logits_dtype
         self.vec = K.vec_of(dtype)
+        # 3x3/s1 layers with at least this many output pixels run on the LDS-halo kernel (conv3x3_halo.hip)
+        self.halo_min_pixels = int(os.environ.get("FS_HALO_MIN_PIXELS", halo_min_pixels))
         self.input = torch.zeros(self.input_shape, dtype=torch.float32, device=self.device)
         self._keep = []            # tensors referenced by raw pointers in the plan
         self._trace(net)
@@ -164,7 +168,11 @@ class InferenceEngine:
     def _add_conv(self, x, out, weight, scale, shift, k, stride, pad, relu, cout, cin, out_off=0, label="conv"):
         N, _, H, W = x.shape
         _, _, Ho, Wo = out.shape
-        wp = K.pack_weight(weight.detach().to(self.device), self.dtype, cout, cin)
+        use_halo = (k == 3 and stride == 1 and pad == 1 and N * H * W >= self.halo_min_pixels)
+        if use_halo:        # LDS-halo 3x3 kernel with the fragment-packed filter bank
+            wp = K.pack_weight_frag(weight.detach().to(self.device), self.dtype, cout, cin)
+        else:
+            wp = K.pack_weight(weight.detach().to(self.device), self.dtype, cout, cin)
         self._keep.append(wp)
         xp, x_cs = self._ptr(x)
         yp, y_cs = self._ptr(out)
@@ -175,7 +183,7 @@ class InferenceEngine:
         flops = 2.0 * N * Ho * Wo * cout * cin * k * k
         nbytes = es * (N * H * W * cin + cout * cin * k * k + N * Ho * Wo * cout)
         args = (ctypes.byref(d), ctypes.c_void_p(xp), ctypes.c_void_p(wp.data_ptr()), K._p(scale), K._p(shift), ctypes.c_void_p(yp), None)
-        self.calls.append(dict(fn="fs_conv2d_fwd", args=args, family="conv%dx%d" % (k, k), flops=flops, bytes=nbytes,
+        self.calls.append(dict(fn="fs_conv3x3_s1_fwd" if use_halo else "fs_conv2d_fwd", args=args, family="conv%dx%d" % (k, k), flops=flops, bytes=nbytes,
                                label="%s %dx%d s%d %d->%d @%dx%d" % (label, k, k, stride, cin, cout, H, W)))
 
     def _lower(self):

@@ -157,6 +157,30 @@ def conv2d(x, w_packed, cout, R, S, stride, pad, scale=None, shift=None, relu=Fa
     return out
 
 
+def pack_weight_frag(w, dtype, cout=None, cin=None):
+    """OIHW fp32 3x3 filter (optionally the leading [:cout,:cin] block) -> MFMA-fragment-ordered bank for conv3x3_halo."""
+    O, I, R, S = w.shape
+    assert (R, S) == (3, 3) and w.dtype == torch.float32 and w.stride(3) == 1 and w.stride(2) == 3
+    cout = O if cout is None else cout
+    cin = I if cin is None else cin
+    n = _lib.lib().fs_packed_weight_frag_elems(cout, cin, dtype_code(dtype))
+    out = torch.empty(n, dtype=dtype, device=w.device)
+    call("fs_pack_weight_frag", _stream(), _p(w), w.stride(0), w.stride(1), cout, cin, dtype_code(dtype), _p(out))
+    return out
+
+
+def conv3x3_halo(x, w_frag, cout, scale=None, shift=None, relu=False, out=None, stats=None):
+    """3x3 / stride 1 / pad 1 conv through the halo-tiled kernel (same epilogue contract as conv2d)."""
+    x_cs = require_nhwc(x, "x")
+    N, Cin, H, W = x.shape
+    d = conv_desc(x.shape, x_cs, cout, 3, 3, 1, 1, 0, x.dtype, FS_CONV_RELU if relu else 0)
+    if out is None:
+        out = empty_nhwc(N, cout, H, W, x.dtype, x.device)
+    d.y_cs = channel_stride(out)
+    call("fs_conv3x3_s1_fwd", _stream(), ctypes.byref(d), _p(x), _p(w_frag), _p(scale), _p(shift), _p(out), _p(stats))
+    return out
+
+
 def conv2d_wgrad(x, dy, R, S, stride, pad, cout=None):
     """fp32 packed weight gradient [Cout][R][S][Cin] of conv(x) w.r.t. its filter."""
     x_cs = require_nhwc(x, "x")

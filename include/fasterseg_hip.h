@@ -84,6 +84,15 @@ fs_status fs_unpack_weight_grad(void* stream, const float* dw_packed, int Cout, 
 fs_status fs_conv2d_fwd(void* stream, const fs_conv_desc* d, const void* x, const void* w_packed,
                         const float* scale, const float* shift, void* y, float* stats);
 
+/* 3x3 / stride 1 / pad 1 convolution with an LDS-staged input halo tile (conv3x3_halo.hip): same contract as
+ * fs_conv2d_fwd (flags: FS_CONV_RELU only) but the filter must be packed in MFMA fragment order by fs_pack_weight_frag
+ * (fs_packed_weight_frag_elems elements).  Used for the large-resolution 3x3 layers that carry the FLOPs. */
+long long fs_packed_weight_frag_elems(int Cout, int Cin, int dtype);
+fs_status fs_pack_weight_frag(void* stream, const float* w_oihw, long long o_stride, long long i_stride, int Cout, int Cin,
+                              int dtype, void* w_frag);
+fs_status fs_conv3x3_s1_fwd(void* stream, const fs_conv_desc* d, const void* x, const void* w_frag, const float* scale,
+                            const float* shift, void* y, float* stats);
+
 /* Replaces conv2d backward-weight: dw[co][r][s][ci] = sum_pixels dy[p][co] * x[p@(r,s)][ci], fp32 packed
  * output (caller zeroes; split-K atomics).  `d` is the forward descriptor. */
 fs_status fs_conv2d_wgrad(void* stream, const fs_conv_desc* d, const void* x, const void* dy, float* dw_packed);

@@ -103,6 +103,36 @@ def test_conv2d_fwd(case, dtype, force_cfg):
     assert torch.allclose(stats[Cout:].cpu(), s2, atol=1e-3, rtol=3e-3), "sumsq"
 
 
+HALO_CASES = [(1, 32, 16, 32, 32), (2, 64, 9, 13, 96), (1, 48, 24, 40, 80), (1, 128, 8, 16, 128), (1, 16, 33, 50, 19),
+              (2, 96, 17, 16, 64), (1, 192, 16, 16, 192), (1, 8, 5, 7, 8), (1, 64, 64, 128, 64)]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", HALO_CASES, ids=[str(c) for c in HALO_CASES])
+def test_conv3x3_halo(case, dtype):
+    """LDS-halo 3x3 kernel == F.conv2d(k3,s1,p1) incl. ragged tiles, channel tails, BN-stat epilogue and slices."""
+    k = K()
+    N, Cin, H, W, Cout = case
+    x = q(rnd(N, Cin, H, W, seed=1), dtype)
+    w = q(rnd(Cout, Cin, 3, 3, seed=2, scale=(2.0 / (Cin * 9)) ** 0.5), dtype)
+    scale, shift = rnd(Cout, seed=3).abs() + 0.5, rnd(Cout, seed=4)
+    raw = F.conv2d(x, w, None, 1, 1)
+    ref = F.relu(raw * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    xd = k.to_nhwc(x.cuda(), dtype)
+    wf = k.pack_weight_frag(w.cuda(), dtype)
+    stats = torch.zeros(2 * Cout, device="cuda")
+    y = k.conv3x3_halo(xd, wf, Cout, scale.cuda(), shift.cuda(), relu=True, stats=stats)
+    check(y, ref, dtype, "halo conv+affine+relu")
+    cnt = raw.numel() / Cout
+    assert torch.allclose(stats[:Cout].cpu(), raw.sum((0, 2, 3)), atol=2e-3 * cnt ** 0.5 + 1e-3, rtol=2e-3)
+    assert torch.allclose(stats[Cout:].cpu(), (raw * raw).sum((0, 2, 3)), atol=1e-3, rtol=3e-3)
+    if Cout % 8 == 0:
+        wide = k.empty_nhwc(N, Cout + 32, H, W, dtype, "cuda", zero=True)
+        k.conv3x3_halo(xd, wf, Cout, out=wide[:, 32:])
+        check(wide[:, 32:], raw, dtype, "halo into slice")
+        assert float(wide[:, :32].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 def test_conv2d_into_channel_slice(dtype):
     """torch.cat fused away: the conv writes into a channel slice of a wider buffer and reads from one."""
