@@ -67,7 +67,7 @@ class _Tracer:
 
 class InferenceEngine:
     def __init__(self, net, input_shape, dtype=torch.bfloat16, logits_dtype=torch.float32, device="cuda", use_graph=True,
-                 halo_min_pixels=16384):
+                 halo_min_pixels=16384, lanes=3):
         assert not net.training, "call net.eval() first"
         self.dtype = dtype
         self.device = torch.device(device)
@@ -76,6 +76,7 @@ class InferenceEngine:
         self.vec = K.vec_of(dtype)
         # 3x3/s1 layers with at least this many output pixels run on the LDS-halo kernel (conv3x3_halo.hip)
         self.halo_min_pixels = int(os.environ.get("FS_HALO_MIN_PIXELS", halo_min_pixels))
+        self.n_lanes = max(1, int(os.environ.get("FS_ENGINE_LANES", lanes)))
         self.input = torch.zeros(self.input_shape, dtype=torch.float32, device=self.device)
         self._keep = []            # tensors referenced by raw pointers in the plan
         self._trace(net)
@@ -186,11 +187,19 @@ class InferenceEngine:
         self.calls.append(dict(fn="fs_conv3x3_s1_fwd" if use_halo else "fs_conv2d_fwd", args=args, family="conv%dx%d" % (k, k), flops=flops, bytes=nbytes,
                                label="%s %dx%d s%d %d->%d @%dx%d" % (label, k, k, stride, cin, cout, H, W)))
 
+    def _ready(self, sym):
+        """call indices that must have completed before `sym` is fully written"""
+        return self._sym_ready.get(sym.id, [])
+
     def _lower(self):
         self.calls = []
+        self._sym_ready = {}
         es = 2 if self.dtype == torch.bfloat16 else 4
         for idx, op in enumerate(self.ops):
             kind, out = op["kind"], op["out"]
+            first_call = len(self.calls)
+            in_syms = op["inputs"] if kind == "cat" else [op["x"]]
+            deps = sorted({d for s_ in in_syms for d in self._ready(s_)})
             if kind == "stem":
                 N, _, H, W = op["x"].shape
                 cout = out.shape[1]
@@ -240,8 +249,41 @@ class InferenceEngine:
                                            label="copy C%d @%dx%d" % (C, H, W)))
             else:
                 raise RuntimeError("unknown op kind " + kind)
+            new_calls = list(range(first_call, len(self.calls)))
+            for ci in new_calls:
+                self.calls[ci]["deps"] = deps
+            # a cat output is ready when its aliased producers and its copy calls are; other outputs when their calls are
+            self._sym_ready[out.id] = (deps + new_calls) if kind == "cat" else new_calls
+        self._assign_lanes()
         self.total_flops = sum(c["flops"] for c in self.calls)
         self.total_bytes = sum(c["bytes"] for c in self.calls)
+
+    # ---- 3b. independent chains (the two branches of the derived network) go to separate HIP streams ----
+    def _assign_lanes(self):
+        """Greedy chain assignment: a call continues the lane of its latest dependency when that dependency is still the
+        lane's tail, otherwise it takes the lane whose tail is oldest.  Cross-lane edges become event waits, so the
+        captured hipGraph has parallel branches and the launch-latency-sized kernels of the 1/16-1/32 branch overlap
+        with those of the 1/8-1/16 branch."""
+        n_lanes = self.n_lanes
+        tails = [-1] * n_lanes
+        for i, c in enumerate(self.calls):
+            deps = c["deps"]
+            lane = None
+            for d in sorted(deps, reverse=True):
+                if tails[self.calls[d]["lane"]] == d:
+                    lane = self.calls[d]["lane"]
+                    break
+            if lane is None:
+                lane = 0 if not deps else min(range(n_lanes), key=lambda l: tails[l])
+            c["lane"] = lane
+            tails[lane] = i
+        for c in self.calls:
+            c["signal"] = False
+        for i, c in enumerate(self.calls):
+            c["waits"] = [d for d in c["deps"] if self.calls[d]["lane"] != c["lane"]]
+            for d in c["waits"]:
+                self.calls[d]["signal"] = True
+        self.lane_tails = tails
 
     # ---- 4. run ----------------------------------------------------------------------------------------
     def _launch_all(self):
@@ -249,15 +291,41 @@ class InferenceEngine:
         for c in self.calls:
             call(c["fn"], st, *c["args"])
 
+    def _launch_all_lanes(self, main):
+        """Issue the plan on `main` + side streams with event edges (used under graph capture)."""
+        streams = [main] + self._side_streams
+        events = {}
+        fork = torch.cuda.Event()
+        fork.record(main)
+        for s_ in streams[1:]:
+            s_.wait_event(fork)
+        for i, c in enumerate(self.calls):
+            s_ = streams[c["lane"]]
+            for d in c["waits"]:
+                s_.wait_event(events[d])
+            call(c["fn"], ctypes.c_void_p(s_.cuda_stream), *c["args"])
+            if c["signal"]:
+                ev = torch.cuda.Event()
+                ev.record(s_)
+                events[i] = ev
+        for s_ in streams[1:]:                      # join every lane back into the capturing stream
+            ev = torch.cuda.Event()
+            ev.record(s_)
+            main.wait_event(ev)
+
     def _capture(self):
         torch.cuda.synchronize()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
+        self._side_streams = [torch.cuda.Stream() for _ in range(self.n_lanes - 1)]
         with torch.cuda.stream(side):
             self._launch_all()                     # warm-up outside capture
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=side):
-                self._launch_all()
+                if self.n_lanes > 1:
+                    self._launch_all_lanes(side)
+                else:
+                    self._launch_all()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = g
