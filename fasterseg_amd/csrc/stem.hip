@@ -30,7 +30,10 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(int N, int H, int W, int
                 for (int s = 0; s < 3; ++s) {
                     const int ih = oh * 2 - 1 + r, iw = ow * 2 - 1 + s;
                     const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
-                    in[(r * 3 + s) * 3 + c] = ok ? x[(((long long)n * 3 + c) * H + ih) * W + iw] : 0.f;
+                    // unconditional load from a clamped address + select: all 27 loads are in flight together
+                    const int ihc = min(max(ih, 0), H - 1), iwc = min(max(iw, 0), W - 1);
+                    const float v = x[(((long long)n * 3 + c) * H + ihc) * W + iwc];
+                    in[(r * 3 + s) * 3 + c] = ok ? v : 0.f;
                 }
         float out[16];
 #pragma unroll

@@ -31,7 +31,9 @@ class ProbOhemCrossEntropy2d(nn.Module):
                 true_prob = prob.gather(0, flat.unsqueeze(0)).squeeze(0).masked_fill(~valid, 1)
                 threshold = self.thresh
                 if self.min_kept > 0:
-                    kth = true_prob.kthvalue(min(true_prob.numel(), self.min_kept)).values   # = sorted[min_kept-1]
+                    # k-th smallest probability = sorted[min_kept-1] (the reference argsorts, loss_opr.py:82-83); a device
+                    # radix sort is ~30x faster than torch.kthvalue at 6.3 M pixels on ROCm
+                    kth = torch.sort(true_prob).values[min(true_prob.numel(), self.min_kept) - 1]
                     if float(kth) > self.thresh:
                         threshold = kth
                 kept = true_prob.le(threshold)
