@@ -36,6 +36,7 @@ SIGNATURES = {
     "fs_conv_stem_fwd": [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int],
     "fs_bilinear_fwd": [c_vp, ctypes.POINTER(ResizeDesc), c_vp, c_vp],
     "fs_bilinear_bwd": [c_vp, ctypes.POINTER(ResizeDesc), c_vp, c_vp, c_vp],
+    "fs_bilinear_bwd_nchw": [c_vp, ctypes.POINTER(ResizeDesc), c_vp, c_vp, c_vp],
     "fs_bn_finalize": [c_vp, c_int, c_ll, c_vp, c_vp, c_vp, c_float, c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "fs_affine_act": [c_vp, c_ll, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int],
     "fs_channel_stats": [c_vp, c_ll, c_int, c_vp, c_int, c_int, c_vp],

@@ -236,6 +236,67 @@ __global__ void bilinear_bwd_nchw_kernel(int N, int Hi, int Wi, int Ho, int Wo, 
     }
 }
 
+// Separable form of the NCHW logits up-sample backward (x8/x16/x32): the 2-D gather touches (2f+2)^2 output pixels per
+// input pixel (4356 at x32); two 1-D passes touch 2*(2f+2).  Pass W: tmp[n,c,oh,iw] = sum_ow ww(ow,iw) dy[n,c,oh,ow];
+// pass H: dx[n,ih,iw,c] = sum_oh wh(oh,ih) tmp[n,c,oh,iw].  Same tap arithmetic as the forward, no atomics.
+__global__ void bilinear_bwd_nchw_w_kernel(long long rows, int Wi, int Wo, float rw, const float* __restrict__ dy,
+                                           float* __restrict__ tmp) {
+    const long long total = rows * Wi;                     // rows = N*C*Ho
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const long long row = idx / Wi;
+        const int iw = (int)(idx - row * Wi);
+        int lo, hi;
+        cand_range(rw, iw, Wo, lo, hi);
+        const float* src = dy + row * Wo;
+        float acc = 0.f;
+        // 8 independent loads per step (clamped index, zero weight outside the range): a plain `for ow` loop issues one
+        // dependent load per iteration and is pure memory latency
+        for (int o0 = lo; o0 <= hi; o0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[min(o0 + u, Wo - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int ow = o0 + u;
+                const float w = (ow <= hi) ? tap_weight(make_tap(rw, ow, Wi), iw) : 0.f;
+                acc += w * v[u];
+            }
+        }
+        tmp[idx] = acc;
+    }
+}
+
+template <typename T>
+__global__ void bilinear_bwd_nchw_h_kernel(int N, int C, int Hi, int Wi, int Ho, float rh, const float* __restrict__ tmp,
+                                           T* __restrict__ dx, int dx_cs) {
+    const long long total = (long long)N * C * Hi * Wi;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        long long t = idx;
+        const int iw = (int)(t % Wi); t /= Wi;
+        const int ih = (int)(t % Hi); t /= Hi;
+        const int c = (int)(t % C);
+        const int n = (int)(t / C);
+        int lo, hi;
+        cand_range(rh, ih, Ho, lo, hi);
+        const float* plane = tmp + ((long long)n * C + c) * Ho * Wi + iw;
+        float acc = 0.f;
+        for (int o0 = lo; o0 <= hi; o0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = plane[(long long)min(o0 + u, Ho - 1) * Wi];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int oh = o0 + u;
+                const float w = (oh <= hi) ? tap_weight(make_tap(rh, oh, Hi), ih) : 0.f;
+                acc += w * v[u];
+            }
+        }
+        Elem<T>::store(dx + (((long long)n * Hi + ih) * Wi + iw) * dx_cs + c, acc);
+    }
+}
+
 static inline int grid_for(long long work, int block = 256, int cap = 16384) {
     long long g = (work + block - 1) / block;
     if (g < 1) g = 1;
@@ -310,6 +371,25 @@ extern "C" fs_status fs_bilinear_fwd(void* stream, const fs_resize_desc* d, cons
         }
     }
     return check_launch("fs_bilinear_fwd");
+}
+
+extern "C" fs_status fs_bilinear_bwd_nchw(void* stream, const fs_resize_desc* d, const float* dy, float* workspace, void* dx) {
+    fs_status s = check_resize("fs_bilinear_bwd_nchw", d);
+    if (s != FS_OK) return s;
+    FS_REQUIRE(d->out_nchw == 1, FS_ERR_INVALID, "fs_bilinear_bwd_nchw: descriptor must have out_nchw = 1");
+    FS_REQUIRE(dy && workspace && dx, FS_ERR_INVALID, "fs_bilinear_bwd_nchw: null pointer");
+    const float rh = host_scale(d->Hi, d->Ho), rw = host_scale(d->Wi, d->Wo);
+    hipStream_t st = (hipStream_t)stream;
+    const long long rows = (long long)d->N * d->C * d->Ho;
+    hipLaunchKernelGGL(bilinear_bwd_nchw_w_kernel, dim3(grid_for(rows * d->Wi)), dim3(256), 0, st, rows, d->Wi, d->Wo, rw, dy, workspace);
+    const long long total = (long long)d->N * d->C * d->Hi * d->Wi;
+    if (d->dtype == FS_F32)
+        hipLaunchKernelGGL((bilinear_bwd_nchw_h_kernel<float>), dim3(grid_for(total)), dim3(256), 0, st, d->N, d->C, d->Hi, d->Wi, d->Ho,
+                           rh, workspace, (float*)dx, d->x_cs);
+    else
+        hipLaunchKernelGGL((bilinear_bwd_nchw_h_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, st, d->N, d->C, d->Hi, d->Wi,
+                           d->Ho, rh, workspace, (bf16_t*)dx, d->x_cs);
+    return check_launch("fs_bilinear_bwd_nchw");
 }
 
 extern "C" fs_status fs_bilinear_bwd(void* stream, const fs_resize_desc* d, const void* dy, const void* y_out, void* dx) {

@@ -44,26 +44,26 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
     if (m_end > p.M) m_end = p.M;
 
     u32x4 ra[NV], rb[NV];
-    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    uint32_t ka[NV], kb[NV];          // zero-masks applied when the data is consumed (keeps every load unconditional)
     auto load_chunk = [&](long long mc) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int v = tid + i * 256;
             const int row = v / VR, cvec = (v - row * VR) * VEC;
-            ra[i] = zero4;
-            rb[i] = zero4;
             const long long m = mc + row;
-            if (v < KC * VR && m < m_end) {
-                if (co0 + cvec < p.Cout) ra[i] = ldg16(p.dy + (m * p.dy_cs + co0 + cvec) * (long long)sizeof(T));
-                const int n = (int)(m / p.HoWo);
-                const int rem = (int)(m - (long long)n * p.HoWo);
-                const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
-                const int ih = oh * p.stride - p.pad + tr, iw = ow * p.stride - p.pad + ts;
-                if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W && ci0 + cvec < p.Cin) {
-                    const long long pix = ((long long)n * p.H + ih) * p.W + iw;
-                    rb[i] = ldg16(p.x + (pix * p.x_cs + ci0 + cvec) * (long long)sizeof(T));
-                }
-            }
+            const bool mok = (v < KC * VR) && (m < m_end);
+            const long long mm = mok ? m : m_begin;
+            const bool aok = mok && (co0 + cvec < p.Cout);
+            ka[i] = aok ? 0xffffffffu : 0u;
+            ra[i] = ldg16(p.dy + (aok ? (mm * p.dy_cs + co0 + cvec) * (long long)sizeof(T) : 0ll));
+            const int n = (int)(mm / p.HoWo);
+            const int rem = (int)(mm - (long long)n * p.HoWo);
+            const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+            const int ih = oh * p.stride - p.pad + tr, iw = ow * p.stride - p.pad + ts;
+            const bool bok = mok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W && (ci0 + cvec < p.Cin);
+            const long long pix = ((long long)n * p.H + ih) * p.W + iw;
+            kb[i] = bok ? 0xffffffffu : 0u;
+            rb[i] = ldg16(p.x + (bok ? (pix * p.x_cs + ci0 + cvec) * (long long)sizeof(T) : 0ll));
         }
     };
     auto store_chunk = [&]() {
@@ -72,9 +72,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
             const int v = tid + i * 256;
             if (v < KC * VR) {
                 const int row = v / VR, cvec = (v - row * VR) * VEC;
+                u32x4 va = ra[i], vb = rb[i];
+                va[0] &= ka[i]; va[1] &= ka[i]; va[2] &= ka[i]; va[3] &= ka[i];
+                vb[0] &= kb[i]; vb[1] &= kb[i]; vb[2] &= kb[i]; vb[3] &= kb[i];
                 float fa[VEC], fb[VEC];
-                Elem<T>::unpack(ra[i], fa);
-                Elem<T>::unpack(rb[i], fb);
+                Elem<T>::unpack(va, fa);
+                Elem<T>::unpack(vb, fb);
 #pragma unroll
                 for (int q = 0; q < VEC; q += 4) {
                     *reinterpret_cast<f32x4*>(&sA[row][cvec + q]) = f32x4{fa[q], fa[q + 1], fa[q + 2], fa[q + 3]};

@@ -242,6 +242,11 @@ def bilinear_bwd(dy, y_out, in_shape, relu, dtype, out_nchw=0, dx_cs=None):
         if relu:
             assert channel_stride(y_out) == y_cs, "y_out and dy must share a channel stride"
     d = ResizeDesc(N, Hi, Wi, Ho, Wo, C, channel_stride(dx), y_cs, dtype_code(dtype), int(relu), int(out_nchw))
+    if out_nchw and Ho >= 2 * Hi and Wo >= 2 * Wi:          # logits up-sample: separable two-pass gather
+        d.out_nchw = 1
+        ws = torch.empty((N, C, Ho, Wi), dtype=torch.float32, device=dy.device)
+        call("fs_bilinear_bwd_nchw", _stream(), ctypes.byref(d), _p(dy), _p(ws), _p(dx))
+        return dx
     call("fs_bilinear_bwd", _stream(), ctypes.byref(d), _p(dy), _p(y_out) if relu else None, _p(dx))
     return dx
 

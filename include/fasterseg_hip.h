@@ -109,6 +109,9 @@ fs_status fs_bilinear_fwd(void* stream, const fs_resize_desc* d, const void* x, 
 /* backward: dx (+)= transpose-of-interpolation(dy); relu mask taken from y_out when d->relu. dx is zeroed by the
  * kernel's gather formulation (no atomics). `y_out` may be NULL when relu==0. */
 fs_status fs_bilinear_bwd(void* stream, const fs_resize_desc* d, const void* dy, const void* y_out, void* dx);
+/* backward of the NCHW logits up-sample (d->out_nchw == 1) in separable form: two 1-D gathers through a caller-provided
+ * fp32 workspace of N*C*Ho*Wi elements; dy is contiguous NCHW fp32, dx NHWC (channel stride d->x_cs, pad lanes untouched). */
+fs_status fs_bilinear_bwd_nchw(void* stream, const fs_resize_desc* d, const float* dy, float* workspace, void* dx);
 
 /* --- batch norm (train mode) and elementwise ------------------------------------------------------ */
 /* Replaces nn.BatchNorm2d in training mode (operations.py:39,80; slimmable_ops.py:58-70).
