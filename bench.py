@@ -55,8 +55,10 @@ def dist_setup(args):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        torch.cuda.set_device(local % torch.cuda.device_count())
+        # backend "nccl" is RCCL on ROCm; FS_DIST_BACKEND=gloo exists only to exercise this path with several ranks on
+        # a single-GPU box (RCCL refuses two ranks on one device)
+        dist.init_process_group(os.environ.get("FS_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
     assert world == args.gpus or world == 1, "WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
