@@ -31,6 +31,7 @@ SIGNATURES = {
     "fs_unpack_weight_grad": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_ll, c_ll, c_int],
     "fs_conv2d_fwd": [c_vp, ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "fs_conv2d_wgrad": [c_vp, ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp],
+    "fs_conv2d_wgrad_strided": [c_vp, ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_ll, c_ll, c_ll],
     "fs_pack_weight_frag": [c_vp, c_vp, c_ll, c_ll, c_int, c_int, c_int, c_vp],
     "fs_conv3x3_s1_fwd": [c_vp, ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "fs_conv_stem_fwd": [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int],

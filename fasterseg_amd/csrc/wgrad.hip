@@ -19,6 +19,7 @@ struct WgradArgs {
     int M, HoWo;
     int tiles_ci;
     long long slab;   // pixels per block
+    long long o_stride, i_stride, t_stride;   // o_stride > 0: accumulate straight into a strided gradient tensor (element strides of O, I and of the flattened R*S tap index)
 };
 
 constexpr int KC = 32;      // pixels per chunk
@@ -110,7 +111,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (co < p.Cout) atomicAdd(p.dw + (((long long)co * p.R + tr) * p.S + ts) * p.Cin + ci, acc[r]);
+            if (co < p.Cout) {
+                float* dst = p.o_stride > 0 ? p.dw + co * p.o_stride + ci * p.i_stride + (tr * p.S + ts) * p.t_stride
+                                            : p.dw + (((long long)co * p.R + tr) * p.S + ts) * p.Cin + ci;
+                atomicAdd(dst, acc[r]);
+            }
         }
     }
 }
@@ -119,7 +124,21 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
 
 using namespace fs;
 
+static fs_status wgrad_impl(void* stream, const fs_conv_desc* d, const void* x, const void* dy, float* dw_packed, long long o_stride,
+                            long long i_stride, long long t_stride);
+
 extern "C" fs_status fs_conv2d_wgrad(void* stream, const fs_conv_desc* d, const void* x, const void* dy, float* dw_packed) {
+    return wgrad_impl(stream, d, x, dy, dw_packed, 0, 0, 0);
+}
+
+extern "C" fs_status fs_conv2d_wgrad_strided(void* stream, const fs_conv_desc* d, const void* x, const void* dy, float* dw,
+                                             long long o_stride, long long i_stride, long long t_stride) {
+    FS_REQUIRE(o_stride > 0 && i_stride > 0 && t_stride > 0, FS_ERR_INVALID, "fs_conv2d_wgrad_strided: strides must be positive");
+    return wgrad_impl(stream, d, x, dy, dw, o_stride, i_stride, t_stride);
+}
+
+static fs_status wgrad_impl(void* stream, const fs_conv_desc* d, const void* x, const void* dy, float* dw_packed, long long o_stride,
+                            long long i_stride, long long t_stride) {
     FS_REQUIRE(d && x && dy && dw_packed, FS_ERR_INVALID, "fs_conv2d_wgrad: null argument");
     FS_REQUIRE(d->dtype == FS_F32 || d->dtype == FS_BF16, FS_ERR_INVALID, "fs_conv2d_wgrad: bad dtype");
     const int vec = vec_elems(d->dtype);
@@ -133,6 +152,7 @@ extern "C" fs_status fs_conv2d_wgrad(void* stream, const fs_conv_desc* d, const 
     a.x = (const unsigned char*)x;
     a.dy = (const unsigned char*)dy;
     a.dw = dw_packed;
+    a.o_stride = o_stride; a.i_stride = i_stride; a.t_stride = t_stride;
     a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.R = d->R; a.S = d->S;
     a.stride = d->stride; a.pad = d->pad; a.Ho = d->Ho; a.Wo = d->Wo;
     a.x_cs = d->x_cs; a.dy_cs = d->y_cs;

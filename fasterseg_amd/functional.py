@@ -117,12 +117,27 @@ def fold_bn(gamma, beta, running_mean, running_var, eps):
 
 
 def _zero_stats(c, device):
-    return torch.zeros(2 * c, dtype=torch.float32, device=device)
+    return K.zeros_f32(2 * c, device)
 
 
-def _weight_grad(weight, dw_packed, cout, cin):
-    g = torch.zeros_like(weight, dtype=torch.float32)
-    K.unpack_weight_grad(dw_packed, g, cout, cin)
+# Set by parallel.FlatGradientSync for the duration of a backward pass: parameters whose .grad is a view of its
+# (pre-zeroed) flat buffer get their weight gradient accumulated IN PLACE by the wgrad kernel, i.e. without a
+# packed temporary, an unpack pass, a zero-filled OIHW tensor and autograd's accumulate-add (4 launches per conv).
+_grad_sink = None
+
+
+def conv_weight_grad(weight, x, dz, R, S, stride, pad, cout, cin):
+    """Weight gradient of conv(x)[:cout,:cin]: returns an OIHW fp32 tensor, or None when it was accumulated directly into
+    weight.grad (fused gradient accumulation)."""
+    sink, g = _grad_sink, weight.grad
+    if (sink is not None and g is not None and g.dtype == torch.float32 and g.shape == weight.shape
+            and g.stride(2) == S * g.stride(3) and sink.accepts(weight)):
+        K.conv2d_wgrad_into(x, dz, R, S, stride, pad, g, cout)
+        sink.touched(weight)
+        return None
+    O, I = weight.shape[0], weight.shape[1]           # physically [O][R][S][I]: the kernel's atomics are then coalesced
+    g = torch.zeros((O, R, S, I), dtype=torch.float32, device=weight.device).permute(0, 3, 1, 2)
+    K.conv2d_wgrad_into(x, dz, R, S, stride, pad, g, cout)
     return g
 
 
@@ -172,7 +187,7 @@ class _ConvBNAct(torch.autograd.Function):
         dz, dgamma, dbeta = K.bn_backward(z, dy, y, mean, invstd, gamma.detach(), relu)
         gw = gx = None
         if ctx.needs_input_grad[1]:
-            gw = _weight_grad(weight, K.conv2d_wgrad(x, dz, R, S, stride, pad), cout, cin)
+            gw = conv_weight_grad(weight, x, dz, R, S, stride, pad, cout, cin)
         if ctx.needs_input_grad[0]:
             gx = _dgrad(dz, weight, cin, R, S, stride, pad, (x.shape[2], x.shape[3]))
         return gx, gw, dgamma, dbeta, None, None, None
@@ -287,14 +302,14 @@ class _ConvBias(torch.autograd.Function):
             dyp = as_nhwc(dy, x.dtype)
         gw = gb = gx = None
         if ctx.needs_input_grad[1]:
-            dw = K.conv2d_wgrad(x, dyp, R, S, stride, pad)
             if cpad != cout:
+                dw = K.conv2d_wgrad(x, dyp, R, S, stride, pad)
                 gfull = torch.zeros((cpad, cin, R, S), dtype=torch.float32, device=x.device)
                 K.unpack_weight_grad(dw, gfull, cpad, cin)
                 gw = torch.zeros_like(weight, dtype=torch.float32)
                 gw[:cout, :cin] = gfull[:cout]
             else:
-                gw = _weight_grad(weight, dw, cout, cin)
+                gw = conv_weight_grad(weight, x, dyp, R, S, stride, pad, cout, cin)
         if has_bias and ctx.needs_input_grad[2]:
             gb = K.channel_stats(dyp)[:cout].clone()
         if ctx.needs_input_grad[0]:
@@ -361,9 +376,9 @@ class _FactorizedReduce(torch.autograd.Function):
         da, db = dz[:, :half], dz[:, half:]
         g1 = g2 = gx = None
         if ctx.needs_input_grad[1]:
-            g1 = _weight_grad(w1, K.conv2d_wgrad(x, da, 1, 1, 2, 0), half, cin)
+            g1 = conv_weight_grad(w1, x, da, 1, 1, 2, 0, half, cin)
         if ctx.needs_input_grad[2]:
-            g2 = _weight_grad(w2, K.conv2d_wgrad(x, db, 1, 1, 2, -1), half, cin)
+            g2 = conv_weight_grad(w2, x, db, 1, 1, 2, -1, half, cin)
         if ctx.needs_input_grad[0]:
             hw = (x.shape[2], x.shape[3])
             gx = _dgrad(da, w1, cin, 1, 1, 2, 0, hw)

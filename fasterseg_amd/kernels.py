@@ -37,6 +37,44 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+class _ZeroPool:
+    """Arena of pre-zeroed fp32 scratch (BN statistic / reduction accumulators, dot outputs).  A train step needs
+    thousands of 100-byte zero buffers; taking them from one arena that is cleared with a single memset per step
+    (reset(), called by parallel.FlatGradientSync.prepare) removes one fill launch per request.  Views are only valid
+    until the next reset; outside an active step (or when the arena is full) requests fall back to torch.zeros."""
+
+    def __init__(self, capacity=1 << 24):
+        self.capacity = capacity
+        self.buf = None
+        self.off = 0
+        self.active = False
+
+    def reset(self, device):
+        if self.buf is None or self.buf.device != torch.device(device):
+            self.buf = torch.zeros(self.capacity, dtype=torch.float32, device=device)
+        elif self.off:
+            self.buf[:self.off].zero_()
+        self.off = 0
+        self.active = True
+
+    def stop(self):
+        self.active = False
+
+    def take(self, n, device):
+        if not self.active or self.buf is None or self.off + n > self.capacity or self.buf.device != torch.device(device):
+            return torch.zeros(n, dtype=torch.float32, device=device)
+        v = self.buf[self.off:self.off + n]
+        self.off += (n + 3) & ~3            # keep 16-byte alignment
+        return v
+
+
+zero_pool = _ZeroPool()
+
+
+def zeros_f32(n, device):
+    return zero_pool.take(n, device)
+
+
 def empty_nhwc(N, C, H, W, dtype, device, cs=None, zero=False):
     """(N,C,H,W) view over a fresh NHWC buffer with channel stride cs (default: C rounded up to the vector width)."""
     cs = cs or round_up(C, vec_of(dtype))
@@ -193,6 +231,20 @@ def conv2d_wgrad(x, dy, R, S, stride, pad, cout=None):
     return dw
 
 
+def conv2d_wgrad_into(x, dy, R, S, stride, pad, grad, cout=None):
+    """Accumulate the weight gradient straight into `grad[:cout, :Cin]`, a logically-OIHW fp32 tensor whose taps have a
+    uniform stride (OIHW-contiguous, or physically [O][R][S][I] = coalesced atomics): a parameter's .grad or a fresh zero
+    tensor.  No packed temporary, no unpack pass."""
+    x_cs = require_nhwc(x, "x")
+    dy_cs = require_nhwc(dy, "dy")
+    N, Cin, H, W = x.shape
+    cout = dy.shape[1] if cout is None else cout
+    assert grad.dtype == torch.float32 and grad.stride(2) == S * grad.stride(3) and grad.shape[0] >= cout and grad.shape[1] >= Cin
+    d = conv_desc(x.shape, x_cs, cout, R, S, stride, pad, dy_cs, x.dtype, 0, (dy.shape[2], dy.shape[3]))
+    call("fs_conv2d_wgrad_strided", _stream(), ctypes.byref(d), _p(x), _p(dy), _p(grad), grad.stride(0), grad.stride(1), grad.stride(3))
+    return grad
+
+
 def conv_stem(x_nchw, w_packed, cout, scale, shift, relu, dtype, out=None):
     N, C, H, W = x_nchw.shape
     assert C == 3 and x_nchw.dtype == torch.float32 and x_nchw.is_contiguous()
@@ -279,7 +331,7 @@ def affine_act(x, scale, shift, relu, out=None):
 def channel_stats(x, stats=None):
     x_cs = require_nhwc(x, "x")
     if stats is None:
-        stats = torch.zeros(2 * x.shape[1], dtype=torch.float32, device=x.device)
+        stats = zeros_f32(2 * x.shape[1], x.device)
     call("fs_channel_stats", _stream(), _pix(x), x.shape[1], _p(x), x_cs, dtype_code(x.dtype), _p(stats))
     return stats
 
@@ -289,7 +341,7 @@ def bn_backward(z, dy, y_out, mean, invstd, gamma, relu):
     z_cs, dy_cs = require_nhwc(z, "z"), require_nhwc(dy, "dy")
     C = z.shape[1]
     y_cs = require_nhwc(y_out, "y_out") if relu else 0
-    red = torch.zeros(2 * C, dtype=torch.float32, device=z.device)
+    red = zeros_f32(2 * C, z.device)
     dt = dtype_code(z.dtype)
     call("fs_bn_bwd_reduce", _stream(), _pix(z), C, _p(z), z_cs, _p(dy), dy_cs, _p(y_out) if relu else None, y_cs, _p(mean),
          _p(invstd), dt, int(relu), _p(red))
@@ -313,7 +365,7 @@ def axpy(x, alpha, out, accumulate):
 
 
 def dot(x, y):
-    out = torch.zeros(1, dtype=torch.float32, device=x.device)
+    out = zeros_f32(1, x.device)
     call("fs_dot", _stream(), _pix(x), x.shape[1], _p(x), require_nhwc(x, "x"), _p(y), require_nhwc(y, "y"),
          dtype_code(x.dtype), _p(out))
     return out

@@ -41,18 +41,26 @@ class FlatGradientSync:
         self.pending = [0] * len(self.buckets)
         self.count = [sum(1 for i in range(len(self.params)) if self.bucket_id[i] == b) for b in range(len(self.buckets))]
         self.handles = {}
-        self.touched = [False] * len(self.params)
+        self._touched = [False] * len(self.params)
+        self._index = {id(p): i for i, p in enumerate(self.params)}
+        self._hooks = []
         for i, p in enumerate(self.params):
-            v = self.flat[self.offsets[i]:self.offsets[i] + sizes[i]].view_as(p)
+            v = self.flat[self.offsets[i]:self.offsets[i] + sizes[i]]
+            if p.dim() == 4:       # conv filters: gradient stored [O][R][S][I] (logical OIHW view) so the wgrad kernel's
+                O, I, R, S = p.shape   # in-place atomics are coalesced; everything else sees an ordinary strided tensor
+                v = v.view(O, R, S, I).permute(0, 3, 1, 2)
+            else:
+                v = v.view_as(p)
             self.views.append(v)
+            self._hooks.append(self._make_hook(i))
             if hasattr(p, "register_post_accumulate_grad_hook"):
-                p.register_post_accumulate_grad_hook(self._make_hook(i))
+                p.register_post_accumulate_grad_hook(self._hooks[i])
         self.prepare()
 
     def _make_hook(self, i):
         def hook(param):
-            if not self.touched[i]:
-                self.touched[i] = True
+            if not self._touched[i]:
+                self._touched[i] = True
                 b = self.bucket_id[i]
                 self.pending[b] += 1
                 if self.pending[b] == self.count[b]:
@@ -64,18 +72,36 @@ class FlatGradientSync:
             s, e = self.buckets[b]
             self.handles[b] = dist.all_reduce(self.flat[s:e], group=self.group, async_op=True)
 
+    # ---- fused gradient accumulation protocol (functional.conv_weight_grad) -------------------------------
+    def accepts(self, param):
+        i = self._index.get(id(param))
+        return i is not None and param.grad is self.views[i]
+
+    def touched(self, param):
+        self._hooks[self._index[id(param)]](param)
+
     def prepare(self):
         """Call before each backward: zero the buffer and point every .grad at its slice."""
+        from . import functional as FN
+        from . import kernels as K
+        if self.flat.is_cuda:
+            K.zero_pool.reset(self.flat.device)
+            FN._grad_sink = self
         self.flat.zero_()
         self.handles = {}
         self.pending = [0] * len(self.buckets)
-        self.touched = [False] * len(self.params)
+        self._touched = [False] * len(self.params)
         for p, v in zip(self.params, self.views):
             p.grad = v
 
     def sync(self):
         """Call after backward: finish the all-reduce of every bucket, average, hide untouched parameters from the
         optimizer (grad=None, as autograd leaves them in a single-GPU run)."""
+        from . import functional as FN
+        from . import kernels as K
+        if FN._grad_sink is self:
+            FN._grad_sink = None
+        K.zero_pool.stop()
         for b in range(len(self.buckets)):
             self._launch(b)
         for h in self.handles.values():
@@ -83,7 +109,7 @@ class FlatGradientSync:
         if self.world > 1 and self.average:
             self.flat.div_(self.world)
         if hasattr(self.params[0], "register_post_accumulate_grad_hook"):
-            for p, t in zip(self.params, self.touched):
+            for p, t in zip(self.params, self._touched):
                 if not t:
                     p.grad = None
 

@@ -96,6 +96,11 @@ fs_status fs_conv3x3_s1_fwd(void* stream, const fs_conv_desc* d, const void* x, 
 /* Replaces conv2d backward-weight: dw[co][r][s][ci] = sum_pixels dy[p][co] * x[p@(r,s)][ci], fp32 packed
  * output (caller zeroes; split-K atomics).  `d` is the forward descriptor. */
 fs_status fs_conv2d_wgrad(void* stream, const fs_conv_desc* d, const void* x, const void* dy, float* dw_packed);
+/* Same contraction accumulated (atomics) straight into a strided fp32 gradient tensor dw[co*o_stride + ci*i_stride +
+ * (r*S+s)*t_stride] — e.g. param.grad[:Cout,:Cin] of a USConv2d, either OIHW-contiguous (t_stride 1) or stored
+ * [O][R][S][I] (i_stride 1: coalesced atomics): no packed temporary, no unpack pass, no extra add. */
+fs_status fs_conv2d_wgrad_strided(void* stream, const fs_conv_desc* d, const void* x, const void* dy, float* dw,
+                                  long long o_stride, long long i_stride, long long t_stride);
 
 /* Stem convolution (model_seg.py:193): NCHW fp32 image (Cin=3) -> NHWC `dtype`, 3x3 stride 2 pad 1, fused
  * scale/shift/ReLU.  w_packed is [Cout][3][3][3] fp32. */
