@@ -86,9 +86,15 @@ def lib():
     return _lib
 
 
+_fns = {}
+
+
 def call(name, *args):
     """Invoke a status-returning entry point; raise FasterSegHipError(message) on failure."""
-    status = getattr(lib(), name)(*args)
+    fn = _fns.get(name)
+    if fn is None:
+        fn = _fns[name] = getattr(lib(), name)
+    status = fn(*args)
     if status != 0:
         msg = lib().fs_last_error()
         raise FasterSegHipError("%s failed (status %d): %s" % (name, status, msg.decode() if msg else "?"))

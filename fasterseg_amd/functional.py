@@ -96,6 +96,8 @@ def _pack_entry(weight):
 def packed_weight(weight, dtype, cout=None, cin=None, flip=False, rows=None):
     """Packed copy of (a leading block of) an OIHW parameter; re-packed only when the parameter's storage or version
     counter changed (optimizer steps bump Tensor._version)."""
+    if weight.is_cuda and torch.cuda.is_current_stream_capturing():
+        return K.pack_weight(weight.detach(), dtype, cout, cin, flip, rows)      # the pack becomes a node of the graph
     entry = _pack_entry(weight)
     stamp = (weight.data_ptr(), weight._version)
     if entry["stamp"] != stamp:

@@ -121,6 +121,14 @@ class Cell(nn.Module):
         return out, down
 
 
+def _positive_table(betas):
+    """[(b0 > 0, b1 > 0), ...] per beta row.  One host read per forward; under hipGraph capture (no host sync allowed) the
+    softmax outputs are taken as positive, which they always are."""
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        return [None] + [[[True, True]] * b.shape[0] for b in betas[1:]]
+    return [None] + [(b > 0).tolist() for b in betas[1:]]
+
+
 def _weighted_sum(weights, tensors):
     """sum(w * t) over the non-None tensors with device-resident scalar weights (model_search.py:331-332)."""
     acc = None
@@ -240,7 +248,7 @@ class Network_Multi_Path(nn.Module):
         mode = self.prun_mode if self.prun_mode is not None else self._prun_modes[k]
         ratios = self.sample_prun_ratio(mode=mode)
         # one host read of the whole beta tables instead of one implicit sync per cell (reference :326-328)
-        beta_pos = [None] + [(b > 0).tolist() for b in betas[1:]]
+        beta_pos = _positive_table(betas)
 
         out_prev = [[stem(input), None]]  # stem: one cell
         # i: layer | j: scale
@@ -288,7 +296,7 @@ class Network_Multi_Path(nn.Module):
             ratios = self.sample_prun_ratio(mode=mode)
         else:
             ratios = self.sample_prun_ratio(mode='max')
-        beta_pos = [None] + [(b > 0).tolist() for b in betas[1:]]
+        beta_pos = _positive_table(betas)
 
         stem_latency = 0
         for m in stem:

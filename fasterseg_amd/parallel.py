@@ -63,7 +63,7 @@ class FlatGradientSync:
                 self._touched[i] = True
                 b = self.bucket_id[i]
                 self.pending[b] += 1
-                if self.pending[b] == self.count[b]:
+                if self.pending[b] == self.count[b] and not (self.flat.is_cuda and torch.cuda.is_current_stream_capturing()):
                     self._launch(b)
         return hook
 
@@ -112,6 +112,14 @@ class FlatGradientSync:
             for p, t in zip(self.params, self._touched):
                 if not t:
                     p.grad = None
+
+    def touched_indices(self):
+        return [i for i, t in enumerate(self._touched) if t]
+
+    def mark_touched(self, indices):
+        """Replay of a captured backward: the Python hooks did not run, so re-declare which parameters it wrote."""
+        for i in indices:
+            self._hooks[i](self.params[i])
 
     def grad_norm(self):
         return self.flat.norm()

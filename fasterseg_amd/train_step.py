@@ -77,7 +77,11 @@ class SupernetStep:
     uses the host RNGs (np.random / torch CPU generator), seeded identically on every rank, so all ranks activate the
     same sub-network."""
 
-    def __init__(self, pretrain=True, cfg=SearchConfig, seed=12345, device="cuda", lut=None):
+    def __init__(self, pretrain=True, cfg=SearchConfig, seed=12345, device="cuda", lut=None, use_graphs=None):
+        import os
+        self.use_graphs = bool(int(os.environ.get("FS_SUPERNET_GRAPHS", "1"))) if use_graphs is None else use_graphs
+        self.graph_modes = ("max", "min")
+        self.graphs = None
         from . import model_search, operations
         from .architect import Architect
         import numpy as np
@@ -103,12 +107,79 @@ class SupernetStep:
                                          arch_learning_rate=cfg.arch_learning_rate, latency_weight=cfg.latency_weight))
             self.architect = Architect(self.model, args, grad_sync=_allreduce_list)
 
+    # ---- hipGraph capture of the shape-static passes ("max" and "min" widths) ----------------------------------
+    def _capture(self, imgs, target):
+        """Forward + backward of one fixed-width supernet pass as a single hipGraph (gradients accumulate into the flat
+        buffer, BN running statistics update on replay).  ~25 k launches per pass collapse into one graph launch; the
+        two "random"-width passes of a pretrain step change shape every step and stay eager."""
+        self.static_imgs, self.static_target = imgs.clone(), target.clone()
+        self.graphs = {}
+        try:        # the flat .grad views were created on the default stream; capture runs on a side stream by design
+            torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+        except AttributeError:
+            pass
+        side = torch.cuda.Stream()
+        for mode in self.graph_modes:
+            self.sync.prepare()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                      # warm-up on the capture stream (allocator, pack caches)
+                self._pass_loss(mode, self.static_imgs, self.static_target).backward()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.sync.prepare()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                loss = self._pass_loss(mode, self.static_imgs, self.static_target)
+                loss.backward()
+            self.graphs[mode] = (g, loss.detach(), self.sync.touched_indices())
+            self.sync.sync()
+        torch.cuda.synchronize()
+
+    def _pass_loss(self, mode, imgs, target):
+        self.model.prun_mode = mode
+        return sum(self.model._criterion(logit, target) for logit in self.model(imgs))
+
+    def _graphed_pretrain_loss(self, imgs, target):
+        """`_loss(imgs, target, pretrain=True)` with the static passes replayed from graphs; same pass order as the reference
+        (max, min, random, random), gradients accumulated pass by pass (d(sum)/dw = sum of d/dw)."""
+        if self.graphs is None:
+            self._capture(imgs, target)
+            self.sync.prepare()
+        self.static_imgs.copy_(imgs)
+        self.static_target.copy_(target)
+        total = 0
+        for mode in ("max", "min"):
+            g, loss, touched = self.graphs[mode]
+            g.replay()
+            self.sync.mark_touched(touched)
+            total = total + loss
+        for _ in range(2):
+            loss = self._pass_loss("random", imgs, target)
+            loss.backward()
+            total = total + loss.detach()
+        return total
+
     def step(self, imgs, target, imgs_search=None, target_search=None):
+        if self.use_graphs and self.pretrain and self.architect is None:
+            self.sync.prepare()
+            loss = self._graphed_pretrain_loss(imgs, target)
+            self.sync.sync()
+            torch.nn.utils.clip_grad_norm_(self.weights, self.cfg.grad_clip)
+            self.optimizer.step()
+            return loss.detach() if torch.is_tensor(loss) else loss, None
         loss_arch = None
         if self.architect is not None:
+            # The reference's architect backward also produces (and then discards: optimizer.zero_grad, train_search.py:245)
+            # gradients for every network weight.  They are never used, so the weights are frozen for the architecture
+            # step: no wgrad / BN-parameter gradient kernels run, the alpha/beta/ratio gradients are unchanged.
             for p in self.weights:
                 p.grad = None
-            loss_arch = self.architect.step(imgs, target, imgs_search, target_search)
+                p.requires_grad_(False)
+            try:
+                loss_arch = self.architect.step(imgs, target, imgs_search, target_search)
+            finally:
+                for p in self.weights:
+                    p.requires_grad_(True)
         self.sync.prepare()
         loss = self.model._loss(imgs, target, self.pretrain)
         loss.backward()
