@@ -38,17 +38,24 @@ SIGNATURES = {
     "fs_bilinear_fwd": [c_vp, ctypes.POINTER(ResizeDesc), c_vp, c_vp],
     "fs_bilinear_bwd": [c_vp, ctypes.POINTER(ResizeDesc), c_vp, c_vp, c_vp],
     "fs_bilinear_bwd_nchw": [c_vp, ctypes.POINTER(ResizeDesc), c_vp, c_vp, c_vp],
-    "fs_bn_finalize": [c_vp, c_int, c_ll, c_vp, c_vp, c_vp, c_float, c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "fs_bn_finalize": [c_vp, c_int, c_ll, c_vp, c_vp, c_vp, c_float, c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "fs_affine_act": [c_vp, c_ll, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int],
     "fs_channel_stats": [c_vp, c_ll, c_int, c_vp, c_int, c_int, c_vp],
     "fs_bn_bwd_reduce": [c_vp, c_ll, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_vp],
     "fs_bn_bwd_apply": [c_vp, c_ll, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_ll, c_int,
-                        c_int, c_vp, c_int],
+                        c_int, c_vp, c_int, c_vp, c_vp],
+    "fs_conv_bn_act_train_fwd": [c_vp, ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_float, c_float,
+                                 c_vp, c_vp, c_vp, c_vp],
+    "fs_conv_bn_act_train_bwd": [c_vp, ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp,
+                                 c_vp, c_vp, c_vp, c_ll, c_ll, c_ll, c_vp, c_int],
     "fs_nchw_to_nhwc": [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int],
     "fs_nhwc_to_nchw": [c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_int, c_vp],
     "fs_copy_channels": [c_vp, c_ll, c_int, c_vp, c_int, c_vp, c_int, c_int],
     "fs_axpy_channels": [c_vp, c_ll, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int],
     "fs_dot": [c_vp, c_ll, c_int, c_vp, c_int, c_vp, c_int, c_int, c_vp],
+    "fs_weighted_sum": [c_vp, c_ll, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_int],
+    "fs_weighted_sum_bwd": [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_int],
+    "fs_weighted_sum_dots": [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_vp],
 }
 _SPECIAL = {
     "fs_last_error": ([], ctypes.c_char_p),

@@ -48,6 +48,10 @@ class Architect(object):
 
     def _backward_step(self, input_valid, target_valid):
         loss = self.model._loss(input_valid, target_valid)
+        return loss, self._latency_loss()
+
+    def _latency_loss(self):
+        """The latency penalty of `_backward_step` (architect.py:60-76): 0, or a device scalar."""
         loss_latency = 0
         self.latency_supernet = 0
         self.model.prun_mode = None
@@ -62,4 +66,4 @@ class Architect(object):
                     latency = latency + weight * self.model.forward_latency(self.latency_input, alpha=a, beta=b, ratio=r)
                 self.latency_supernet = latency
                 loss_latency = loss_latency + latency * self.latency_weight[idx]
-        return loss, loss_latency
+        return loss_latency

@@ -218,10 +218,15 @@ __global__ void bn_bwd_apply_kernel(long long pixels, int cv, const T* __restric
                                     int dy_cs, const T* __restrict__ yo, int y_cs, const float* __restrict__ mean,
                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
                                     const float* __restrict__ red, float inv_count, int relu, T* __restrict__ dx,
-                                    int dx_cs) {
+                                    int dx_cs, float* dgamma_acc, float* dbeta_acc) {
     constexpr int VEC = Elem<T>::VEC;
     const int C = cv * VEC;
     const long long total = pixels * cv;
+    if (dgamma_acc && blockIdx.x == 0)          // parameter gradients: grad += this pass's reduction (one block, plain RMW)
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            dgamma_acc[c] += red[C + c];
+            dbeta_acc[c] += red[c];
+        }
     for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
         const long long pix = idx / cv;
@@ -247,8 +252,10 @@ __global__ void bn_bwd_apply_kernel(long long pixels, int cv, const T* __restric
 
 __global__ void bn_finalize_kernel(int C, float count, const float* __restrict__ stats, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float eps, float momentum, float* running_mean,
-                                   float* running_var, float* mean, float* invstd, float* scale, float* shift) {
+                                   float* running_var, float* mean, float* invstd, float* scale, float* shift,
+                                   long long* num_batches_tracked) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
     if (c >= C) return;
     const float m = stats[c] / count;
     float var = stats[C + c] / count - m * m;
@@ -288,6 +295,103 @@ __global__ __launch_bounds__(256) void dot_kernel(long long pixels, int cv, cons
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// n-way weighted sums (MixedOp / beta mixing of the supernet, model_search.py:76-78,330-333): n <= FS_WSUM_MAX
+// operands, coefficients resident on the device.
+// ---------------------------------------------------------------------------------------------------
+struct WsumOperands {
+    const void* p[FS_WSUM_MAX];
+    int cs[FS_WSUM_MAX];
+    int n;
+};
+
+template <typename T>
+__global__ void wsum_kernel(long long pixels, int cv, WsumOperands a, const float* __restrict__ coef, T* __restrict__ out,
+                            int out_cs) {
+    constexpr int VEC = Elem<T>::VEC;
+    const long long total = pixels * cv;
+    float w[FS_WSUM_MAX];
+#pragma unroll
+    for (int k = 0; k < FS_WSUM_MAX; ++k) w[k] = k < a.n ? coef[k] : 0.f;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const long long pix = idx / cv;
+        const int c = (int)(idx - pix * cv) * VEC;
+        float acc[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int k = 0; k < FS_WSUM_MAX; ++k)
+            if (k < a.n) {
+                float f[VEC];
+                Elem<T>::unpack(ldg16((const T*)a.p[k] + pix * a.cs[k] + c), f);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) acc[i] += w[k] * f[i];
+            }
+        stg16(out + pix * out_cs + c, Elem<T>::pack(acc));
+    }
+}
+
+// dx_k = coef[k] * dy for every operand k with a non-null destination
+template <typename T>
+__global__ void wsum_bwd_kernel(long long pixels, int cv, const T* __restrict__ dy, int dy_cs, const float* __restrict__ coef,
+                                WsumOperands a) {
+    constexpr int VEC = Elem<T>::VEC;
+    const long long total = pixels * cv;
+    float w[FS_WSUM_MAX];
+#pragma unroll
+    for (int k = 0; k < FS_WSUM_MAX; ++k) w[k] = k < a.n ? coef[k] : 0.f;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const long long pix = idx / cv;
+        const int c = (int)(idx - pix * cv) * VEC;
+        float g[VEC];
+        Elem<T>::unpack(ldg16(dy + pix * dy_cs + c), g);
+#pragma unroll
+        for (int k = 0; k < FS_WSUM_MAX; ++k)
+            if (k < a.n && a.p[k]) {
+                float f[VEC];
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) f[i] = w[k] * g[i];
+                stg16((T*)a.p[k] + pix * a.cs[k] + c, Elem<T>::pack(f));
+            }
+    }
+}
+
+// out[k] += <dy, x_k>: gradients of the n mixing coefficients in one pass over dy
+template <typename T>
+__global__ __launch_bounds__(256) void wsum_dot_kernel(long long pixels, int cv, const T* __restrict__ dy, int dy_cs,
+                                                       WsumOperands a, float* __restrict__ out) {
+    constexpr int VEC = Elem<T>::VEC;
+    __shared__ float part[FS_WSUM_MAX][4];
+    const long long total = pixels * cv;
+    float acc[FS_WSUM_MAX];
+#pragma unroll
+    for (int k = 0; k < FS_WSUM_MAX; ++k) acc[k] = 0.f;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const long long pix = idx / cv;
+        const int c = (int)(idx - pix * cv) * VEC;
+        float g[VEC];
+        Elem<T>::unpack(ldg16(dy + pix * dy_cs + c), g);
+#pragma unroll
+        for (int k = 0; k < FS_WSUM_MAX; ++k)
+            if (k < a.n) {
+                float f[VEC];
+                Elem<T>::unpack(ldg16((const T*)a.p[k] + pix * a.cs[k] + c), f);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) acc[k] += f[i] * g[i];
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < FS_WSUM_MAX; ++k) {
+        const float v = wave_sum(acc[k]);
+        if ((threadIdx.x & 63) == 0) part[k][threadIdx.x >> 6] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < a.n) atomicAdd(out + threadIdx.x, part[threadIdx.x][0] + part[threadIdx.x][1] + part[threadIdx.x][2] + part[threadIdx.x][3]);
 }
 
 static fs_status check_slice(const char* fn, const void* p, int cs, int C, int dtype) {
@@ -389,8 +493,8 @@ extern "C" fs_status fs_axpy_channels(void* stream, long long pixels, int C, con
 
 static int reduce_blocks(long long pixels, int rpb, long long* ppb) {
     long long iters = (pixels + rpb - 1) / rpb;
-    long long blocks = (iters + 15) / 16;        // >= 16 iterations per block
-    if (blocks > 1024) blocks = 1024;
+    long long blocks = (iters + 3) / 4;          // >= 4 iterations per block (each is a dependent 16-byte gather)
+    if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     long long per = (pixels + blocks - 1) / blocks;
     per = (per + rpb - 1) / rpb * rpb;
@@ -414,10 +518,10 @@ extern "C" fs_status fs_channel_stats(void* stream, long long pixels, int C, con
 
 extern "C" fs_status fs_bn_finalize(void* stream, int C, long long count, const float* stats, const float* gamma,
                                     const float* beta, float eps, float momentum, float* running_mean, float* running_var,
-                                    float* mean, float* invstd, float* scale, float* shift) {
+                                    float* mean, float* invstd, float* scale, float* shift, long long* num_batches_tracked) {
     FS_REQUIRE(stats && C > 0 && count > 0, FS_ERR_INVALID, "fs_bn_finalize: bad argument");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, C, (float)count, stats, gamma,
-                       beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
+                       beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift, num_batches_tracked);
     return check_launch("fs_bn_finalize");
 }
 
@@ -441,8 +545,10 @@ extern "C" fs_status fs_bn_bwd_reduce(void* stream, long long pixels, int C, con
 
 extern "C" fs_status fs_bn_bwd_apply(void* stream, long long pixels, int C, const void* x, int x_cs, const void* dy, int dy_cs,
                                      const void* y_out, int y_cs, const float* mean, const float* invstd, const float* gamma,
-                                     const float* red, long long count, int dtype, int relu, void* dx, int dx_cs) {
+                                     const float* red, long long count, int dtype, int relu, void* dx, int dx_cs,
+                                     float* dgamma_acc, float* dbeta_acc) {
     fs_status s;
+    FS_REQUIRE((dgamma_acc == nullptr) == (dbeta_acc == nullptr), FS_ERR_INVALID, "fs_bn_bwd_apply: dgamma_acc/dbeta_acc go together");
     if ((s = check_slice("fs_bn_bwd_apply", x, x_cs, C, dtype)) != FS_OK) return s;
     if ((s = check_slice("fs_bn_bwd_apply", dy, dy_cs, C, dtype)) != FS_OK) return s;
     if ((s = check_slice("fs_bn_bwd_apply", dx, dx_cs, C, dtype)) != FS_OK) return s;
@@ -451,7 +557,7 @@ extern "C" fs_status fs_bn_bwd_apply(void* stream, long long pixels, int C, cons
     const int cv = C / vec_elems(dtype);
     DT_DISPATCH(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(grid_for(pixels * cv)), dim3(256), 0, (hipStream_t)stream,
                                           pixels, cv, (const T*)x, x_cs, (const T*)dy, dy_cs, (const T*)y_out, y_cs, mean, invstd,
-                                          gamma, red, 1.0f / (float)count, relu, (T*)dx, dx_cs);)
+                                          gamma, red, 1.0f / (float)count, relu, (T*)dx, dx_cs, dgamma_acc, dbeta_acc);)
     return check_launch("fs_bn_bwd_apply");
 }
 
@@ -465,4 +571,58 @@ extern "C" fs_status fs_dot(void* stream, long long pixels, int C, const void* x
     DT_DISPATCH(dtype, hipLaunchKernelGGL((dot_kernel<T>), dim3(grid_for(pixels * cv, 256, 1024)), dim3(256), 0,
                                           (hipStream_t)stream, pixels, cv, (const T*)x, x_cs, (const T*)y, y_cs, out);)
     return check_launch("fs_dot");
+}
+
+static fs_status wsum_operands(const char* fn, int n, const void* const* ptrs, const int* cs, int C, int dtype, bool allow_null,
+                               WsumOperands* a) {
+    FS_REQUIRE(n >= 1 && n <= FS_WSUM_MAX && ptrs && cs, FS_ERR_INVALID, "%s: n=%d operands (1..%d)", fn, n, FS_WSUM_MAX);
+    a->n = n;
+    for (int k = 0; k < FS_WSUM_MAX; ++k) { a->p[k] = nullptr; a->cs[k] = 0; }
+    for (int k = 0; k < n; ++k) {
+        if (ptrs[k] == nullptr && allow_null) continue;
+        fs_status s = check_slice(fn, ptrs[k], cs[k], C, dtype);
+        if (s != FS_OK) return s;
+        a->p[k] = ptrs[k];
+        a->cs[k] = cs[k];
+    }
+    return FS_OK;
+}
+
+extern "C" fs_status fs_weighted_sum(void* stream, long long pixels, int C, int n, const void* const* xs, const int* x_cs,
+                                     const float* coef, void* out, int out_cs, int dtype) {
+    fs_status s;
+    WsumOperands a;
+    if ((s = wsum_operands("fs_weighted_sum", n, xs, x_cs, C, dtype, false, &a)) != FS_OK) return s;
+    if ((s = check_slice("fs_weighted_sum", out, out_cs, C, dtype)) != FS_OK) return s;
+    FS_REQUIRE(coef, FS_ERR_INVALID, "fs_weighted_sum: null coefficients");
+    const int cv = C / vec_elems(dtype);
+    DT_DISPATCH(dtype, hipLaunchKernelGGL((wsum_kernel<T>), dim3(grid_for(pixels * cv)), dim3(256), 0, (hipStream_t)stream, pixels,
+                                          cv, a, coef, (T*)out, out_cs);)
+    return check_launch("fs_weighted_sum");
+}
+
+extern "C" fs_status fs_weighted_sum_bwd(void* stream, long long pixels, int C, int n, const void* dy, int dy_cs, const float* coef,
+                                         void* const* dxs, const int* dx_cs, int dtype) {
+    fs_status s;
+    WsumOperands a;
+    if ((s = wsum_operands("fs_weighted_sum_bwd", n, (const void* const*)dxs, dx_cs, C, dtype, true, &a)) != FS_OK) return s;
+    if ((s = check_slice("fs_weighted_sum_bwd", dy, dy_cs, C, dtype)) != FS_OK) return s;
+    FS_REQUIRE(coef, FS_ERR_INVALID, "fs_weighted_sum_bwd: null coefficients");
+    const int cv = C / vec_elems(dtype);
+    DT_DISPATCH(dtype, hipLaunchKernelGGL((wsum_bwd_kernel<T>), dim3(grid_for(pixels * cv)), dim3(256), 0, (hipStream_t)stream,
+                                          pixels, cv, (const T*)dy, dy_cs, coef, a);)
+    return check_launch("fs_weighted_sum_bwd");
+}
+
+extern "C" fs_status fs_weighted_sum_dots(void* stream, long long pixels, int C, int n, const void* dy, int dy_cs,
+                                          const void* const* xs, const int* x_cs, int dtype, float* out) {
+    fs_status s;
+    WsumOperands a;
+    if ((s = wsum_operands("fs_weighted_sum_dots", n, xs, x_cs, C, dtype, false, &a)) != FS_OK) return s;
+    if ((s = check_slice("fs_weighted_sum_dots", dy, dy_cs, C, dtype)) != FS_OK) return s;
+    FS_REQUIRE(out, FS_ERR_INVALID, "fs_weighted_sum_dots: null out");
+    const int cv = C / vec_elems(dtype);
+    DT_DISPATCH(dtype, hipLaunchKernelGGL((wsum_dot_kernel<T>), dim3(grid_for(pixels * cv, 256, 1024)), dim3(256), 0,
+                                          (hipStream_t)stream, pixels, cv, (const T*)dy, dy_cs, a, out);)
+    return check_launch("fs_weighted_sum_dots");
 }

@@ -1,0 +1,69 @@
+// Train-mode fused units: the whole launch sequence of one reference module issued from ONE host call.
+//
+// The supernet of the search phase runs ~3400 conv->BN->[ReLU] modules per step on maps as small as 4x8 pixels
+// (reference search/operations.py:42-128 ConvNorm, :131-262 BasicResidual*, model_search.py:66-93 MixedOp); each module
+// is three kernels forward and four backward of a few microseconds each, so the host side of a launch costs more than
+// the kernel.  These entry points keep the per-module host work to one FFI crossing: descriptor derivation for the
+// data-gradient conv, the BN bookkeeping (running statistics, num_batches_tracked) and the parameter-gradient
+// accumulation all happen here or inside the kernels.
+#include "common.h"
+
+extern "C" fs_status fs_conv_bn_act_train_fwd(void* stream, const fs_conv_desc* d, const void* x, const void* w_packed,
+                                              const float* gamma, const float* beta, float* running_mean,
+                                              float* running_var, long long* num_batches_tracked, float eps,
+                                              float momentum, float* stats, float* saved, void* z, void* y) {
+    FS_REQUIRE(d && x && w_packed && stats && saved && z && y, FS_ERR_INVALID, "fs_conv_bn_act_train_fwd: null argument");
+    fs_conv_desc c = *d;
+    c.flags &= ~FS_CONV_RELU;          // the conv writes the raw pre-normalisation map z (+ per-channel sum / sumsq)
+    fs_status s = fs_conv2d_fwd(stream, &c, x, w_packed, nullptr, nullptr, z, stats);
+    if (s != FS_OK) return s;
+    const int C = d->Cout;
+    const long long count = (long long)d->N * d->Ho * d->Wo;
+    s = fs_bn_finalize(stream, C, count, stats, gamma, beta, eps, momentum, running_mean, running_var, saved, saved + C,
+                       saved + 2 * C, saved + 3 * C, num_batches_tracked);
+    if (s != FS_OK) return s;
+    return fs_affine_act(stream, count, C, z, d->y_cs, saved + 2 * C, saved + 3 * C, y, d->y_cs, d->dtype,
+                         (d->flags & FS_CONV_RELU) ? 1 : 0);
+}
+
+extern "C" fs_status fs_conv_bn_act_train_bwd(void* stream, const fs_conv_desc* d, const void* x, const void* w_flip,
+                                              const void* z, const void* y, const void* dy, int dy_cs, const float* saved,
+                                              const float* gamma, float* red, float* dgamma_acc, float* dbeta_acc,
+                                              void* dz, float* dw, long long o_stride, long long i_stride,
+                                              long long t_stride, void* dx, int dx_cs) {
+    FS_REQUIRE(d && z && dy && saved && gamma && red && dz, FS_ERR_INVALID, "fs_conv_bn_act_train_bwd: null argument");
+    const int relu = (d->flags & FS_CONV_RELU) ? 1 : 0;
+    FS_REQUIRE(!relu || y, FS_ERR_INVALID, "fs_conv_bn_act_train_bwd: ReLU unit needs its output y");
+    const int C = d->Cout;
+    const long long pixels = (long long)d->N * d->Ho * d->Wo;
+    const float* mean = saved;
+    const float* invstd = saved + C;
+    fs_status s = fs_bn_bwd_reduce(stream, pixels, C, z, d->y_cs, dy, dy_cs, y, d->y_cs, mean, invstd, d->dtype, relu, red);
+    if (s != FS_OK) return s;
+    s = fs_bn_bwd_apply(stream, pixels, C, z, d->y_cs, dy, dy_cs, y, d->y_cs, mean, invstd, gamma, red, pixels, d->dtype, relu,
+                        dz, C, dgamma_acc, dbeta_acc);          // dz is dense: channel stride == Cout
+    if (s != FS_OK) return s;
+    if (dw) {
+        FS_REQUIRE(x, FS_ERR_INVALID, "fs_conv_bn_act_train_bwd: weight gradient needs x");
+        fs_conv_desc w = *d;
+        w.flags = 0;
+        w.y_cs = C;
+        s = fs_conv2d_wgrad_strided(stream, &w, x, dz, dw, o_stride, i_stride, t_stride);
+        if (s != FS_OK) return s;
+    }
+    if (dx) {
+        // data gradient = conv of dz with the 180-degree-rotated, IO-transposed filter (zero insertion for stride 2)
+        FS_REQUIRE(w_flip, FS_ERR_INVALID, "fs_conv_bn_act_train_bwd: data gradient needs the flipped filter pack");
+        fs_conv_desc g;
+        g.N = d->N; g.H = d->Ho; g.W = d->Wo; g.Cin = d->Cout;
+        g.Cout = d->Cin; g.R = d->R; g.S = d->S;
+        g.stride = 1; g.pad = d->R - 1 - d->pad;
+        g.Ho = d->H; g.Wo = d->W;
+        g.x_cs = C; g.y_cs = dx_cs;
+        g.dtype = d->dtype;
+        g.flags = d->stride == 2 ? FS_CONV_TRANSPOSED : 0;
+        s = fs_conv2d_fwd(stream, &g, dz, w_flip, nullptr, nullptr, dx, nullptr);
+        if (s != FS_OK) return s;
+    }
+    return FS_OK;
+}

@@ -9,6 +9,7 @@ Each Function is one fused unit of the hot path (forward and backward both run o
   scale_accumulate  acc + coef * x with a device-resident scalar coef               model_search.py:76-78,330-333
 There is no eager/ATen fallback: inputs that are not NHWC views are converted with fs_nchw_to_nhwc.
 """
+import ctypes
 import weakref
 
 import torch
@@ -154,9 +155,21 @@ def _dgrad(dz, weight, cin, R, S, stride, pad, in_hw, rows=None):
     return K.conv2d(dz, wf, cin, R, S, 1, R - 1 - pad, transposed=(stride == 2), out_hw=in_hw)
 
 
+def _sink_slot(sink, param, n):
+    """The flat-buffer slice behind `param.grad` if the active gradient sink owns it (fused accumulation), else None."""
+    g = param.grad
+    if sink is not None and g is not None and g.dtype == torch.float32 and g.numel() == n and g.is_contiguous() and sink.accepts(param):
+        return g
+    return None
+
+
 class _ConvBNAct(torch.autograd.Function):
+    """conv -> BN -> [ReLU].  Training mode goes through the fused-unit entry points (one FFI crossing forward, one
+    backward: fs_conv_bn_act_train_fwd / _bwd) and touches as little Python as possible: the supernet calls this ~3000
+    times per step on maps of a few thousand pixels."""
+
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, cfg):
+    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, num_batches_tracked, cfg):
         stride, pad, relu, training, momentum, eps, cout, cin = cfg
         R, S = weight.shape[2], weight.shape[3]
         assert x.shape[1] == cin, "input has %d channels, conv expects %d" % (x.shape[1], cin)
@@ -167,43 +180,85 @@ class _ConvBNAct(torch.autograd.Function):
             ctx.eval_mode = True
             ctx.mark_non_differentiable(y)
             return y
-        stats = _zero_stats(cout, x.device)
-        z = K.conv2d(x, wp, cout, R, S, stride, pad, stats=stats)
-        count = z.shape[0] * z.shape[2] * z.shape[3]
-        mean, invstd, scale, shift = K.bn_finalize(stats, count, gamma.detach(), beta.detach(), eps, momentum,
-                                                   running_mean, running_var)
-        y = K.affine_act(z, scale, shift, relu)
+        N, _, H, W = x.shape
+        Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
+        dtype, dev = x.dtype, x.device
+        d = K.ConvDesc(N, H, W, cin, cout, R, S, stride, pad, Ho, Wo, x.stride(3), cout, K.dtype_code(dtype),
+                       K.FS_CONV_RELU if relu else 0)
+        strides = (Ho * Wo * cout, 1, Wo * cout, cout)
+        z = torch.empty_strided((N, cout, Ho, Wo), strides, dtype=dtype, device=dev)
+        y = torch.empty_strided((N, cout, Ho, Wo), strides, dtype=dtype, device=dev)
+        saved = torch.empty(4 * cout, dtype=torch.float32, device=dev)      # mean | invstd | scale | shift
+        stats = K.zeros_f32(2 * cout, dev)
+        K.call("fs_conv_bn_act_train_fwd", K._stream(), ctypes.byref(d), x.data_ptr(), wp.data_ptr(), gamma.data_ptr(),
+               beta.data_ptr(), running_mean.data_ptr() if running_mean is not None else None,
+               running_var.data_ptr() if running_var is not None else None,
+               num_batches_tracked.data_ptr() if num_batches_tracked is not None else None, eps, momentum,
+               stats.data_ptr(), saved.data_ptr(), z.data_ptr(), y.data_ptr())
         ctx.eval_mode = False
         ctx.cfg = cfg
-        ctx.save_for_backward(x, weight, gamma, z, y if relu else None, mean, invstd)
+        ctx.desc = d
+        ctx.save_for_backward(x, weight, gamma, beta, z, y if relu else None, saved)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         if ctx.eval_mode:
             raise RuntimeError("fasterseg_amd: backward through eval-mode conv+BN is not part of the hot path")
-        x, weight, gamma, z, y, mean, invstd = ctx.saved_tensors
+        x, weight, gamma, beta, z, y, saved = ctx.saved_tensors
         stride, pad, relu, training, momentum, eps, cout, cin = ctx.cfg
-        R, S = weight.shape[2], weight.shape[3]
-        dy = as_nhwc(dy, z.dtype)
-        dz, dgamma, dbeta = K.bn_backward(z, dy, y, mean, invstd, gamma.detach(), relu)
-        gw = gx = None
-        if ctx.needs_input_grad[1]:
-            gw = conv_weight_grad(weight, x, dz, R, S, stride, pad, cout, cin)
-        if ctx.needs_input_grad[0]:
-            gx = _dgrad(dz, weight, cin, R, S, stride, pad, (x.shape[2], x.shape[3]))
-        return gx, gw, dgamma, dbeta, None, None, None
+        d = ctx.desc
+        R, S = d.R, d.S
+        dtype, dev = z.dtype, z.device
+        dy = as_nhwc(dy, dtype)
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        sink = _grad_sink
+        red = K.zeros_f32(2 * cout, dev)
+        gslot = bslot = None
+        if ctx.needs_input_grad[2] and ctx.needs_input_grad[3]:
+            gslot = _sink_slot(sink, gamma, cout)
+            bslot = _sink_slot(sink, beta, cout) if gslot is not None else None
+            if bslot is None:
+                gslot = None
+        dz = torch.empty_strided(z.shape, z.stride(), dtype=dtype, device=dev)
+        gw = gx = wslot = None
+        if need_w:
+            g = weight.grad
+            if (sink is not None and g is not None and g.dtype == torch.float32 and g.shape == weight.shape
+                    and g.stride(2) == S * g.stride(3) and sink.accepts(weight)):
+                wslot = g
+            else:       # physically [O][R][S][I]: the kernel's atomics are then coalesced
+                gw = torch.zeros((weight.shape[0], R, S, weight.shape[1]), dtype=torch.float32, device=dev).permute(0, 3, 1, 2)
+            wdst = wslot if wslot is not None else gw
+        wf = None
+        if need_x:
+            wf = packed_weight(weight, dtype, cout, cin, flip=True)
+            gx = torch.empty_strided(x.shape, (d.H * d.W * cin, 1, d.W * cin, cin), dtype=dtype, device=dev)
+        K.call("fs_conv_bn_act_train_bwd", K._stream(), ctypes.byref(d), x.data_ptr(), wf.data_ptr() if need_x else None,
+               z.data_ptr(), y.data_ptr() if relu else None, dy.data_ptr(), dy.stride(3), saved.data_ptr(), gamma.data_ptr(),
+               red.data_ptr(), gslot.data_ptr() if gslot is not None else None, bslot.data_ptr() if bslot is not None else None,
+               dz.data_ptr(), wdst.data_ptr() if need_w else None, wdst.stride(0) if need_w else 0,
+               wdst.stride(1) if need_w else 0, wdst.stride(3) if need_w else 0, gx.data_ptr() if need_x else None, cin)
+        if wslot is not None:
+            sink.touched(weight)
+        dgamma, dbeta = red[cout:], red[:cout]
+        if gslot is not None:
+            sink.touched(gamma)
+            sink.touched(beta)
+            dgamma = dbeta = None
+        return gx, gw, dgamma, dbeta, None, None, None, None
 
 
 def conv_bn_act(x, weight, gamma, beta, running_mean, running_var, stride, pad, relu, training, momentum=0.1, eps=1e-5,
-                cout=None, cin=None):
+                cout=None, cin=None, num_batches_tracked=None):
+    """`num_batches_tracked` (the BN module's counter, or None) is incremented on the device in training mode."""
     x = as_nhwc(x)
     cout = weight.shape[0] if cout is None else cout
     cin = weight.shape[1] if cin is None else cin
     if _tracer is not None:
         return _tracer.conv(x, weight, (gamma, beta, running_mean, running_var, eps), None, stride, pad, relu, training, cout, cin)
     cfg = (stride, pad, relu, training, momentum, eps, cout, cin)
-    return _ConvBNAct.apply(x, weight, gamma, beta, running_mean, running_var, cfg)
+    return _ConvBNAct.apply(x, weight, gamma, beta, running_mean, running_var, num_batches_tracked if training else None, cfg)
 
 
 class _StemConvBNAct(torch.autograd.Function):
@@ -519,6 +574,42 @@ def scale_accumulate(acc, x, coef):
     if not torch.is_tensor(coef):
         coef = torch.tensor(float(coef), dtype=torch.float32, device=x.device)
     return _ScaleAccumulate.apply(acc, x, coef)
+
+
+class _WeightedSum(torch.autograd.Function):
+    """out = sum_k coef[k] * x_k in one launch (MixedOp's five primitives, the beta mixing of two cell inputs); coef is a
+    contiguous fp32 device vector.  Backward: one launch for all dx_k, one for all d coef[k] (only when coef needs it)."""
+
+    @staticmethod
+    def forward(ctx, coef, *xs):
+        c = coef.detach()
+        if c.dtype != torch.float32 or not c.is_contiguous():
+            c = c.float().contiguous()
+        out = K.weighted_sum(xs, c)
+        ctx.n = len(xs)
+        ctx.save_for_backward(c, *(xs if ctx.needs_input_grad[0] else ()))
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        c = ctx.saved_tensors[0]
+        dy = as_nhwc(dy)
+        gxs = K.weighted_sum_bwd(dy, c, ctx.needs_input_grad[1:])
+        gc = None
+        if ctx.needs_input_grad[0]:
+            gc = K.weighted_sum_dots(dy, [as_nhwc(t, dy.dtype) for t in ctx.saved_tensors[1:]])
+        return (gc,) + tuple(gxs)
+
+
+def weighted_sum(xs, coef):
+    """sum_k coef[k] * xs[k] for NHWC feature maps and a device-resident coefficient vector (len(xs) <= 8)."""
+    xs = [as_nhwc(t) for t in xs]
+    if any(t.dtype != xs[0].dtype for t in xs):
+        xs = [as_nhwc(t, xs[0].dtype) for t in xs]
+    if coef.device != xs[0].device:
+        coef = coef.to(xs[0].device)
+    assert coef.numel() == len(xs) <= 8, "weighted_sum: %d coefficients for %d operands" % (coef.numel(), len(xs))
+    return _WeightedSum.apply(coef, *xs)
 
 
 def cat(tensors):

@@ -313,12 +313,11 @@ def _pix(t):
     return t.shape[0] * t.shape[2] * t.shape[3]
 
 
-def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean, running_var):
+def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked=None):
     C = stats.numel() // 2
-    mean = torch.empty(C, dtype=torch.float32, device=stats.device)
-    invstd, scale, shift = torch.empty_like(mean), torch.empty_like(mean), torch.empty_like(mean)
+    mean, invstd, scale, shift = torch.empty((4, C), dtype=torch.float32, device=stats.device).unbind(0)
     call("fs_bn_finalize", _stream(), C, int(count), _p(stats), _p(gamma), _p(beta), float(eps), float(momentum),
-         _p(running_mean), _p(running_var), _p(mean), _p(invstd), _p(scale), _p(shift))
+         _p(running_mean), _p(running_var), _p(mean), _p(invstd), _p(scale), _p(shift), _p(num_batches_tracked))
     return mean, invstd, scale, shift
 
 
@@ -339,8 +338,9 @@ def channel_stats(x, stats=None):
     return stats
 
 
-def bn_backward(z, dy, y_out, mean, invstd, gamma, relu):
-    """Returns (dz, dgamma, dbeta) for y = relu?(gamma*(z-mean)*invstd + beta)."""
+def bn_backward(z, dy, y_out, mean, invstd, gamma, relu, dgamma_acc=None, dbeta_acc=None):
+    """Returns (dz, dgamma, dbeta) for y = relu?(gamma*(z-mean)*invstd + beta); with dgamma_acc/dbeta_acc (fp32 [C]) the two
+    parameter gradients are also accumulated into those buffers by the apply pass."""
     z_cs, dy_cs = require_nhwc(z, "z"), require_nhwc(dy, "dy")
     C = z.shape[1]
     y_cs = require_nhwc(y_out, "y_out") if relu else 0
@@ -350,7 +350,7 @@ def bn_backward(z, dy, y_out, mean, invstd, gamma, relu):
          _p(invstd), dt, int(relu), _p(red))
     dz = empty_nhwc(z.shape[0], C, z.shape[2], z.shape[3], z.dtype, z.device)
     call("fs_bn_bwd_apply", _stream(), _pix(z), C, _p(z), z_cs, _p(dy), dy_cs, _p(y_out) if relu else None, y_cs, _p(mean),
-         _p(invstd), _p(gamma), _p(red), _pix(z), dt, int(relu), _p(dz), channel_stride(dz))
+         _p(invstd), _p(gamma), _p(red), _pix(z), dt, int(relu), _p(dz), channel_stride(dz), _p(dgamma_acc), _p(dbeta_acc))
     return dz, red[C:], red[:C]
 
 
@@ -371,6 +371,46 @@ def dot(x, y):
     out = zeros_f32(1, x.device)
     call("fs_dot", _stream(), _pix(x), x.shape[1], _p(x), require_nhwc(x, "x"), _p(y), require_nhwc(y, "y"),
          dtype_code(x.dtype), _p(out))
+    return out
+
+
+def _operand_arrays(tensors):
+    n = len(tensors)
+    ptrs = (ctypes.c_void_p * n)(*[None if t is None else t.data_ptr() for t in tensors])
+    strides = (ctypes.c_int * n)(*[0 if t is None else t.stride(3) for t in tensors])
+    return n, ptrs, strides
+
+
+def weighted_sum(xs, coef, out=None):
+    """out = sum_k coef[k] * xs[k]; xs are NHWC views of one shape/dtype, coef a contiguous fp32 device vector."""
+    x0 = xs[0]
+    for t in xs:
+        require_nhwc(t, "operand")
+    n, ptrs, strides = _operand_arrays(xs)
+    if out is None:
+        out = empty_nhwc(*x0.shape, x0.dtype, x0.device)
+    call("fs_weighted_sum", _stream(), _pix(x0), x0.shape[1], n, ptrs, strides, coef.data_ptr(), out.data_ptr(), out.stride(3),
+         dtype_code(x0.dtype))
+    return out
+
+
+def weighted_sum_bwd(dy, coef, need):
+    """[coef[k] * dy if need[k] else None for k]."""
+    dy_cs = require_nhwc(dy, "dy")
+    outs = [empty_nhwc(*dy.shape, dy.dtype, dy.device) if nd else None for nd in need]
+    n, ptrs, strides = _operand_arrays(outs)
+    call("fs_weighted_sum_bwd", _stream(), _pix(dy), dy.shape[1], n, dy.data_ptr(), dy_cs, coef.data_ptr(), ptrs, strides,
+         dtype_code(dy.dtype))
+    return outs
+
+
+def weighted_sum_dots(dy, xs):
+    """fp32 vector [<dy, x_k>]."""
+    dy_cs = require_nhwc(dy, "dy")
+    n, ptrs, strides = _operand_arrays(xs)
+    out = torch.zeros(n, dtype=torch.float32, device=dy.device)
+    call("fs_weighted_sum_dots", _stream(), _pix(dy), dy.shape[1], n, dy.data_ptr(), dy_cs, ptrs, strides, dtype_code(dy.dtype),
+         out.data_ptr())
     return out
 
 

@@ -79,10 +79,14 @@ class MixedOp(nn.Module):
         ratio0, r_score0 = _width_and_score(ratios[0], self._width_mult_list)
         ratio1, r_score1 = _width_and_score(ratios[1], self._width_mult_list)
         self.set_prun_ratio((ratio0, ratio1))
-        result = None
-        for w, op in zip(weights, self._ops):
-            result = FN.scale_accumulate(result, op(x), w * r_score0 * r_score1)
-        return result
+        coef = weights                                 # sum_k w_k * r_score0 * r_score1 * op_k(x), reference :76-78
+        if not torch.is_tensor(coef):
+            coef = torch.stack([torch.as_tensor(w, dtype=torch.float32, device=x.device).reshape(()) for w in coef])
+        if torch.is_tensor(r_score0):                  # (a forced width has score 1.: no `* 1.` launches)
+            coef = coef * r_score0
+        if torch.is_tensor(r_score1):
+            coef = coef * r_score1
+        return FN.weighted_sum([op(x) for op in self._ops], coef)
 
     def forward_latency(self, size, weights, ratios):
         ratio0, r_score0 = _width_and_score(ratios[0], self._width_mult_list)
@@ -131,11 +135,15 @@ def _positive_table(betas):
 
 def _weighted_sum(weights, tensors):
     """sum(w * t) over the non-None tensors with device-resident scalar weights (model_search.py:331-332)."""
+    live = [k for k, t in enumerate(tensors) if t is not None]
+    if not live:
+        return 0
+    if len(live) == len(tensors):
+        return FN.weighted_sum(list(tensors), weights)
     acc = None
-    for w, t in zip(weights, tensors):
-        if t is not None:
-            acc = FN.scale_accumulate(acc, t, w)
-    return 0 if acc is None else acc
+    for k in live:
+        acc = FN.scale_accumulate(acc, tensors[k], weights[k])
+    return acc
 
 
 class Network_Multi_Path(nn.Module):

@@ -44,10 +44,11 @@ def lookup_latency(name, measure):
     return latency
 
 
-def _bn_args(bn):
-    """(module holding the active statistics, use-batch-stats flag); bumps num_batches_tracked like nn.BatchNorm2d."""
+def _bn_args(bn, bump=True):
+    """(module holding the active statistics, use-batch-stats flag); bumps num_batches_tracked like nn.BatchNorm2d
+    (bump=False: the caller hands the counter to a kernel that increments it on the device)."""
     b = bn.active() if isinstance(bn, USBatchNorm2d) else bn
-    if b.training and b.track_running_stats and b.num_batches_tracked is not None:
+    if bump and b.training and b.track_running_stats and b.num_batches_tracked is not None:
         b.num_batches_tracked.add_(1)
     return b, (b.training or not b.track_running_stats)
 
@@ -58,9 +59,10 @@ def conv_bn(x, conv, bn, relu):
         cout, cin = conv.active_channels()
     else:
         cout, cin = conv.out_channels, conv.in_channels
-    b, use_batch = _bn_args(bn)
+    b, use_batch = _bn_args(bn, bump=False)
+    nbt = b.num_batches_tracked if (b.training and b.track_running_stats) else None
     return FN.conv_bn_act(x, conv.weight, b.weight, b.bias, b.running_mean, b.running_var, conv.stride[0], conv.padding[0],
-                          relu, use_batch, 0.1 if b.momentum is None else b.momentum, b.eps, cout, cin)
+                          relu, use_batch, 0.1 if b.momentum is None else b.momentum, b.eps, cout, cin, nbt)
 
 
 def _conv_macs(h, w, c_in, c_out, k):
@@ -106,7 +108,7 @@ class ConvNorm(nn.Module):
     def set_ratio(self, ratio):
         assert self.slimmable
         assert len(ratio) == 2
-        self.ratio = ratio
+        self.__dict__['ratio'] = ratio      # plain attribute: skip nn.Module.__setattr__'s type dispatch
         self.conv[0].set_ratio(ratio)
         self.conv[1].set_ratio(ratio[1])
 
@@ -187,7 +189,7 @@ class _Residual(nn.Module):
 
     def set_ratio(self, ratio):
         assert len(ratio) == 2
-        self.ratio = ratio
+        self.__dict__['ratio'] = ratio      # plain attribute: skip nn.Module.__setattr__'s type dispatch
         self.conv1.set_ratio(ratio)
         self.bn1.set_ratio(ratio[1])
         if self.NUM_CONVS == 2:
@@ -299,7 +301,7 @@ class FactorizedReduce(nn.Module):
 
     def set_ratio(self, ratio):
         assert len(ratio) == 2
-        self.ratio = ratio
+        self.__dict__['ratio'] = ratio      # plain attribute: skip nn.Module.__setattr__'s type dispatch
         if self.stride == 1:
             self.conv1.set_ratio(ratio)
             self.bn.set_ratio(ratio[1])

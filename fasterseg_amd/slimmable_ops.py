@@ -35,14 +35,15 @@ class USConv2d(tnn.Conv2d):
         self.ratio = (1., 1.)
 
     def set_ratio(self, ratio):
-        self.ratio = ratio
+        self.__dict__['ratio'] = ratio      # plain attribute: skip nn.Module.__setattr__'s type dispatch
 
     def active_channels(self):
         """(out', in') for the current ratio; same membership asserts as slimmable_ops.py:37-40."""
         assert self.ratio[0] in self.width_mult_list, str(self.ratio[0]) + " in? " + str(self.width_mult_list)
         assert self.ratio[1] in self.width_mult_list, str(self.ratio[1]) + " in? " + str(self.width_mult_list)
-        self.in_channels = make_divisible(self.in_channels_max * self.ratio[0])
-        self.out_channels = make_divisible(self.out_channels_max * self.ratio[1])
+        d = self.__dict__
+        d['in_channels'] = make_divisible(self.in_channels_max * self.ratio[0])
+        d['out_channels'] = make_divisible(self.out_channels_max * self.ratio[1])
         return self.out_channels, self.in_channels
 
     def forward(self, x):
@@ -65,7 +66,7 @@ class USBatchNorm2d(tnn.BatchNorm2d):
         self.ratio = 1.
 
     def set_ratio(self, ratio):
-        self.ratio = ratio
+        self.__dict__['ratio'] = ratio      # plain attribute: skip nn.Module.__setattr__'s type dispatch
 
     def active(self):
         assert self.ratio in self.width_mult_list

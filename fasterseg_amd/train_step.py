@@ -20,8 +20,10 @@ from .parallel import FlatGradientSync, broadcast_parameters
 
 class StudentDistillStep:
     def __init__(self, batch, height, width, lr=0.01, momentum=0.9, weight_decay=5e-4, teacher_engine_dtype=None, seed=12345,
-                 device="cuda"):
+                 device="cuda", compute_dtype=torch.float32):
         self.device = torch.device(device)
+        self.compute_dtype = compute_dtype      # activation storage / MFMA operand type; master weights, BN statistics,
+        # accumulators and gradients of parameters stay fp32
         self.teacher = archs.init_weight(archs.build_derived(0, training=True), seed).to(self.device).eval()
         self.student = archs.init_weight(archs.build_derived(1, training=True), seed + 1).to(self.device).train()
         broadcast_parameters(self.student)
@@ -43,9 +45,14 @@ class StudentDistillStep:
             return self.teacher(imgs)
 
     def step(self, imgs, target):
+        from . import functional as FN
         self.sync.prepare()
         t_logits = self.teacher_logits(imgs)
-        p8, p16, p32 = self.student(imgs)
+        FN.set_compute_dtype(self.compute_dtype)
+        try:
+            p8, p16, p32 = self.student(imgs)
+        finally:
+            FN.set_compute_dtype(torch.float32)
         loss = self.ohem(p8, target) + self.lamb * self.ohem(p16, target) + self.lamb * self.ohem(p32, target)
         loss = loss + distill_kl(p8, t_logits)
         loss.backward()
@@ -77,10 +84,11 @@ class SupernetStep:
     uses the host RNGs (np.random / torch CPU generator), seeded identically on every rank, so all ranks activate the
     same sub-network."""
 
-    def __init__(self, pretrain=True, cfg=SearchConfig, seed=12345, device="cuda", lut=None, use_graphs=None):
+    def __init__(self, pretrain=True, cfg=SearchConfig, seed=12345, device="cuda", lut=None, use_graphs=None,
+                 compute_dtype=torch.float32):
         import os
+        self.compute_dtype = compute_dtype
         self.use_graphs = bool(int(os.environ.get("FS_SUPERNET_GRAPHS", "1"))) if use_graphs is None else use_graphs
-        self.graph_modes = ("max", "min")
         self.graphs = None
         from . import model_search, operations
         from .architect import Architect
@@ -95,6 +103,11 @@ class SupernetStep:
         broadcast_parameters(self.model)
         arch_ids = {id(p) for group in self.model._arch_parameters for p in group}
         self.weights = [p for p in self.model.parameters() if id(p) not in arch_ids]      # train_search.py:94-98
+        # The weight step's backward also reaches alpha/beta/ratio in the reference, but those gradients are zeroed by
+        # the architect before it ever reads them (architect.py: optimizer.zero_grad() first); they are not computed here.
+        self.arch_params = [p for group in self.model._arch_parameters for p in group]
+        for p in self.arch_params:
+            p.requires_grad_(False)
         self.optimizer = torch.optim.SGD(self.weights, lr=cfg.lr, momentum=cfg.momentum, weight_decay=cfg.weight_decay)
         self.sync = FlatGradientSync(self.weights, bucket_mb=128)
         np.random.seed(seed)
@@ -107,66 +120,161 @@ class SupernetStep:
                                          arch_learning_rate=cfg.arch_learning_rate, latency_weight=cfg.latency_weight))
             self.architect = Architect(self.model, args, grad_sync=_allreduce_list)
 
-    # ---- hipGraph capture of the shape-static passes ("max" and "min" widths) ----------------------------------
-    def _capture(self, imgs, target):
-        """Forward + backward of one fixed-width supernet pass as a single hipGraph (gradients accumulate into the flat
-        buffer, BN running statistics update on replay).  ~25 k launches per pass collapse into one graph launch; the
-        two "random"-width passes of a pretrain step change shape every step and stay eager."""
-        self.static_imgs, self.static_target = imgs.clone(), target.clone()
-        self.graphs = {}
+    # ---- the passes of one `_loss` call ---------------------------------------------------------------------------
+    # A pass = (arch_idx to select or None to leave it, prun_mode); model_search.py `_loss` runs, in this order,
+    #   pretrain:  (., max) (., min) (., random) (., random)
+    #   search:    (0, None) (1, None) (., max) (., min)          None -> the arch's own mode: arch 0 "max", arch 1 "arch_ratio"
+    # Passes whose widths are fixed ("max"/"min") have static shapes: forward + backward are captured once into a hipGraph
+    # and replayed (~12 k launches -> one graph launch).  "random" / Gumbel "arch_ratio" passes change shape every step and
+    # stay eager.
+    def _specs(self):
+        if self.pretrain:
+            return [(None, "max"), (None, "min"), (None, "random"), (None, "random")]
+        return [(0, None), (1, None), (None, "max"), (None, "min")]
+
+    def _is_static(self, spec):
+        arch_idx, mode = spec
+        if mode is None:
+            mode = self.model._prun_modes[arch_idx]
+        return mode in ("max", "min")
+
+    def _select(self, spec):
+        arch_idx, mode = spec
+        if arch_idx is not None:
+            self.model.arch_idx = arch_idx
+        self.model.prun_mode = mode
+
+    def _run_pass(self, spec, imgs, target):
+        self._select(spec)
+        return sum(self.model._criterion(logit, target) for logit in self.model(imgs))
+
+    def _pass_loss(self, mode, imgs, target):
+        return self._run_pass((None, mode), imgs, target)
+
+    def _set_phase(self, phase):
+        """'w': network weights receive gradients, architecture parameters are frozen; 'a': the opposite.  The reference
+        computes both sets in both phases and throws one away (train_search.py:245 optimizer.zero_grad / architect.py:38)."""
+        for p in self.weights:
+            p.requires_grad_(phase == "w")
+        for p in self.arch_params:
+            p.requires_grad_(phase == "a")
+
+    def _zero_arch_grads(self):
+        for p in self.arch_params:          # persistent .grad tensors: captured AccumulateGrad nodes write into them
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            else:
+                p.grad.zero_()
+
+    def _capture_pass(self, phase, spec, side):
+        imgs, target = self.static[phase]
+
+        def fresh():
+            if phase == "w":
+                self.sync.prepare()
+            else:
+                self._zero_arch_grads()
+        fresh()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                      # warm-up on the capture stream (allocator, pack caches)
+            self._run_pass(spec, imgs, target).backward()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        fresh()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            loss = self._run_pass(spec, imgs, target)
+            loss.backward()
+        touched = self.sync.touched_indices() if phase == "w" else None
+        if phase == "w":
+            self.sync.sync()
+        return g, loss.detach(), touched
+
+    def _capture(self, batches):
+        """batches: {'w': (imgs, target)[, 'a': (imgs_search, target_search)]}."""
         try:        # the flat .grad views were created on the default stream; capture runs on a side stream by design
             torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         except AttributeError:
             pass
+        self.static = {ph: (i.clone(), t.clone()) for ph, (i, t) in batches.items()}
+        self.graphs = {}
         side = torch.cuda.Stream()
-        for mode in self.graph_modes:
-            self.sync.prepare()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):                      # warm-up on the capture stream (allocator, pack caches)
-                self._pass_loss(mode, self.static_imgs, self.static_target).backward()
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            self.sync.prepare()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                loss = self._pass_loss(mode, self.static_imgs, self.static_target)
-                loss.backward()
-            self.graphs[mode] = (g, loss.detach(), self.sync.touched_indices())
-            self.sync.sync()
+        state = (self.model.arch_idx, self.model.prun_mode)
+        for phase in self.static:
+            self._set_phase(phase)
+            for spec in self._specs():
+                self._select(spec)          # also for the eager passes: later ones inherit arch_idx from them
+                if self._is_static(spec) and (phase, spec) not in self.graphs:
+                    self.graphs[(phase, spec)] = self._capture_pass(phase, spec, side)
+        self.model.arch_idx, self.model.prun_mode = state
         torch.cuda.synchronize()
 
-    def _pass_loss(self, mode, imgs, target):
-        self.model.prun_mode = mode
-        return sum(self.model._criterion(logit, target) for logit in self.model(imgs))
-
-    def _graphed_pretrain_loss(self, imgs, target):
-        """`_loss(imgs, target, pretrain=True)` with the static passes replayed from graphs; same pass order as the reference
-        (max, min, random, random), gradients accumulated pass by pass (d(sum)/dw = sum of d/dw)."""
-        if self.graphs is None:
-            self._capture(imgs, target)
-            self.sync.prepare()
-        self.static_imgs.copy_(imgs)
-        self.static_target.copy_(target)
+    def _phase_loss(self, phase, imgs, target):
+        """All passes of `_loss(imgs, target)` with their backward; gradients accumulate pass by pass (d(sum)/dp = sum d/dp)."""
+        s_imgs, s_target = self.static[phase]
+        s_imgs.copy_(imgs)
+        s_target.copy_(target)
         total = 0
-        for mode in ("max", "min"):
-            g, loss, touched = self.graphs[mode]
-            g.replay()
-            self.sync.mark_touched(touched)
+        for spec in self._specs():
+            if self._is_static(spec):
+                g, loss, touched = self.graphs[(phase, spec)]
+                self._select(spec)
+                g.replay()
+                if touched is not None:
+                    self.sync.mark_touched(touched)
+            else:
+                loss = self._run_pass(spec, imgs, target)
+                loss.backward()
+                loss = loss.detach()
             total = total + loss
-        for _ in range(2):
-            loss = self._pass_loss("random", imgs, target)
-            loss.backward()
-            total = total + loss.detach()
         return total
 
+    def _graphed_pretrain_loss(self, imgs, target):
+        return self._phase_loss("w", imgs, target)
+
     def step(self, imgs, target, imgs_search=None, target_search=None):
-        if self.use_graphs and self.pretrain and self.architect is None:
-            self.sync.prepare()
-            loss = self._graphed_pretrain_loss(imgs, target)
-            self.sync.sync()
-            torch.nn.utils.clip_grad_norm_(self.weights, self.cfg.grad_clip)
-            self.optimizer.step()
-            return loss.detach() if torch.is_tensor(loss) else loss, None
+        from . import functional as FN
+        FN.set_compute_dtype(self.compute_dtype)
+        try:
+            if self.use_graphs:
+                return self._step_graphed(imgs, target, imgs_search, target_search)
+            return self._step_eager(imgs, target, imgs_search, target_search)
+        finally:
+            FN.set_compute_dtype(torch.float32)
+
+    def _step_graphed(self, imgs, target, imgs_search, target_search):
+        from . import kernels as K
+        if self.graphs is None:
+            batches = {"w": (imgs, target)}
+            if self.architect is not None:
+                batches["a"] = (imgs_search, target_search)
+            self._capture(batches)
+        loss_arch = None
+        if self.architect is not None:                       # Architect.step (architect.py:34-47), pass by pass
+            self._set_phase("a")
+            self._zero_arch_grads()
+            K.zero_pool.reset(imgs.device)
+            try:
+                loss_arch = self._phase_loss("a", imgs_search, target_search)
+                loss_latency = self.architect._latency_loss()
+                if torch.is_tensor(loss_latency):
+                    loss_latency.backward()
+                    loss_arch = loss_arch + loss_latency.detach()
+            finally:
+                K.zero_pool.stop()
+            if self.architect.grad_sync is not None:
+                self.architect.grad_sync(self.arch_params)
+            for optimizer in self.architect.optimizers:
+                optimizer.step()
+        self._set_phase("w")
+        self.sync.prepare()
+        loss = self._phase_loss("w", imgs, target)
+        self.sync.sync()
+        torch.nn.utils.clip_grad_norm_(self.weights, self.cfg.grad_clip)
+        self.optimizer.step()
+        return loss, loss_arch
+
+    def _step_eager(self, imgs, target, imgs_search=None, target_search=None):
         loss_arch = None
         if self.architect is not None:
             # The reference's architect backward also produces (and then discards: optimizer.zero_grad, train_search.py:245)
@@ -174,12 +282,11 @@ class SupernetStep:
             # step: no wgrad / BN-parameter gradient kernels run, the alpha/beta/ratio gradients are unchanged.
             for p in self.weights:
                 p.grad = None
-                p.requires_grad_(False)
+            self._set_phase("a")
             try:
                 loss_arch = self.architect.step(imgs, target, imgs_search, target_search)
             finally:
-                for p in self.weights:
-                    p.requires_grad_(True)
+                self._set_phase("w")
         self.sync.prepare()
         loss = self.model._loss(imgs, target, self.pretrain)
         loss.backward()
@@ -216,7 +323,7 @@ def bench_student_train(args, world, rank, barrier, max_over_ranks):
     batch = args.batch or 12
     H, W = (args.height, args.width) if (args.height, args.width) != (1024, 2048) else (512, 1024)   # config C4 crop
     eng_dtype = {"bf16": torch.bfloat16, "fp32": torch.float32}[args.dtype]
-    stepper = StudentDistillStep(batch, H, W, teacher_engine_dtype=eng_dtype)
+    stepper = StudentDistillStep(batch, H, W, teacher_engine_dtype=eng_dtype, compute_dtype=eng_dtype)
     imgs, target = synthetic_batch(batch, H, W, rank, "cuda")
     for _ in range(args.warmup):
         stepper.step(imgs, target)
@@ -231,7 +338,9 @@ def bench_student_train(args, world, rank, barrier, max_over_ranks):
         "metric": "supernet train-step images/sec @1024x2048 (1/2/4/8 GPU) + student fps",
         "value": round(ips, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "fp32 student (exact-fp32 MFMA); teacher engine %s" % args.dtype, "data": "synthetic",
+        "dtype": args.dtype, "data": "synthetic",
+        "precision": ("bf16 activations + bf16 MFMA, fp32 accumulate / BN statistics / master weights / parameter gradients"
+                      if args.dtype == "bf16" else "fp32 storage, exact-fp32 MFMA") + "; teacher engine %s" % args.dtype,
         "config": {"workload": "student KL-distillation train step (BASELINE configs[3]): %d x 3x%dx%d per GPU, teacher arch_0 eval "
                                "+ student arch_1 train (3 heads), OHEM-CE + KLDiv, SGD" % (batch, H, W),
                    "global_batch": world * batch, "parallelism": "dp%d, flat fp32 gradient bucket all-reduce (RCCL)" % world},
@@ -250,7 +359,7 @@ def bench_supernet(args, world, rank, barrier, max_over_ranks, pretrain):
         path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "latency_lut_1080ti.json")
         with open(path) as f:
             lut = json.load(f)      # the reference's shipped table until fasterseg_amd.latency_lookup_table regenerates it
-    stepper = SupernetStep(pretrain=pretrain, lut=lut)
+    stepper = SupernetStep(pretrain=pretrain, lut=lut, compute_dtype={"bf16": torch.bfloat16, "fp32": torch.float32}[args.dtype])
     g = torch.Generator().manual_seed(2000 + rank)
 
     def make():
@@ -274,7 +383,9 @@ def bench_supernet(args, world, rank, barrier, max_over_ranks, pretrain):
         "metric": "supernet train-step images/sec @1024x2048 (1/2/4/8 GPU) + student fps",
         "value": round(ips, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "fp32 (exact-fp32 MFMA)", "data": "synthetic",
+        "dtype": args.dtype, "data": "synthetic",
+        "precision": ("bf16 activations + bf16 MFMA, fp32 accumulate / BN statistics / master weights / parameter gradients"
+                      if args.dtype == "bf16" else "fp32 storage, exact-fp32 MFMA"),
         "config": {"workload": "%s: %d x 3x%dx%d per GPU, F12.L16, widths {4,6,8,10,12}/12, all 5 primitives per MixedOp, "
                                "fwd+bwd, clip 5, SGD" % (name, batch, H, W),
                    "global_batch": world * batch, "parallelism": "dp%d, flat fp32 gradient buckets all-reduced over RCCL" % world},

@@ -122,10 +122,11 @@ fs_status fs_bilinear_bwd_nchw(void* stream, const fs_resize_desc* d, const floa
 /* Replaces nn.BatchNorm2d in training mode (operations.py:39,80; slimmable_ops.py:58-70).
  * fs_bn_finalize turns (sum,sumsq) over `count` elements per channel into mean/invstd, the folded
  * scale = gamma*invstd, shift = beta-mean*scale, and updates running stats with `momentum`
- * (unbiased variance, as torch). */
+ * (unbiased variance, as torch).  `num_batches_tracked` (device int64, may be null) is incremented by one, as
+ * nn.BatchNorm2d.forward does in training mode. */
 fs_status fs_bn_finalize(void* stream, int C, long long count, const float* stats, const float* gamma,
                          const float* beta, float eps, float momentum, float* running_mean, float* running_var,
-                         float* mean, float* invstd, float* scale, float* shift);
+                         float* mean, float* invstd, float* scale, float* shift, long long* num_batches_tracked);
 /* y = relu?(x*scale[c]+shift[c]) over an NHWC tensor (in place allowed). */
 fs_status fs_affine_act(void* stream, long long pixels, int C, const void* x, int x_cs, const float* scale,
                         const float* shift, void* y, int y_cs, int dtype, int relu);
@@ -134,13 +135,37 @@ fs_status fs_affine_act(void* stream, long long pixels, int C, const void* x, in
 fs_status fs_channel_stats(void* stream, long long pixels, int C, const void* x, int x_cs, int dtype, float* stats);
 /* BN(+ReLU) backward, two passes.
  * pass 1: red[0..C)=sum(dz), red[C..2C)=sum(dz*xhat) where dz = dy * (y>0 if relu) and xhat=(x-mean)*invstd.
- * pass 2: dx = gamma*invstd*(dz - red0/count - xhat*red1/count). */
+ * pass 2: dx = gamma*invstd*(dz - red0/count - xhat*red1/count); when dgamma_acc/dbeta_acc are given (both or neither)
+ *         the pass also does dgamma_acc[c] += red[C+c], dbeta_acc[c] += red[c] (autograd's AccumulateGrad, fused). */
 fs_status fs_bn_bwd_reduce(void* stream, long long pixels, int C, const void* x, int x_cs, const void* dy, int dy_cs,
                            const void* y_out, int y_cs, const float* mean, const float* invstd, int dtype, int relu,
                            float* red);
 fs_status fs_bn_bwd_apply(void* stream, long long pixels, int C, const void* x, int x_cs, const void* dy, int dy_cs,
                           const void* y_out, int y_cs, const float* mean, const float* invstd, const float* gamma,
-                          const float* red, long long count, int dtype, int relu, void* dx, int dx_cs);
+                          const float* red, long long count, int dtype, int relu, void* dx, int dx_cs,
+                          float* dgamma_acc, float* dbeta_acc);
+
+/* --- train-mode fused units ------------------------------------------------------------------------ */
+/* One reference module = one host call (the supernet runs thousands of these per step on tiny maps, so the per-launch
+ * host cost matters more than the kernels).
+ * fs_conv_bn_act_train_fwd: conv -> BatchNorm(batch statistics) -> [ReLU if d->flags & FS_CONV_RELU]
+ *   (ConvNorm, search/operations.py:42-128; the conv+bn(+relu) pairs of BasicResidual*, :131-262).
+ *   z (raw conv output) and y (normalised output) are NHWC buffers with channel stride d->y_cs; `stats` is 2*Cout zeroed
+ *   floats of scratch; `saved` receives 4*Cout floats: mean, invstd, scale, shift (mean/invstd are needed by the
+ *   backward).  Running statistics and num_batches_tracked (both may be null) are updated as by nn.BatchNorm2d. */
+fs_status fs_conv_bn_act_train_fwd(void* stream, const fs_conv_desc* d, const void* x, const void* w_packed,
+                                   const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                   long long* num_batches_tracked, float eps, float momentum, float* stats, float* saved,
+                                   void* z, void* y);
+/* Backward of the same unit (replaces the autograd of F.conv2d + F.batch_norm + relu): given dy (channel stride dy_cs)
+ *   red[0..C) = dbeta, red[C..2C) = dgamma (red must be zeroed), optionally accumulated into dgamma_acc/dbeta_acc;
+ *   dz (dense NHWC, channel stride Cout) = gradient w.r.t. the conv output;
+ *   dw != null: weight gradient accumulated into a strided fp32 tensor (see fs_conv2d_wgrad_strided), needs x;
+ *   dx != null: data gradient (N,H,W,Cin) with channel stride dx_cs, needs w_flip = fs_pack_weight(flip=1). */
+fs_status fs_conv_bn_act_train_bwd(void* stream, const fs_conv_desc* d, const void* x, const void* w_flip, const void* z,
+                                   const void* y, const void* dy, int dy_cs, const float* saved, const float* gamma,
+                                   float* red, float* dgamma_acc, float* dbeta_acc, void* dz, float* dw, long long o_stride,
+                                   long long i_stride, long long t_stride, void* dx, int dx_cs);
 
 /* --- layout / copies ------------------------------------------------------------------------------ */
 /* NCHW contiguous fp32 <-> NHWC (dtype) with channel stride; C arbitrary (zero-fills up to c_pad on the way in). */
@@ -155,6 +180,20 @@ fs_status fs_axpy_channels(void* stream, long long pixels, int C, const void* x,
 /* full-tensor dot product sum(x*y) -> out[0] (+=), the gradient of a scalar architecture weight. */
 fs_status fs_dot(void* stream, long long pixels, int C, const void* x, int x_cs, const void* y, int y_cs, int dtype,
                  float* out);
+
+/* n-way mixing of the supernet (MixedOp: sum_k alpha_k * op_k(x), model_search.py:76-78; beta mixing :330-333), one
+ * launch each instead of n axpy/copy passes.  xs/x_cs/dxs/dx_cs are HOST arrays of n device pointers / channel
+ * strides, coef is a DEVICE array of n floats (architecture weights never leave the GPU).
+ *   fs_weighted_sum:      out = sum_k coef[k] * x_k
+ *   fs_weighted_sum_bwd:  dx_k = coef[k] * dy           (entries of dxs may be null: that operand needs no gradient)
+ *   fs_weighted_sum_dots: out[k] += <dy, x_k>            (gradient of coef; out must be zeroed) */
+#define FS_WSUM_MAX 8
+fs_status fs_weighted_sum(void* stream, long long pixels, int C, int n, const void* const* xs, const int* x_cs,
+                          const float* coef, void* out, int out_cs, int dtype);
+fs_status fs_weighted_sum_bwd(void* stream, long long pixels, int C, int n, const void* dy, int dy_cs, const float* coef,
+                              void* const* dxs, const int* dx_cs, int dtype);
+fs_status fs_weighted_sum_dots(void* stream, long long pixels, int C, int n, const void* dy, int dy_cs,
+                               const void* const* xs, const int* x_cs, int dtype, float* out);
 
 #ifdef __cplusplus
 }

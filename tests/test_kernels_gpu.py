@@ -293,6 +293,54 @@ def test_layout_copy_axpy_dot(dtype):
     assert abs(float(d) - float((x * y).sum())) < 1e-2 * float((x * y).abs().sum()) ** 0.5 + 1e-2
 
 
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("n", [1, 2, 5, 8])
+def test_weighted_sum_fwd_bwd_dots(dtype, n):
+    """fs_weighted_sum{,_bwd,_dots} against sum_k c_k x_k and its autograd (MixedOp mixing, model_search.py:76-78)."""
+    k = K()
+    shape = (2, 48, 5, 9)
+    xs = [q(rnd(*shape, seed=40 + i), dtype).requires_grad_(True) for i in range(n)]
+    coef = (rnd(n, seed=39) * 0.5).requires_grad_(True)
+    ref = sum(c * x for c, x in zip(coef, xs))
+    dy = q(rnd(*shape, seed=38), dtype)
+    ref.backward(dy)
+    xd = [k.to_nhwc(x.detach().cuda(), dtype) for x in xs]
+    cd = coef.detach().cuda()
+    out = k.weighted_sum(xd, cd)
+    check(out, ref, dtype, "weighted_sum")
+    dyd = k.to_nhwc(dy.cuda(), dtype)
+    need = [i % 3 != 1 for i in range(n)]
+    gxs = k.weighted_sum_bwd(dyd, cd, need)
+    for i in range(n):
+        if need[i]:
+            check(gxs[i], xs[i].grad, dtype, "weighted_sum dx%d" % i)
+        else:
+            assert gxs[i] is None
+    dots = k.weighted_sum_dots(dyd, xd).cpu()
+    scale = float(dy.pow(2).sum().sqrt()) * max(float(x.detach().pow(2).sum().sqrt()) for x in xs)
+    assert float((dots - coef.grad).abs().max()) < 1e-4 * scale + 1e-3
+
+
+def test_bn_finalize_counter_and_fused_param_grad_accumulation():
+    """num_batches_tracked is bumped by fs_bn_finalize; fs_bn_bwd_apply adds dgamma/dbeta into the given buffers."""
+    k = K()
+    N, C, H, W = 2, 32, 6, 10
+    z = rnd(N, C, H, W, seed=50)
+    zd = k.to_nhwc(z.cuda(), torch.float32)
+    gamma, beta = (rnd(C, seed=51).abs() + 0.5).cuda(), rnd(C, seed=52).cuda()
+    nbt = torch.tensor(7, dtype=torch.long, device="cuda")
+    stats = k.channel_stats(zd)
+    mean, invstd, scale, shift = k.bn_finalize(stats, N * H * W, gamma, beta, 1e-5, 0.1, None, None, nbt)
+    assert int(nbt) == 8
+    out = k.affine_act(zd, scale, shift, True)
+    dy = k.to_nhwc(rnd(N, C, H, W, seed=53).cuda(), torch.float32)
+    dz0, dg0, db0 = k.bn_backward(zd, dy, out, mean, invstd, gamma, True)
+    gacc, bacc = torch.full((C,), 2.0, device="cuda"), torch.full((C,), -1.0, device="cuda")
+    dz1, dg1, db1 = k.bn_backward(zd, dy, out, mean, invstd, gamma, True, gacc, bacc)
+    assert torch.equal(dz0, dz1)
+    assert torch.allclose(gacc, dg0 + 2.0, atol=1e-5) and torch.allclose(bacc, db0 - 1.0, atol=1e-5)
+
+
 def test_errors_are_raised_not_fatal():
     from fasterseg_amd._lib import FasterSegHipError
     k = K()

@@ -52,6 +52,36 @@ def test_graphed_supernet_step_equals_eager():
         assert rel < 2e-2, (k, rel)
 
 
+def _run_search(use_graphs, steps=2):
+    import json
+    import os
+    from fasterseg_amd.train_step import SupernetStep
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "latency_lut_1080ti.json")) as f:
+        lut = json.load(f)
+    st = SupernetStep(pretrain=False, cfg=SmallSearch, seed=11, use_graphs=use_graphs, lut=lut)
+    imgs, tgt = _batch()
+    imgs_s, tgt_s = imgs.flip(3).contiguous(), tgt.flip(2).contiguous()
+    init = [p.detach().cpu().clone() for p in st.arch_params]
+    np.random.seed(21)
+    torch.manual_seed(22)                      # Gumbel noise of the arch_ratio passes comes from the host generator
+    out = [st.step(imgs, tgt, imgs_s, tgt_s) for _ in range(steps)]
+    losses = [(float(a), float(b)) for a, b in out]
+    delta = torch.cat([(p.detach().cpu() - i).reshape(-1) for p, i in zip(st.arch_params, init)])
+    return losses, delta
+
+
+def test_graphed_search_step_equals_eager():
+    """Architecture step + weight step with the six fixed-width passes replayed from hipGraphs vs the plain eager
+    Architect.step / _loss sequence: same losses, same Adam updates of alpha/beta/ratio."""
+    eager_losses, eager_delta = _run_search(False)
+    graph_losses, graph_delta = _run_search(True)
+    for (a, la), (b, lb) in zip(eager_losses, graph_losses):
+        assert abs(a - b) <= 5e-3 * abs(a) and abs(la - lb) <= 5e-3 * abs(la), (eager_losses, graph_losses)
+    assert float(eager_delta.abs().max()) > 1e-4               # Adam moved the architecture parameters
+    differing = float(((eager_delta - graph_delta).abs() > 1e-4).float().mean())
+    assert differing < 0.05, differing
+
+
 def test_fused_weight_grad_accumulation_matches_autograd():
     """FlatGradientSync makes the wgrad kernel accumulate in place into [O][R][S][I]-stored .grad views; the result must equal
     the plain autograd path (fresh gradient tensors + accumulate)."""
