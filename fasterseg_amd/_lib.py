@@ -56,6 +56,7 @@ SIGNATURES = {
     "fs_weighted_sum": [c_vp, c_ll, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_int],
     "fs_weighted_sum_bwd": [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_int],
     "fs_weighted_sum_dots": [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_vp],
+    "fs_sgd_momentum_multi": [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_float, c_float, c_float],
 }
 _SPECIAL = {
     "fs_last_error": ([], ctypes.c_char_p),
@@ -63,6 +64,7 @@ _SPECIAL = {
     "fs_packed_weight_elems": ([c_int, c_int, c_int, c_int], c_ll),
     "fs_debug_force_conv_cfg": ([c_int], None),
     "fs_packed_weight_frag_elems": ([c_int, c_int, c_int], c_ll),
+    "fs_sgd_chunk_elems": ([], c_int),
 }
 ALL_SYMBOLS = sorted(list(SIGNATURES) + list(_SPECIAL))
 

@@ -80,7 +80,13 @@ def as_nhwc(x, dtype=None):
 # ---------------------------------------------------------------------------------------------------
 # packed-filter cache: re-pack only when the parameter changed (optimizer steps bump Tensor._version)
 # ---------------------------------------------------------------------------------------------------
-_pack_cache = {}     # id(parameter) -> (weakref to it, {"stamp": (ptr, version), key: packed})
+_pack_cache = {}     # id(parameter) -> (weakref to it, {"stamp": (ptr, version, epoch), key: packed})
+_weights_epoch = 0   # bumped by optimizers that update parameters without going through autograd's version counters
+
+
+def bump_weights_epoch():
+    global _weights_epoch
+    _weights_epoch += 1
 
 
 def _pack_entry(weight):
@@ -100,7 +106,7 @@ def packed_weight(weight, dtype, cout=None, cin=None, flip=False, rows=None):
     if weight.is_cuda and torch.cuda.is_current_stream_capturing():
         return K.pack_weight(weight.detach(), dtype, cout, cin, flip, rows)      # the pack becomes a node of the graph
     entry = _pack_entry(weight)
-    stamp = (weight.data_ptr(), weight._version)
+    stamp = (weight.data_ptr(), weight._version, _weights_epoch)
     if entry["stamp"] != stamp:
         entry.clear()
         entry["stamp"] = stamp

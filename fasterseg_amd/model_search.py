@@ -89,14 +89,31 @@ class MixedOp(nn.Module):
         return FN.weighted_sum([op(x) for op in self._ops], coef)
 
     def forward_latency(self, size, weights, ratios):
+        """sum_k latency_k * w_k * r_score0 * r_score1 (reference :80-93) as ONE dot product with a cached device vector of
+        the five LUT latencies instead of ten scalar kernels per MixedOp (~150 MixedOp visits per architecture step)."""
         ratio0, r_score0 = _width_and_score(ratios[0], self._width_mult_list)
         ratio1, r_score1 = _width_and_score(ratios[1], self._width_mult_list)
         self.set_prun_ratio((ratio0, ratio1))
-        result = 0
-        for w, op in zip(weights, self._ops):
+        lats = []
+        for op in self._ops:
             latency, size_out = op.forward_latency(size)
-            result = result + latency * w * r_score0 * r_score1
+            lats.append(float(latency))
+        if not torch.is_tensor(weights):
+            result = sum(latency * w for latency, w in zip(lats, weights))
+        else:
+            key = (tuple(lats), weights.device, weights.dtype)
+            vec = _latency_vectors.get(key)
+            if vec is None:
+                vec = _latency_vectors[key] = torch.tensor(lats, dtype=weights.dtype, device=weights.device)
+            result = torch.dot(vec, weights.reshape(-1))
+        if torch.is_tensor(r_score0) or r_score0 != 1.:
+            result = result * r_score0
+        if torch.is_tensor(r_score1) or r_score1 != 1.:
+            result = result * r_score1
         return result, size_out
+
+
+_latency_vectors = {}      # (five LUT latencies, device, dtype) -> device vector
 
 
 class Cell(nn.Module):

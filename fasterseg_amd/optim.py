@@ -1,0 +1,70 @@
+"""Optimizer step over the flat gradient buffer: `clip_grad_norm_` + `torch.optim.SGD(momentum, weight_decay).step()` for
+every parameter in ONE kernel launch (fs_sgd_momentum_multi).
+
+The supernet has ~40 k parameter tensors (252 M floats); torch's foreach SGD plus the clip cost ~105 ms of host and
+launch time per step, a fifth of the whole pretrain step, for what is a single streaming pass over 3 GB.  The gradients
+already sit in `FlatGradientSync.flat`; the momentum buffer mirrors it, and a static device-side table tells the kernel
+where each parameter lives.  Semantics are those of the reference's optimiser calls (search/train_search.py:94-98,248-250;
+train/train.py:173-176): global L2 norm over all gradients, scale = min(1, max_norm / (norm + 1e-6)), then
+buf = momentum*buf + (g + wd*p), p -= lr*buf; a parameter that received no gradient in a step is skipped entirely (torch
+skips grad=None parameters: no decay, no momentum update).
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from . import functional as FN
+from . import kernels as K
+
+_TENSOR = np.dtype([("p", "<u8"), ("g_off", "<i8"), ("numel", "<i8"), ("I", "<i4"), ("taps", "<i4")])     # fs_sgd_tensor
+
+
+class FlatSGD:
+    def __init__(self, sync, lr, momentum=0.9, weight_decay=0.0, max_norm=None):
+        self.sync = sync
+        self.lr, self.momentum, self.weight_decay, self.max_norm = lr, momentum, weight_decay, max_norm
+        params = sync.params
+        dev = sync.flat.device
+        if dev.type != "cuda":
+            raise RuntimeError("FlatSGD runs on the HIP kernels only (no CPU path)")
+        chunk = _lib.lib().fs_sgd_chunk_elems()
+        table = np.zeros(len(params), _TENSOR)
+        chunks = []
+        for i, p in enumerate(params):
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise ValueError("FlatSGD needs contiguous fp32 parameters")
+            I, taps = (p.shape[1], p.shape[2] * p.shape[3]) if p.dim() == 4 else (1, 1)
+            table[i] = (p.data_ptr(), sync.offsets[i], p.numel(), I, taps)
+            n = (p.numel() + chunk - 1) // chunk
+            chunks.append(np.stack([np.full(n, i, np.int32), np.arange(n, dtype=np.int32)], 1))
+        self._ptrs = [(i, params[i].data_ptr()) for i in range(0, len(params), 61)]
+        self.table = torch.from_numpy(table.view(np.uint8).copy()).to(dev)
+        self.chunks = torch.from_numpy(np.ascontiguousarray(np.concatenate(chunks))).to(dev)
+        self.momentum_buf = torch.zeros_like(sync.flat)
+        self.touched_dev = torch.ones(len(params), dtype=torch.uint8, device=dev)
+        self._last_touched = None
+        self.last_norm = None
+
+    def step(self):
+        """Call after `sync.sync()`.  Returns the global gradient norm (device scalar) when clipping, else None."""
+        sync = self.sync
+        for i, ptr in self._ptrs:          # parameters must not have been re-homed (.to(), .data = ...) since construction
+            if sync.params[i].data_ptr() != ptr:
+                raise RuntimeError("FlatSGD: parameter storage moved since the optimizer was built")
+        scale = None
+        self.last_norm = None
+        if self.max_norm is not None:
+            self.last_norm = sync.flat.norm()                 # slices of untouched parameters are zero
+            scale = torch.clamp(self.max_norm / (self.last_norm + 1e-6), max=1.0)
+        touched = sync._touched
+        if touched != self._last_touched:
+            self.touched_dev.copy_(torch.tensor(touched, dtype=torch.uint8))
+            self._last_touched = list(touched)
+        K.call("fs_sgd_momentum_multi", K._stream(), self.table.data_ptr(), self.chunks.data_ptr(), self.chunks.shape[0],
+               self.touched_dev.data_ptr(), sync.flat.data_ptr(), self.momentum_buf.data_ptr(),
+               scale.data_ptr() if scale is not None else None, float(self.lr), float(self.momentum), float(self.weight_decay))
+        FN.bump_weights_epoch()            # parameters changed behind autograd's version counters: drop packed copies
+        return self.last_norm
+
+    def zero_grad(self, set_to_none=True):
+        pass                                # FlatGradientSync.prepare() owns the gradient buffer

@@ -15,6 +15,7 @@ import torch
 
 from . import archs
 from .losses import ProbOhemCrossEntropy2d, distill_kl
+from .optim import FlatSGD
 from .parallel import FlatGradientSync, broadcast_parameters
 
 
@@ -30,8 +31,8 @@ class StudentDistillStep:
         broadcast_parameters(self.teacher)
         min_kept = int(batch * height * width // 16)                       # train/train.py:62 with gt_down_sampling = 1
         self.ohem = ProbOhemCrossEntropy2d(ignore_label=255, thresh=0.7, min_kept=min_kept, use_weight=False)
-        self.optimizer = torch.optim.SGD(self.student.parameters(), lr=lr, momentum=momentum, weight_decay=weight_decay)
         self.sync = FlatGradientSync(self.student.parameters(), bucket_mb=256)
+        self.optimizer = FlatSGD(self.sync, lr, momentum, weight_decay)           # train/train.py:173-176
         self.lamb = 0.2
         self.teacher_engine = None
         if teacher_engine_dtype is not None:        # frozen teacher through the static-plan engine (hipGraph)
@@ -108,8 +109,9 @@ class SupernetStep:
         self.arch_params = [p for group in self.model._arch_parameters for p in group]
         for p in self.arch_params:
             p.requires_grad_(False)
-        self.optimizer = torch.optim.SGD(self.weights, lr=cfg.lr, momentum=cfg.momentum, weight_decay=cfg.weight_decay)
         self.sync = FlatGradientSync(self.weights, bucket_mb=128)
+        # train_search.py:94-98 SGD + :249 clip_grad_norm_(5), one launch over the flat buffers
+        self.optimizer = FlatSGD(self.sync, cfg.lr, cfg.momentum, cfg.weight_decay, max_norm=cfg.grad_clip)
         np.random.seed(seed)
         torch.manual_seed(seed)
         self.architect = None
@@ -270,7 +272,6 @@ class SupernetStep:
         self.sync.prepare()
         loss = self._phase_loss("w", imgs, target)
         self.sync.sync()
-        torch.nn.utils.clip_grad_norm_(self.weights, self.cfg.grad_clip)
         self.optimizer.step()
         return loss, loss_arch
 
@@ -291,7 +292,6 @@ class SupernetStep:
         loss = self.model._loss(imgs, target, self.pretrain)
         loss.backward()
         self.sync.sync()
-        torch.nn.utils.clip_grad_norm_(self.weights, self.cfg.grad_clip)
         self.optimizer.step()
         return loss.detach(), loss_arch
 

@@ -195,6 +195,26 @@ fs_status fs_weighted_sum_bwd(void* stream, long long pixels, int C, int n, cons
 fs_status fs_weighted_sum_dots(void* stream, long long pixels, int C, int n, const void* dy, int dy_cs,
                                const void* const* xs, const int* x_cs, int dtype, float* out);
 
+/* --- optimizer step over the flat gradient buffer ------------------------------------------------- */
+/* clip_grad_norm_ scaling + SGD(momentum, weight_decay).step for ALL parameters in one launch (train_search.py:94-98,
+ * 248-250; train/train.py:173-176).  `tensors` is a DEVICE array describing each parameter: its storage (contiguous
+ * fp32, OIHW for filters), the offset of its slice in the flat gradient / momentum buffers, and for filters the [O][taps][I]
+ * order of that slice (taps = R*S, I = in-channels; taps = 1: same order as the parameter).  `chunks` is a DEVICE array of
+ * n_chunks (tensor index, chunk index) pairs, chunk = fs_sgd_chunk_elems() consecutive gradient elements.  touched[t]==0
+ * skips tensor t (a parameter that received no gradient is left alone, as torch does for grad=None).  grad_scale: device
+ * scalar multiplied into every gradient (the clip factor), may be null. */
+typedef struct fs_sgd_tensor {
+    float* p;
+    long long g_off;
+    long long numel;
+    int I;
+    int taps;
+} fs_sgd_tensor;
+int fs_sgd_chunk_elems(void);
+fs_status fs_sgd_momentum_multi(void* stream, const fs_sgd_tensor* tensors, const int* chunks, int n_chunks,
+                                const unsigned char* touched, const float* grads, float* momentum_buf,
+                                const float* grad_scale, float lr, float momentum, float weight_decay);
+
 #ifdef __cplusplus
 }
 #endif

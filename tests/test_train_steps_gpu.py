@@ -106,6 +106,39 @@ def test_fused_weight_grad_accumulation_matches_autograd():
     assert not bad, bad[:5]
 
 
+def test_flat_sgd_matches_torch_sgd_with_clip():
+    """fs_sgd_momentum_multi over the flat buffers == clip_grad_norm_ + torch.optim.SGD(momentum, weight_decay) fed the same
+    gradients, including parameters that receive no gradient (skipped) and the [O][R][S][I] gradient storage of filters."""
+    from fasterseg_amd import archs
+    from fasterseg_amd import functional as FN
+    from fasterseg_amd.optim import FlatSGD
+    from fasterseg_amd.parallel import FlatGradientSync
+    torch.manual_seed(1)
+    net = archs.init_weight(archs.build_derived(1, training=True), 5).cuda().train()
+    sync = FlatGradientSync(net.parameters())
+    opt = FlatSGD(sync, 0.05, 0.9, 5e-4, max_norm=0.5)
+    ref = [p.detach().clone().requires_grad_(True) for p in sync.params]
+    ref_opt = torch.optim.SGD(ref, lr=0.05, momentum=0.9, weight_decay=5e-4)
+    x = torch.randn(2, 3, 64, 128, device="cuda")
+    for step in range(3):
+        sync.prepare()
+        p8, p16, p32 = net(x)
+        (p8.square().mean() + p16.square().mean() + 3 * p32.square().mean()).backward()
+        sync.sync()
+        for r, p in zip(ref, sync.params):
+            r.grad = None if p.grad is None else p.grad.detach().clone().contiguous()
+        assert any(r.grad is None for r in ref)
+        norm_ref = torch.nn.utils.clip_grad_norm_(ref, 0.5)
+        ref_opt.step()
+        norm = opt.step()
+        assert abs(float(norm) - float(norm_ref)) <= 1e-4 * float(norm_ref)
+        assert float(norm_ref) > 0.5 or step > 0                 # the clip is active at least on the first step
+        worst = max(float((r.detach() - p.detach()).abs().max()) for r, p in zip(ref, sync.params))
+        assert worst < 2e-6, (step, worst)
+        w = net.stem[0].conv[0].weight
+        assert torch.equal(FN.packed_weight(w, torch.float32).reshape(w.shape[0], 3, 3, w.shape[1]), w.detach().permute(0, 2, 3, 1))
+
+
 def test_student_distill_step_runs_and_learns():
     from fasterseg_amd.train_step import StudentDistillStep, synthetic_batch
     st = StudentDistillStep(2, 128, 256, teacher_engine_dtype=torch.bfloat16)
