@@ -11,6 +11,8 @@ fs_axpy_channels pass per term with the scalar coefficient left on the device (i
 functional.scale_accumulate), and the `betas[..] > 0` tests that make the reference synchronise the GPU once per cell
 are evaluated once per forward.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -62,6 +64,48 @@ def _width_and_score(ratio, width_mult_list):
     return ratio, 1.
 
 
+# Inside a hipGraph capture the five primitives of a MixedOp (independent given x) are issued on separate HIP streams, so
+# the captured graph has five parallel chains per MixedOp instead of one: the supernet's kernels are a few microseconds on
+# a fraction of the CUs, and a replayed pass is bound by their serial latency, not by throughput.  autograd runs each
+# node's backward on the stream of its forward, so the backward graph forks and joins the same way.  Eager passes are
+# host-bound and stay on one stream.  FS_BRANCH_LANES=1 disables the fork.
+_BRANCH_LANES = int(os.environ.get("FS_BRANCH_LANES", "5"))
+_lane_pool = {}
+
+
+def branch_lanes(stream):
+    """Side streams that fork from `stream` (created on first use; call once BEFORE capturing on `stream`, stream creation
+    is not a capturable operation)."""
+    key = (stream.device, stream.cuda_stream)
+    lanes = _lane_pool.get(key)
+    if lanes is None:
+        lanes = _lane_pool[key] = [torch.cuda.Stream(device=stream.device) for _ in range(max(0, _BRANCH_LANES - 1))]
+    return lanes
+
+
+def _run_branches(ops, x):
+    main = torch.cuda.current_stream()
+    lanes = branch_lanes(main)
+    used = []
+    plan = []
+    for k, op in enumerate(ops):                  # branch 0 stays on the current stream, the others round-robin the lanes
+        lane = None if k == 0 else lanes[(k - 1) % len(lanes)]
+        if lane is not None and lane not in used:
+            lane.wait_stream(main)                # fork: every lane starts after x is ready
+            used.append(lane)
+        plan.append((op, lane))
+    outs = []
+    for op, lane in plan:
+        if lane is None:
+            outs.append(op(x))
+        else:
+            with torch.cuda.stream(lane):
+                outs.append(op(x))
+    for lane in used:
+        main.wait_stream(lane)                    # join before the weighted sum
+    return outs
+
+
 class MixedOp(nn.Module):
 
     def __init__(self, C_in, C_out, stride=1, width_mult_list=[1.]):
@@ -86,6 +130,8 @@ class MixedOp(nn.Module):
             coef = coef * r_score0
         if torch.is_tensor(r_score1):
             coef = coef * r_score1
+        if x.is_cuda and _BRANCH_LANES > 1 and torch.cuda.is_current_stream_capturing():
+            return FN.weighted_sum(_run_branches(self._ops, x), coef)
         return FN.weighted_sum([op(x) for op in self._ops], coef)
 
     def forward_latency(self, size, weights, ratios):

@@ -184,7 +184,7 @@ class SupernetStep:
         torch.cuda.synchronize()
         fresh()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, stream=side):
             loss = self._run_pass(spec, imgs, target)
             loss.backward()
         touched = self.sync.touched_indices() if phase == "w" else None
@@ -200,7 +200,9 @@ class SupernetStep:
             pass
         self.static = {ph: (i.clone(), t.clone()) for ph, (i, t) in batches.items()}
         self.graphs = {}
+        from . import model_search
         side = torch.cuda.Stream()
+        model_search.branch_lanes(side)           # MixedOp forks its five primitives onto these inside the capture
         state = (self.model.arch_idx, self.model.prun_mode)
         for phase in self.static:
             self._set_phase(phase)
