@@ -607,6 +607,55 @@ class _WeightedSum(torch.autograd.Function):
         return (gc,) + tuple(gxs)
 
 
+class _MixedOpProgram(torch.autograd.Function):
+    """A whole supernet MixedOp (five primitives + weighted sum) replayed from its pre-built launch programs
+    (fasterseg_amd.program): one FFI crossing and three arena allocations per direction instead of ~12 autograd nodes."""
+
+    @staticmethod
+    def forward(ctx, x, coef, prog):
+        c = coef.detach()
+        if c.dtype != torch.float32 or not c.is_contiguous():
+            c = c.float().contiguous()
+        dev = x.device
+        save = torch.empty(prog.save_bytes, dtype=torch.uint8, device=dev)
+        tmp = torch.empty(prog.tmpf_bytes, dtype=torch.uint8, device=dev)
+        N, C, H, W = prog.out_shape
+        out = torch.empty_strided((N, C, H, W), (H * W * C, 1, W * C, C), dtype=x.dtype, device=dev)
+        prog.run(prog.f_words, prog.f_n, prog.f_blob,
+                 (None, x.data_ptr(), c.data_ptr(), out.data_ptr(), save.data_ptr(), None, None, None, tmp.data_ptr()))
+        ctx.prog = prog
+        ctx.save_for_backward(x, c, save)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        prog = ctx.prog
+        x, c, save = ctx.saved_tensors
+        N, C, H, W = prog.out_shape
+        if not (K.is_nhwc(dy, x.dtype) and K.channel_stride(dy) == C):          # the program reads a dense gradient
+            dy = K.copy_channels(as_nhwc(dy, x.dtype), K.empty_nhwc(N, C, H, W, x.dtype, x.device))
+        tmp = torch.empty(prog.tmpb_bytes, dtype=torch.uint8, device=x.device)
+        gx = None
+        if prog.need_x:
+            n, ci, h, w = x.shape
+            gx = torch.empty_strided((n, ci, h, w), (h * w * ci, 1, w * ci, ci), dtype=x.dtype, device=x.device)
+        prog.run(prog.b_words, prog.b_n, prog.b_blob,
+                 (None, x.data_ptr(), c.data_ptr(), None, save.data_ptr(), dy.data_ptr(), tmp.data_ptr(),
+                  gx.data_ptr() if gx is not None else None, None))
+        if prog.touched:
+            sink = _grad_sink
+            for p in prog.touched:
+                sink.touched(p)
+        gc = None
+        if prog.need_coef:
+            gc = tmp[prog.gcoef_off:prog.gcoef_off + 4 * c.numel()].view(torch.float32).reshape(c.shape)
+        return gx, gc, None
+
+
+def mixed_op_program(x, coef, prog):
+    return _MixedOpProgram.apply(x, coef, prog)
+
+
 def weighted_sum(xs, coef):
     """sum_k coef[k] * xs[k] for NHWC feature maps and a device-resident coefficient vector (len(xs) <= 8)."""
     xs = [as_nhwc(t) for t in xs]

@@ -70,6 +70,9 @@ def _width_and_score(ratio, width_mult_list):
 # node's backward on the stream of its forward, so the backward graph forks and joins the same way.  Eager passes are
 # host-bound and stay on one stream.  FS_BRANCH_LANES=1 disables the fork.
 _BRANCH_LANES = int(os.environ.get("FS_BRANCH_LANES", "5"))
+# Eager training passes replay each MixedOp from pre-built launch programs (fasterseg_amd/program.py); FS_MIXEDOP_PROGRAMS=0
+# keeps the per-module autograd path.
+_PROGRAMS = bool(int(os.environ.get("FS_MIXEDOP_PROGRAMS", "1")))
 _lane_pool = {}
 
 
@@ -130,9 +133,34 @@ class MixedOp(nn.Module):
             coef = coef * r_score0
         if torch.is_tensor(r_score1):
             coef = coef * r_score1
-        if x.is_cuda and _BRANCH_LANES > 1 and torch.cuda.is_current_stream_capturing():
-            return FN.weighted_sum(_run_branches(self._ops, x), coef)
+        if x.is_cuda and torch.cuda.is_current_stream_capturing():
+            if _BRANCH_LANES > 1:
+                return FN.weighted_sum(_run_branches(self._ops, x), coef)
+        elif _PROGRAMS and self.training and x.is_cuda and torch.is_grad_enabled():
+            prog = self._program(FN.as_nhwc(x), coef, ratio0, ratio1)
+            if prog is not None:
+                return FN.mixed_op_program(FN.as_nhwc(x), coef, prog)
         return FN.weighted_sum([op(x) for op in self._ops], coef)
+
+    def _program(self, x, coef, ratio0, ratio1):
+        """The launch programs of this MixedOp for the current widths (built on first use), or None when the per-module
+        path must run: network weights that want gradients outside a FlatGradientSync backward, nothing to differentiate."""
+        w0 = self._ops[1].conv1.weight
+        want_w = w0.requires_grad
+        sink = FN._grad_sink if want_w else None
+        if want_w and (sink is None or w0.grad is None or not sink.accepts(w0)):
+            return None
+        need_x, need_coef = x.requires_grad, coef.requires_grad
+        if not (need_x or need_coef):
+            return None
+        key = (ratio0, ratio1, tuple(x.shape), x.stride(3), x.dtype, need_x, need_coef, want_w, id(sink))
+        cache = self.__dict__.setdefault("_programs", {})
+        prog = cache.get(key)
+        if prog is None or not prog.valid():
+            from . import program
+            prog = cache[key] = program.lower_mixed_op(self, tuple(x.shape), x.stride(3), x.dtype, x.device, need_x, need_coef,
+                                                       want_w, sink)
+        return prog
 
     def forward_latency(self, size, weights, ratios):
         """sum_k latency_k * w_k * r_score0 * r_score1 (reference :80-93) as ONE dot product with a cached device vector of

@@ -1,0 +1,392 @@
+"""Relocatable launch programs for the supernet's MixedOp (reference search/model_search.py:46-99), replayed by
+fs_exec_program (csrc/program.hip) from one FFI call.
+
+Why: an eager supernet pass is ~12 k launches of a few microseconds.  Issued module by module from Python (one autograd
+node, four allocations and one FFI crossing per conv->BN->ReLU) the host needs ~35 us per module; the kernels ~10.  For
+given widths a MixedOp is a FIXED sequence - five primitives (skip / conv / conv_downup / conv_2x / conv_2x_downup,
+operations.py:131-534) and the alpha-weighted sum - so it is lowered once per (MixedOp, widths, input geometry, which
+gradients are wanted) into two command lists, forward and backward, whose pointers are (slot, offset) pairs:
+
+    slot 0  absolute   parameters, BN buffers, slices of the flat gradient buffer (never move)
+    slot 1  X          the input feature map             slot 5  DY    incoming gradient (dense NHWC)
+    slot 2  COEF       the 5 mixing coefficients         slot 6  TMPB  backward scratch (zero region first)
+    slot 3  OUT        the mixed output                  slot 7  GX    gradient w.r.t. X
+    slot 4  SAVE       activations kept for backward     slot 8  TMPF  forward scratch (zero region first)
+
+Per call the autograd Function (functional._MixedOpProgram) allocates three arenas and the output and crosses the FFI once
+per direction.  The per-module path in functional.py computes exactly the same thing and remains the reference
+implementation of these programs (tests compare the two); it is also what runs under hipGraph capture and whenever a
+precondition below does not hold.
+"""
+import ctypes
+import struct
+
+import torch
+
+from . import _lib
+from . import kernels as K
+from ._lib import ConvDesc, ResizeDesc
+
+ABS, X, COEF, OUT, SAVE, DY, TMPB, GX, TMPF = range(9)
+N_SLOTS = 9
+_ALIGN = 256
+
+(OP_MEMSET, OP_PACK_WEIGHT, OP_CONV_FWD, OP_UNIT_FWD, OP_UNIT_BWD, OP_WGRAD_STRIDED, OP_CHANNEL_STATS, OP_BN_FINALIZE,
+ OP_AFFINE_ACT, OP_BN_BWD_REDUCE, OP_BN_BWD_APPLY, OP_BILINEAR_FWD, OP_BILINEAR_BWD, OP_WSUM, OP_WSUM_BWD, OP_WSUM_DOTS,
+ OP_AXPY) = range(17)      # enum in include/fasterseg_hip.h
+
+
+class Ref:
+    """A device address = slots[slot] + off.  Arena allocations carry their region ("z": zero-filled part at the start of
+    the arena, "p": the plain part behind it) until the list is finished and the size of the zero part is known."""
+    __slots__ = ("slot", "off", "region")
+
+    def __init__(self, slot, off, region=None):
+        self.slot, self.off, self.region = slot, off, region
+
+    def __add__(self, nbytes):
+        return Ref(self.slot, self.off + nbytes, self.region)
+
+
+NULL = Ref(ABS, 0)
+
+
+def absolute(t):
+    return NULL if t is None else Ref(ABS, t.data_ptr())
+
+
+class Buf:
+    """Symbolic NHWC feature map."""
+    __slots__ = ("ref", "N", "C", "H", "W", "cs", "esize")
+
+    def __init__(self, ref, N, C, H, W, cs, esize):
+        self.ref, self.N, self.C, self.H, self.W, self.cs, self.esize = ref, N, C, H, W, cs, esize
+
+    @property
+    def pixels(self):
+        return self.N * self.H * self.W
+
+    def channels(self, start, count):
+        return Buf(self.ref + start * self.esize, self.N, count, self.H, self.W, self.cs, self.esize)
+
+
+class _Desc:
+    def __init__(self, struct):
+        self.raw = bytes(struct)
+
+
+class _List:
+    """One direction (forward or backward) of a program."""
+
+    def __init__(self):
+        self.words = []
+        self.blob = bytearray()
+        self.sizes = {}             # arena slot -> [zeroed bytes, plain bytes]
+
+    def alloc(self, slot, nbytes, zero=False):
+        z = self.sizes.setdefault(slot, [0, 0])
+        nbytes = (nbytes + _ALIGN - 1) // _ALIGN * _ALIGN
+        k = 0 if zero else 1
+        off = z[k]
+        z[k] += nbytes
+        return Ref(slot, off, "z" if zero else "p")          # resolved in finish(): plain region follows the zero region
+
+    def emit(self, op, *args):
+        self.words.append((op, args))
+
+    def finish(self):
+        zero = {s: z[0] for s, z in self.sizes.items()}
+
+        def resolve(r):       # arenas of the other direction (SAVE seen from the backward list) have no zero region
+            return r.slot, r.off + (zero.get(r.slot, 0) if r.region == "p" else 0)
+        out = []
+        for slot, z in sorted(self.sizes.items()):
+            if z[0]:
+                out += [OP_MEMSET, 2, 2, slot, 0, 0, 0, z[0]]
+        for op, args in self.words:
+            out += [op, len(args)]
+            for a in args:
+                if isinstance(a, Ref):
+                    s, o = resolve(a)
+                    out += [2, s, o]
+                elif isinstance(a, _Desc):
+                    off = len(self.blob)
+                    self.blob += a.raw
+                    self.blob += b"\0" * (-len(self.blob) % 8)
+                    out += [3, 0, off]
+                elif isinstance(a, float):
+                    out += [1, 0, struct.unpack("<q", struct.pack("<d", a))[0]]
+                elif isinstance(a, (list, tuple)):
+                    if any(r is None or isinstance(r, Ref) for r in a):
+                        out += [4, len(a), 0]
+                        for r in a:
+                            if r is None:
+                                out += [0, -1]
+                            else:
+                                out += list(resolve(r))
+                    else:
+                        out += [5, len(a), 0] + [int(v) for v in a]
+                else:
+                    out += [0, 0, int(a)]
+        words = (ctypes.c_longlong * len(out))(*out)
+        blob = (ctypes.c_ubyte * max(1, len(self.blob))).from_buffer_copy(bytes(self.blob) or b"\0")
+        total = {s: z[0] + z[1] for s, z in self.sizes.items()}
+        return words, len(out), blob, total
+
+
+class MixedOpProgram:
+    """Forward + backward command lists of one MixedOp configuration."""
+
+    def __init__(self, fwd, bwd, out_shape, touched, need_x, need_coef, gcoef_off, guard):
+        assert fwd.sizes.get(SAVE, [0, 0])[0] == 0, "SAVE is addressed from both lists: it must not have a zero region"
+        self.f_words, self.f_n, self.f_blob, f_sizes = fwd.finish()
+        self.b_words, self.b_n, self.b_blob, b_sizes = bwd.finish()
+        self.save_bytes = max(_ALIGN, f_sizes.get(SAVE, 0))
+        self.tmpf_bytes = max(_ALIGN, f_sizes.get(TMPF, 0))
+        self.tmpb_bytes = max(_ALIGN, b_sizes.get(TMPB, 0))
+        self.out_shape = out_shape            # (N, C, H, W)
+        self.touched = touched                # parameters whose flat-gradient slices the backward writes
+        self.need_x, self.need_coef, self.gcoef_off = need_x, need_coef, gcoef_off
+        self.guard = guard[:2] + guard[-2:]   # (tensor, data_ptr) samples of the storage the program hard-codes
+        self.n_launches = (len(fwd.words), len(bwd.words))
+
+    def valid(self):
+        return all(t.data_ptr() == p for t, p in self.guard)
+
+    def run(self, words, n, blob, slots):
+        arr = (ctypes.c_void_p * N_SLOTS)(*slots)
+        K.call("fs_exec_program", K._stream(), words, n, blob, arr, N_SLOTS)
+
+
+# ---------------------------------------------------------------------------------------------------
+# lowering
+# ---------------------------------------------------------------------------------------------------
+class _Lowering:
+    def __init__(self, dtype, want_w, sink):
+        self.f, self.b = _List(), _List()
+        self.dtype = dtype
+        self.dt = K.dtype_code(dtype)
+        self.esize = 4 if dtype == torch.float32 else 2
+        self.want_w = want_w                  # network weights receive gradients (through the flat-buffer sink)
+        self.sink = sink
+        self.touched = []
+        self.guard = []
+        self.back = []                        # closures emitting the backward, run in reverse
+
+    # -- buffers -------------------------------------------------------------------------------------
+    def new(self, lst, slot, N, C, H, W):
+        return Buf(lst.alloc(slot, N * H * W * C * self.esize), N, C, H, W, C, self.esize)
+
+    def grad_slot(self, p, n=None):
+        """Address of p.grad inside the flat buffer (fused accumulation), asserting the sink owns it."""
+        g = p.grad
+        assert self.sink is not None and g is not None and self.sink.accepts(p), "parameter gradient is not a flat-buffer view"
+        self.guard.append((g, g.data_ptr()))
+        self.touched.append(p)
+        return g
+
+    def param(self, t):
+        self.guard.append((t, t.data_ptr()))
+        return absolute(t)
+
+    # -- one conv -> BN -> [ReLU] module -----------------------------------------------------------------
+    def unit(self, x, conv, bn, relu):
+        f = self.f
+        cout, cin = conv.active_channels()
+        b = bn.active()
+        assert b.training and b.track_running_stats and x.C == cin
+        w = conv.weight
+        R, S = w.shape[2], w.shape[3]
+        stride, pad = conv.stride[0], conv.padding[0]
+        assert w.stride(3) == 1 and w.stride(2) == S
+        Ho, Wo = (x.H + 2 * pad - R) // stride + 1, (x.W + 2 * pad - S) // stride + 1
+        desc = ConvDesc(x.N, x.H, x.W, cin, cout, R, S, stride, pad, Ho, Wo, x.cs, cout, self.dt, K.FS_CONV_RELU if relu else 0)
+        wp = f.alloc(TMPF, cout * R * S * cin * self.esize)
+        f.emit(OP_PACK_WEIGHT, self.param(w), w.stride(0), w.stride(1), cout, cin, R, S, self.dt, 0, wp)
+        stats = f.alloc(TMPF, 2 * cout * 4, zero=True)
+        saved = f.alloc(SAVE, 4 * cout * 4)
+        z = self.new(f, SAVE, x.N, cout, Ho, Wo)
+        y = self.new(f, SAVE, x.N, cout, Ho, Wo)
+        momentum = 0.1 if b.momentum is None else float(b.momentum)
+        f.emit(OP_UNIT_FWD, _Desc(desc), x.ref, wp, self.param(b.weight), self.param(b.bias), self.param(b.running_mean),
+               self.param(b.running_var), self.param(b.num_batches_tracked), float(b.eps), momentum, stats, saved, z.ref, y.ref)
+
+        def backward(dy, need_x):
+            bl = self.b
+            red = bl.alloc(TMPB, 2 * cout * 4, zero=True)
+            dz = self.new(bl, TMPB, x.N, cout, Ho, Wo)
+            wf = dx = None
+            if need_x:
+                wf = bl.alloc(TMPB, cout * R * S * cin * self.esize)
+                bl.emit(OP_PACK_WEIGHT, absolute(w), w.stride(0), w.stride(1), cout, cin, R, S, self.dt, 1, wf)
+                dx = self.new(bl, TMPB, x.N, cin, x.H, x.W)
+            if self.want_w:
+                g = self.grad_slot(w)
+                assert g.stride(2) == S * g.stride(3)
+                gg, gb = self.grad_slot(b.weight), self.grad_slot(b.bias)
+                dw = (absolute(g), g.stride(0), g.stride(1), g.stride(3))
+                acc = (absolute(gg), absolute(gb))
+            else:
+                dw, acc = (NULL, 0, 0, 0), (NULL, NULL)
+            bl.emit(OP_UNIT_BWD, _Desc(desc), x.ref, wf or NULL, z.ref, y.ref if relu else NULL, dy.ref, dy.cs, saved,
+                    absolute(b.weight), red, acc[0], acc[1], dz.ref, dw[0], dw[1], dw[2], dw[3], dx.ref if need_x else NULL,
+                    cin)
+            return dx
+        return y, backward
+
+    # -- bilinear resize (align_corners=True) --------------------------------------------------------
+    def resize(self, x, Ho, Wo, relu):
+        f = self.f
+        y = self.new(f, SAVE, x.N, x.C, Ho, Wo)
+        f.emit(OP_BILINEAR_FWD, _Desc(ResizeDesc(x.N, x.H, x.W, Ho, Wo, x.C, x.cs, y.cs, self.dt, int(relu), 0)), x.ref, y.ref)
+
+        def backward(dy, need_x):
+            if not need_x:
+                return None
+            bl = self.b
+            if relu and dy.cs != y.cs:
+                raise NotImplementedError("strided gradient into a ReLU-fused resize")
+            dx = self.new(bl, TMPB, x.N, x.C, x.H, x.W)
+            bl.emit(OP_BILINEAR_BWD, _Desc(ResizeDesc(x.N, x.H, x.W, Ho, Wo, x.C, dx.cs, dy.cs, self.dt, int(relu), 0)), dy.ref,
+                    y.ref if relu else NULL, dx.ref)
+            return dx
+        return y, backward
+
+    # -- 'skip' with stride 2: FactorizedReduce (operations.py:521-526) -------------------------------
+    def factorized_reduce(self, x, op):
+        f = self.f
+        half, cin = op.conv1.active_channels()
+        assert op.conv2.active_channels() == (half, cin) and x.C == cin and x.H % 2 == 0 and x.W % 2 == 0
+        b = op.bn.active()
+        assert b.training and b.track_running_stats
+        C2 = 2 * half
+        Ho, Wo = x.H // 2, x.W // 2
+        z = self.new(f, SAVE, x.N, C2, Ho, Wo)
+        y = self.new(f, SAVE, x.N, C2, Ho, Wo)
+        descs = []
+        for k, (conv, pad) in enumerate(((op.conv1, 0), (op.conv2, -1))):
+            w = conv.weight
+            wp = f.alloc(TMPF, half * cin * self.esize)
+            f.emit(OP_PACK_WEIGHT, self.param(w), w.stride(0), w.stride(1), half, cin, 1, 1, self.dt, 0, wp)
+            d = ConvDesc(x.N, x.H, x.W, cin, half, 1, 1, 2, pad, Ho, Wo, x.cs, C2, self.dt, 0)
+            descs.append(d)
+            f.emit(OP_CONV_FWD, _Desc(d), x.ref, wp, NULL, NULL, z.ref + k * half * self.esize, NULL)
+        stats = f.alloc(TMPF, 2 * C2 * 4, zero=True)
+        saved = f.alloc(SAVE, 4 * C2 * 4)
+        momentum = 0.1 if b.momentum is None else float(b.momentum)
+        f.emit(OP_CHANNEL_STATS, z.pixels, C2, z.ref, z.cs, self.dt, stats)
+        f.emit(OP_BN_FINALIZE, C2, z.pixels, stats, self.param(b.weight), self.param(b.bias), float(b.eps), momentum,
+               self.param(b.running_mean), self.param(b.running_var), saved, saved + 4 * C2, saved + 8 * C2, saved + 12 * C2,
+               self.param(b.num_batches_tracked))
+        f.emit(OP_AFFINE_ACT, z.pixels, C2, z.ref, z.cs, saved + 8 * C2, saved + 12 * C2, y.ref, y.cs, self.dt, 1)
+
+        def backward(dy, need_x):
+            bl = self.b
+            red = bl.alloc(TMPB, 2 * C2 * 4, zero=True)
+            dz = self.new(bl, TMPB, x.N, C2, Ho, Wo)
+            acc = (absolute(self.grad_slot(b.weight)), absolute(self.grad_slot(b.bias))) if self.want_w else (NULL, NULL)
+            bl.emit(OP_BN_BWD_REDUCE, z.pixels, C2, z.ref, z.cs, dy.ref, dy.cs, y.ref, y.cs, saved, saved + 4 * C2, self.dt, 1, red)
+            bl.emit(OP_BN_BWD_APPLY, z.pixels, C2, z.ref, z.cs, dy.ref, dy.cs, y.ref, y.cs, saved, saved + 4 * C2,
+                    absolute(b.weight), red, z.pixels, self.dt, 1, dz.ref, dz.cs, acc[0], acc[1])
+            dx = None
+            for k, conv in enumerate((op.conv1, op.conv2)):
+                w = conv.weight
+                dzk = dz.ref + k * half * self.esize
+                if self.want_w:
+                    g = self.grad_slot(w)
+                    bl.emit(OP_WGRAD_STRIDED, _Desc(descs[k]), x.ref, dzk, absolute(g), g.stride(0), g.stride(1), g.stride(3))
+                if need_x:
+                    wf = bl.alloc(TMPB, half * cin * self.esize)
+                    bl.emit(OP_PACK_WEIGHT, absolute(w), w.stride(0), w.stride(1), half, cin, 1, 1, self.dt, 1, wf)
+                    gk = self.new(bl, TMPB, x.N, cin, x.H, x.W)
+                    g = ConvDesc(x.N, Ho, Wo, half, cin, 1, 1, 1, 0 - descs[k].pad, x.H, x.W, C2, cin, self.dt, K.FS_CONV_TRANSPOSED)
+                    bl.emit(OP_CONV_FWD, _Desc(g), dzk, wf, NULL, NULL, gk.ref, NULL)
+                    if dx is None:
+                        dx = gk
+                    else:       # the second branch touches only odd (h, w): disjoint from the first one's even taps
+                        bl.emit(OP_AXPY, dx.pixels, cin, gk.ref, gk.cs, absolute(_ones(b.weight.device)), dx.ref, dx.cs, self.dt, 1)
+            return dx
+        return y, backward
+
+    # -- the five primitives ---------------------------------------------------------------------------
+    def primitive(self, x, op):
+        from .operations import FactorizedReduce, _Residual
+        steps = []
+        if isinstance(op, FactorizedReduce):
+            assert op.slimmable
+            if op.stride == 2:
+                y, bw = self.factorized_reduce(x, op)
+                steps.append(bw)
+            else:
+                y, bw = self.unit(x, op.conv1, op.bn, True)
+                steps.append(bw)
+        elif isinstance(op, _Residual):
+            assert op.slimmable
+            upsample = op.ZOOM and op.stride == 1
+            y = x
+            if op.ZOOM:
+                y, bw = self.resize(y, x.H // 2, x.W // 2, False)
+                steps.append(bw)
+            y, bw = self.unit(y, op.conv1, op.bn1, op.NUM_CONVS == 2 or not upsample)
+            steps.append(bw)
+            if op.NUM_CONVS == 2:
+                y, bw = self.unit(y, op.conv2, op.bn2, not upsample)
+                steps.append(bw)
+            if upsample:
+                y, bw = self.resize(y, x.H, x.W, True)
+                steps.append(bw)
+        else:
+            raise NotImplementedError(type(op).__name__)
+
+        def backward(dy, need_x):
+            for k in range(len(steps) - 1, -1, -1):
+                dy = steps[k](dy, need_x or k > 0)
+            return dy
+        return y, backward
+
+
+_one_vectors = {}
+
+
+def _ones(device):
+    key = str(device)
+    if key not in _one_vectors:
+        _one_vectors[key] = torch.ones(8, dtype=torch.float32, device=device)
+    return _one_vectors[key]
+
+
+def lower_mixed_op(mixed, x_shape, x_cs, dtype, device, need_x, need_coef, want_w, sink):
+    """Programs for `mixed` (ratios already set through set_prun_ratio) on an (N, C, H, W) NHWC input with channel stride x_cs."""
+    N, C, H, W = x_shape
+    lo = _Lowering(dtype, want_w, sink)
+    x = Buf(Ref(X, 0), N, C, H, W, x_cs, lo.esize)
+    outs, backs = [], []
+    for op in mixed._ops:
+        y, bw = lo.primitive(x, op)
+        outs.append(y)
+        backs.append(bw)
+    n = len(outs)
+    y0 = outs[0]
+    assert all((o.N, o.C, o.H, o.W) == (y0.N, y0.C, y0.H, y0.W) for o in outs)
+    lo.f.emit(OP_WSUM, y0.pixels, y0.C, n, [o.ref for o in outs], [o.cs for o in outs], Ref(COEF, 0), Ref(OUT, 0), y0.C, lo.dt)
+    # backward: dy -> the five branch gradients -> each primitive -> sum into GX
+    b = lo.b
+    dy = Buf(Ref(DY, 0), y0.N, y0.C, y0.H, y0.W, y0.C, lo.esize)
+    gcoef = None
+    if need_coef:
+        gcoef = b.alloc(TMPB, 4 * 8, zero=True)
+        b.emit(OP_WSUM_DOTS, dy.pixels, dy.C, n, dy.ref, dy.cs, [o.ref for o in outs], [o.cs for o in outs], lo.dt, gcoef)
+    gys = [lo.new(b, TMPB, y0.N, y0.C, y0.H, y0.W) for _ in range(n)]
+    b.emit(OP_WSUM_BWD, dy.pixels, dy.C, n, dy.ref, dy.cs, Ref(COEF, 0), [g.ref for g in gys], [g.cs for g in gys], lo.dt)
+    dxs = [backs[k](gys[k], need_x) for k in range(n)]
+    if need_x:
+        b.emit(OP_WSUM, x.pixels, C, n, [d.ref for d in dxs], [d.cs for d in dxs], absolute(_ones(device)), Ref(GX, 0), C, lo.dt)
+    gcoef_off = None
+    if gcoef is not None:
+        gcoef_off = gcoef.off             # the zero region starts the arena
+    touched, seen = [], set()
+    for p in lo.touched:
+        if id(p) not in seen:
+            seen.add(id(p))
+            touched.append(p)
+    return MixedOpProgram(lo.f, lo.b, (y0.N, y0.C, y0.H, y0.W), touched, need_x, need_coef, gcoef_off, lo.guard)

@@ -215,6 +215,36 @@ fs_status fs_sgd_momentum_multi(void* stream, const fs_sgd_tensor* tensors, cons
                                 const unsigned char* touched, const float* grads, float* momentum_buf,
                                 const float* grad_scale, float lr, float momentum, float weight_decay);
 
+/* --- command-list executor ------------------------------------------------------------------------ */
+/* Replays a pre-built sequence of the launches above from one host call (csrc/program.hip describes the word encoding).
+ * A supernet MixedOp (model_search.py:46-99) with given widths is a fixed sequence of ~60 launches forward and ~90
+ * backward; the host cost of issuing them one Python call at a time dominates the eager search passes.  Pointers in
+ * the program are (slot, byte offset) pairs resolved against `slots` (slot 0 must be NULL: absolute addresses of
+ * parameters); `blob` holds the fs_conv_desc / fs_resize_desc structs the commands reference.  Stops at the first
+ * failing command and returns its status. */
+enum {
+    FS_OP_MEMSET = 0,        /* (ptr, nbytes)                          zero-fill                       */
+    FS_OP_PACK_WEIGHT,       /* arguments of fs_pack_weight after `stream`, likewise below             */
+    FS_OP_CONV_FWD,
+    FS_OP_UNIT_FWD,          /* fs_conv_bn_act_train_fwd */
+    FS_OP_UNIT_BWD,          /* fs_conv_bn_act_train_bwd */
+    FS_OP_WGRAD_STRIDED,
+    FS_OP_CHANNEL_STATS,
+    FS_OP_BN_FINALIZE,
+    FS_OP_AFFINE_ACT,
+    FS_OP_BN_BWD_REDUCE,
+    FS_OP_BN_BWD_APPLY,
+    FS_OP_BILINEAR_FWD,
+    FS_OP_BILINEAR_BWD,
+    FS_OP_WSUM,
+    FS_OP_WSUM_BWD,
+    FS_OP_WSUM_DOTS,
+    FS_OP_AXPY,
+    FS_OP_COUNT
+};
+fs_status fs_exec_program(void* stream, const long long* words, long long n_words, const unsigned char* blob,
+                          void* const* slots, int n_slots);
+
 #ifdef __cplusplus
 }
 #endif

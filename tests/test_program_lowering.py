@@ -1,0 +1,103 @@
+"""Host-side checks of the MixedOp launch programs (fasterseg_amd/program.py): the lowering runs without a GPU (it only
+needs shapes, strides and addresses), so the command stream can be decoded here and checked against the executor's
+contract (csrc/program.hip): argument counts per op, every arena reference inside its arena, zero regions first.  The
+numerical equivalence with the per-module autograd path is a GPU test (tests/test_train_steps_gpu.py)."""
+import pytest
+import torch
+
+from fasterseg_amd import model_search, program
+from fasterseg_amd.parallel import FlatGradientSync
+
+NARGS = {program.OP_MEMSET: 2, program.OP_PACK_WEIGHT: 10, program.OP_CONV_FWD: 7, program.OP_UNIT_FWD: 14, program.OP_UNIT_BWD: 19,
+         program.OP_WGRAD_STRIDED: 7, program.OP_CHANNEL_STATS: 6, program.OP_BN_FINALIZE: 14, program.OP_AFFINE_ACT: 10,
+         program.OP_BN_BWD_REDUCE: 13, program.OP_BN_BWD_APPLY: 19, program.OP_BILINEAR_FWD: 3, program.OP_BILINEAR_BWD: 4,
+         program.OP_WSUM: 9, program.OP_WSUM_BWD: 9, program.OP_WSUM_DOTS: 9, program.OP_AXPY: 9}
+WIDTHS = [4. / 12, 6. / 12, 8. / 12, 10. / 12, 1.]
+
+
+def decode(words, n, sizes):
+    """-> list of (op, [args]); asserts structural validity."""
+    w = list(words[:n])
+    pos, cmds = 0, []
+    while pos < n:
+        op, nargs = w[pos], w[pos + 1]
+        pos += 2
+        assert op in NARGS and nargs == NARGS[op], (op, nargs)
+        args = []
+        for _ in range(nargs):
+            kind, s, v = w[pos:pos + 3]
+            pos += 3
+            if kind == 2:
+                assert 0 <= s < program.N_SLOTS
+                if s in sizes:
+                    assert 0 <= v < sizes[s], (op, s, v, sizes[s])
+                args.append(("ptr", s, v))
+            elif kind == 4:
+                arr = [(w[pos + 2 * j], w[pos + 2 * j + 1]) for j in range(s)]
+                pos += 2 * s
+                for sl, off in arr:
+                    assert (sl, off) == (0, -1) or sl not in sizes or 0 <= off < sizes[sl]
+                args.append(("ptrs", arr))
+            elif kind == 5:
+                args.append(("ints", w[pos:pos + s]))
+                pos += s
+            else:
+                assert kind in (0, 1, 3)
+                args.append((kind, v))
+        cmds.append((op, args))
+    assert pos == n
+    return cmds
+
+
+@pytest.mark.parametrize("stride", [1, 2])
+@pytest.mark.parametrize("want_w", [False, True])
+def test_mixed_op_lowering_structure(stride, want_w):
+    torch.manual_seed(0)
+    m = model_search.MixedOp(48, 48 * stride, stride=stride, width_mult_list=WIDTHS).train()
+    sync = None
+    if want_w:
+        sync = FlatGradientSync(m.parameters())
+        sync.prepare()
+    else:
+        for p in m.parameters():
+            p.requires_grad_(False)
+    m.set_prun_ratio((8. / 12, 10. / 12))
+    cin = 32
+    prog = program.lower_mixed_op(m, (2, cin, 16, 24), cin, torch.float32, torch.device("cpu"), need_x=True, need_coef=not want_w,
+                                  want_w=want_w, sink=sync)
+    cout = int(48 * stride * 10 / 12)
+    assert prog.out_shape == (2, cout, 16 // stride, 24 // stride)
+    fwd = decode(prog.f_words, prog.f_n, {program.SAVE: prog.save_bytes, program.TMPF: prog.tmpf_bytes})
+    bwd = decode(prog.b_words, prog.b_n, {program.SAVE: prog.save_bytes, program.TMPB: prog.tmpb_bytes})
+    f_ops, b_ops = [c[0] for c in fwd], [c[0] for c in bwd]
+    # forward: zero-fill first, one weighted sum last; 6 conv->BN units for stride 1 (skip 1x1, conv, downup, 2x conv_2x, 2x ...)
+    assert f_ops[0] == program.OP_MEMSET and f_ops[-1] == program.OP_WSUM
+    units = 7 if stride == 1 else 6            # stride 2: the skip is a FactorizedReduce (two plain convs + BN), no 1x1 unit
+    assert f_ops.count(program.OP_UNIT_FWD) == units and b_ops.count(program.OP_UNIT_BWD) == units
+    assert f_ops.count(program.OP_BILINEAR_FWD) == (4 if stride == 1 else 2)
+    assert f_ops.count(program.OP_CONV_FWD) == (0 if stride == 1 else 2)
+    assert b_ops.count(program.OP_WSUM_BWD) == 1 and b_ops[-1] == program.OP_WSUM
+    assert (program.OP_WSUM_DOTS in b_ops) == (not want_w)
+    if want_w:
+        names = {id(p) for p in prog.touched}
+        used = [p for n, p in m.named_parameters() if p.grad is not None]
+        assert len(prog.touched) == len(names) and len(names) > 0
+        assert all(sync.accepts(p) for p in prog.touched)
+        if stride == 2:
+            assert b_ops.count(program.OP_WGRAD_STRIDED) == 2
+    else:
+        assert prog.touched == []
+    assert prog.valid()
+
+
+def test_executor_rejects_malformed_programs():
+    """fs_exec_program validates before it launches: unknown ops / wrong arity are status codes, not crashes."""
+    import ctypes
+    from fasterseg_amd import _lib
+    lib = _lib.lib()
+    slots = (ctypes.c_void_p * program.N_SLOTS)()
+    blob = (ctypes.c_ubyte * 8)()
+    for words in ([999, 0], [program.OP_AFFINE_ACT, 1, 0, 0, 5], [program.OP_WSUM, 9]):
+        arr = (ctypes.c_longlong * len(words))(*words)
+        assert lib.fs_exec_program(None, arr, len(words), blob, slots, program.N_SLOTS) == 1     # FS_ERR_INVALID
+        assert b"fs_exec_program" in lib.fs_last_error()

@@ -106,6 +106,85 @@ def test_fused_weight_grad_accumulation_matches_autograd():
     assert not bad, bad[:5]
 
 
+WIDTHS = [4. / 12, 6. / 12, 8. / 12, 10. / 12, 1.]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("phase", ["w", "a"])
+@pytest.mark.parametrize("stride", [1, 2])
+def test_mixed_op_program_matches_module_path(stride, phase, dtype):
+    """The launch program of a MixedOp (fs_exec_program) against the per-module autograd path on the same inputs: output,
+    dx, d alpha, every parameter gradient (through the flat buffer) and the BN running statistics."""
+    import copy
+    from fasterseg_amd import kernels as K
+    from fasterseg_amd import model_search
+    from fasterseg_amd.parallel import FlatGradientSync
+    torch.manual_seed(3)
+    m = model_search.MixedOp(48, 48 * stride, stride=stride, width_mult_list=WIDTHS).cuda().train()
+    for p in m.parameters():
+        if p.dim() == 1:
+            p.data.uniform_(0.5, 1.5)
+    state0 = copy.deepcopy(m.state_dict())
+    sync = FlatGradientSync(m.parameters())
+    x0 = K.to_nhwc(torch.randn(2, 32, 16, 24, device="cuda"), dtype)
+    coef0 = torch.softmax(torch.randn(5, device="cuda"), 0)
+    dy0 = K.to_nhwc(torch.randn(2, 40 * stride, 16 // stride, 24 // stride, device="cuda"), dtype)
+    got = []
+    saved_flag = model_search._PROGRAMS
+    try:
+        for use_program in (False, True):
+            model_search._PROGRAMS = use_program
+            m.load_state_dict(state0)
+            for p in m.parameters():
+                p.requires_grad_(phase == "w")
+            if phase == "w":
+                sync.prepare()
+            x = x0.clone().requires_grad_(True)
+            coef = coef0.clone().requires_grad_(phase == "a")
+            out = m(x, coef, (8. / 12, 10. / 12))
+            assert (type(out.grad_fn).__name__ == "_MixedOpProgramBackward") == use_program
+            out.backward(dy0)
+            rec = {"out": out.detach().float().clone(), "dx": x.grad.float().clone()}
+            if phase == "a":
+                rec["dcoef"] = coef.grad.clone()
+            else:
+                sync.sync()
+                rec["flat"] = sync.flat.clone()
+                rec["touched"] = list(sync._touched)
+            rec["running"] = torch.cat([b.float().reshape(-1) for n, b in m.named_buffers()])
+            got.append(rec)
+    finally:
+        model_search._PROGRAMS = saved_flag
+        for p in m.parameters():
+            p.requires_grad_(True)
+    ref, new = got
+    tol = 2e-4 if dtype == torch.float32 else 3e-2
+    for k in ref:
+        if k == "touched":
+            assert ref[k] == new[k]
+            continue
+        rel = float((ref[k] - new[k]).norm() / (ref[k].norm() + 1e-12))
+        assert rel < tol, (k, rel)
+
+
+def test_supernet_step_with_programs_equals_module_path():
+    """Eager pretrain steps (all four passes, random widths included) with the MixedOp programs vs the per-module path."""
+    from fasterseg_amd import model_search
+    saved_flag = model_search._PROGRAMS
+    try:
+        model_search._PROGRAMS = False
+        ref_losses, ref_w = _run(False)
+        model_search._PROGRAMS = True
+        new_losses, new_w = _run(False)
+    finally:
+        model_search._PROGRAMS = saved_flag
+    for a, b in zip(ref_losses, new_losses):
+        assert abs(a - b) <= 5e-3 * abs(a), (ref_losses, new_losses)
+    for k in ref_w:
+        rel = float((ref_w[k] - new_w[k]).norm() / (ref_w[k].norm() + 1e-12))
+        assert rel < 2e-2, (k, rel)
+
+
 def test_flat_sgd_matches_torch_sgd_with_clip():
     """fs_sgd_momentum_multi over the flat buffers == clip_grad_norm_ + torch.optim.SGD(momentum, weight_decay) fed the same
     gradients, including parameters that receive no gradient (skipped) and the [O][R][S][I] gradient storage of filters."""
