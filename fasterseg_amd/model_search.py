@@ -53,13 +53,17 @@ def gumbel_softmax(logits, temperature=1, hard=False):
     y_hard.scatter_(1, ind.view(-1, 1), 1)
     y_hard = y_hard.view(*shape)
     # straight-through: forward one-hot, gradient of the soft sample
-    return (y_hard - y).detach() + y
+    out = (y_hard - y).detach() + y
+    out._fs_index_t = ind.reshape(-1)          # device-side arg-max, read back in one batch by sample_prun_ratio
+    return out
 
 
 def _width_and_score(ratio, width_mult_list):
     """int: force #channel; tensor: arch_ratio; float(<=1): force width (reference comment, model_search.py:61)."""
     if isinstance(ratio, torch.Tensor):
-        k = int(ratio.argmax())
+        k = getattr(ratio, "_fs_index", None)
+        if k is None:
+            k = int(ratio.argmax())            # one host sync; sample_prun_ratio pre-reads all of a forward's indices at once
         return width_mult_list[k], ratio[k]
     return ratio, 1.
 
@@ -308,8 +312,15 @@ class Network_Multi_Path(nn.Module):
         counts = (self._layers - 1, self._layers - 1, self._layers - 2)
         if mode == "arch_ratio":
             names = self._arch_names[self.arch_idx]["ratios"]
-            return [[gumbel_softmax(F.log_softmax(getattr(self, names[s])[layer], dim=-1), hard=True) for layer in range(counts[s])]
-                    for s in range(3)]
+            ratios = [[gumbel_softmax(F.log_softmax(getattr(self, names[s])[layer], dim=-1), hard=True) for layer in range(counts[s])]
+                      for s in range(3)]
+            # The reference reads `ratio.argmax()` on the host once per MixedOp (model_search.py:64-65): ~230 device syncs per
+            # forward, each draining the launch queue.  Read all sampled indices back in ONE transfer instead.
+            flat = [r for scale in ratios for r in scale]
+            if flat and flat[0].is_cuda and not torch.cuda.is_current_stream_capturing():
+                for r, k in zip(flat, torch.cat([r._fs_index_t for r in flat]).tolist()):
+                    r._fs_index = k
+            return ratios
         if mode == "random":      # same draw order as the reference: all of scale 0, then scale 1, then scale 2
             return [[np.random.choice(self._width_mult_list) for _ in range(counts[s])] for s in range(3)]
         w = self._width_mult_list[0] if mode == "min" else self._width_mult_list[-1]
