@@ -18,7 +18,7 @@ c_int, c_ll, c_float, c_vp = ctypes.c_int, ctypes.c_longlong, ctypes.c_float, ct
 
 class ConvDesc(ctypes.Structure):
     _fields_ = [(n, c_int) for n in ("N", "H", "W", "Cin", "Cout", "R", "S", "stride", "pad", "Ho", "Wo",
-                                     "x_cs", "y_cs", "dtype", "flags")]
+                                     "x_cs", "y_cs", "dtype", "flags", "w_os", "w_ts")]
 
 
 class ResizeDesc(ctypes.Structure):
@@ -47,7 +47,7 @@ SIGNATURES = {
     "fs_conv_bn_act_train_fwd": [c_vp, ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_float, c_float,
                                  c_vp, c_vp, c_vp, c_vp],
     "fs_conv_bn_act_train_bwd": [c_vp, ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp,
-                                 c_vp, c_vp, c_vp, c_ll, c_ll, c_ll, c_vp, c_int],
+                                 c_vp, c_vp, c_vp, c_ll, c_ll, c_ll, c_vp, c_int, c_int, c_int],
     "fs_nchw_to_nhwc": [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int],
     "fs_nhwc_to_nchw": [c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_int, c_vp],
     "fs_copy_channels": [c_vp, c_ll, c_int, c_vp, c_int, c_vp, c_int, c_int],
@@ -57,7 +57,7 @@ SIGNATURES = {
     "fs_weighted_sum_bwd": [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_int],
     "fs_weighted_sum_dots": [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_vp],
     "fs_exec_program": [c_vp, c_vp, c_ll, c_vp, c_vp, c_int],
-    "fs_sgd_momentum_multi": [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_float, c_float, c_float],
+    "fs_sgd_momentum_multi": [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_float, c_float, c_float, c_int, c_int],
 }
 _SPECIAL = {
     "fs_last_error": ([], ctypes.c_char_p),

@@ -36,6 +36,7 @@ struct ConvArgs {
     int flags;
     int tiles_n;
     unsigned cin_magic;   // ceil(2^32 / Cin): k / Cin == umulhi(k, cin_magic) for k < 2^16
+    int w_os, w_tgap;     // filter row stride (elements) and (tap stride - Cin): 0 gap = dense [Cout][R*S][Cin] pack
 };
 
 template <typename T> struct Mma;
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     for (int ps = 0; ps < B_PASS; ++ps) {
         const int n = n0 + ps * B_RPP + b_row;
         b_ok[ps] = n < p.Cout;
-        b_ptr[ps] = p.w + ((long long)(b_ok[ps] ? n : 0) * p.K) * sizeof(T);
+        b_ptr[ps] = p.w + ((long long)(b_ok[ps] ? n : 0) * p.w_os) * sizeof(T);
     }
     int bk[B_SUBS];
 #pragma unroll
@@ -167,11 +168,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
         for (int j = 0; j < B_SUBS; ++j) {
             const bool kvalid = bk[j] < p.K;
+            // a slice of a wider resident pack: taps are w_tgap elements further apart than Cin (0 for a dense pack)
+            const long long koff = bk[j] + (long long)__umulhi((unsigned)bk[j], p.cin_magic) * p.w_tgap;
 #pragma unroll
             for (int ps = 0; ps < B_PASS; ++ps) {
                 const bool ok = kvalid && b_ok[ps];
                 b_keep[ps][j] = ok ? 0xffffffffu : 0u;
-                b_reg[ps][j] = ldg16(ok ? b_ptr[ps] + (long long)bk[j] * sizeof(T) : p.w);
+                b_reg[ps][j] = ldg16(ok ? b_ptr[ps] + koff * (long long)sizeof(T) : p.w);
             }
             bk[j] += BKT;
         }
@@ -421,6 +424,13 @@ extern "C" fs_status fs_conv2d_fwd(void* stream, const fs_conv_desc* d, const vo
     a.flags = d->flags;
     a.tiles_n = 1;
     a.cin_magic = (unsigned)(((1ull << 32) + (unsigned)d->Cin - 1) / (unsigned)d->Cin);
+    if (d->w_os == 0 && d->w_ts == 0) {
+        a.w_os = a.K; a.w_tgap = 0;
+    } else {          // filter = leading block of a wider resident pack
+        FS_REQUIRE(d->w_ts >= d->Cin && d->w_os >= d->R * d->S * d->w_ts && d->w_ts % vec == 0 && d->w_os % vec == 0,
+                   FS_ERR_INVALID, "fs_conv2d_fwd: filter strides (%d,%d) invalid for Cin=%d", d->w_os, d->w_ts, d->Cin);
+        a.w_os = d->w_os; a.w_tgap = d->w_ts - d->Cin;
+    }
     // 16-byte epilogue stores need an aligned slice; otherwise every tile takes the element-wise path
     if (!(aligned16(y) && (d->y_cs % vec == 0))) a.flags |= CONV_SCALAR_STORE;
     if (d->dtype == FS_F32) dispatch<float>((hipStream_t)stream, a, g_force_cfg);

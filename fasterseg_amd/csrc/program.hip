@@ -116,9 +116,10 @@ extern "C" fs_status fs_exec_program(void* stream, const long long* words, long 
                                               (long long*)P(7), F(8), F(9), PF(10), PF(11), P(12), P(13));
                 break;
             case FS_OP_UNIT_BWD:
-                NEED(19);
+                NEED(21);
                 st = fs_conv_bn_act_train_bwd(stream, (const fs_conv_desc*)P(0), P(1), P(2), P(3), P(4), P(5), I(6), PF(7), PF(8),
-                                              PF(9), PF(10), PF(11), P(12), PF(13), L(14), L(15), L(16), P(17), I(18));
+                                              PF(9), PF(10), PF(11), P(12), PF(13), L(14), L(15), L(16), P(17), I(18), I(19),
+                                              I(20));
                 break;
             case FS_OP_WGRAD_STRIDED:
                 NEED(7);

@@ -30,7 +30,7 @@ extern "C" fs_status fs_conv_bn_act_train_bwd(void* stream, const fs_conv_desc* 
                                               const void* z, const void* y, const void* dy, int dy_cs, const float* saved,
                                               const float* gamma, float* red, float* dgamma_acc, float* dbeta_acc,
                                               void* dz, float* dw, long long o_stride, long long i_stride,
-                                              long long t_stride, void* dx, int dx_cs) {
+                                              long long t_stride, void* dx, int dx_cs, int wf_os, int wf_ts) {
     FS_REQUIRE(d && z && dy && saved && gamma && red && dz, FS_ERR_INVALID, "fs_conv_bn_act_train_bwd: null argument");
     const int relu = (d->flags & FS_CONV_RELU) ? 1 : 0;
     FS_REQUIRE(!relu || y, FS_ERR_INVALID, "fs_conv_bn_act_train_bwd: ReLU unit needs its output y");
@@ -54,7 +54,8 @@ extern "C" fs_status fs_conv_bn_act_train_bwd(void* stream, const fs_conv_desc* 
     if (dx) {
         // data gradient = conv of dz with the 180-degree-rotated, IO-transposed filter (zero insertion for stride 2)
         FS_REQUIRE(w_flip, FS_ERR_INVALID, "fs_conv_bn_act_train_bwd: data gradient needs the flipped filter pack");
-        fs_conv_desc g;
+        fs_conv_desc g = {};
+        g.w_os = wf_os; g.w_ts = wf_ts;          // 0,0: dense flipped pack; else a block of a resident [Cin][R][S][Cout] pack
         g.N = d->N; g.H = d->Ho; g.W = d->Wo; g.Cin = d->Cout;
         g.Cout = d->Cin; g.R = d->R; g.S = d->S;
         g.stride = 1; g.pad = d->R - 1 - d->pad;

@@ -118,6 +118,31 @@ def packed_weight(weight, dtype, cout=None, cin=None, flip=False, rows=None):
     return hit
 
 
+# Resident packs: optim.FlatSGD keeps packed copies of every conv filter up to date inside its update kernel.  Train-mode
+# convs read the leading [:cout][..][:cin] block of them in place (fs_conv_desc.w_os / w_ts) - no fs_pack_weight launches.
+_resident = {}      # id(parameter) -> [weakref, fwd [O][R][S][I], flip [I][R][S][O], version at registration]
+
+
+def register_resident_pack(param, fwd, flip):
+    k = id(param)
+    _resident[k] = [weakref.ref(param, lambda _, k=k: _resident.pop(k, None)), fwd, flip, param._version]
+
+
+def revalidate_resident_pack(param):
+    e = _resident.get(id(param))
+    if e is not None and e[0]() is param:
+        e[3] = param._version
+
+
+def resident_pack(param, dtype):
+    """(fwd pack, flipped pack) of the FULL filter in `dtype`, or None when there is none or the parameter was modified behind
+    the optimizer's back (in-place ops bump Tensor._version; FlatSGD's own updates rewrite the packs and do not)."""
+    e = _resident.get(id(param))
+    if e is None or e[1].dtype != dtype or e[3] != param._version or e[0]() is not param:
+        return None
+    return e[1], e[2]
+
+
 def fold_bn(gamma, beta, running_mean, running_var, eps):
     """eval-mode BatchNorm as per-channel scale/shift (C-length vectors; plumbing, not on the pixel path)."""
     scale = gamma.detach().float() * torch.rsqrt(running_var.float() + eps)
@@ -179,8 +204,8 @@ class _ConvBNAct(torch.autograd.Function):
         stride, pad, relu, training, momentum, eps, cout, cin = cfg
         R, S = weight.shape[2], weight.shape[3]
         assert x.shape[1] == cin, "input has %d channels, conv expects %d" % (x.shape[1], cin)
-        wp = packed_weight(weight, x.dtype, cout, cin)
         if not training:
+            wp = packed_weight(weight, x.dtype, cout, cin)
             scale, shift = fold_bn(gamma, beta, running_mean, running_var, eps)
             y = K.conv2d(x, wp, cout, R, S, stride, pad, scale, shift, relu)
             ctx.eval_mode = True
@@ -189,8 +214,13 @@ class _ConvBNAct(torch.autograd.Function):
         N, _, H, W = x.shape
         Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
         dtype, dev = x.dtype, x.device
+        rp = resident_pack(weight, dtype)
+        if rp is not None:          # leading block of the resident full-size pack, read in place
+            wp, w_os, w_ts = rp[0], R * S * weight.shape[1], weight.shape[1]
+        else:
+            wp, w_os, w_ts = packed_weight(weight, dtype, cout, cin), 0, 0
         d = K.ConvDesc(N, H, W, cin, cout, R, S, stride, pad, Ho, Wo, x.stride(3), cout, K.dtype_code(dtype),
-                       K.FS_CONV_RELU if relu else 0)
+                       K.FS_CONV_RELU if relu else 0, w_os, w_ts)
         strides = (Ho * Wo * cout, 1, Wo * cout, cout)
         z = torch.empty_strided((N, cout, Ho, Wo), strides, dtype=dtype, device=dev)
         y = torch.empty_strided((N, cout, Ho, Wo), strides, dtype=dtype, device=dev)
@@ -236,15 +266,20 @@ class _ConvBNAct(torch.autograd.Function):
             else:       # physically [O][R][S][I]: the kernel's atomics are then coalesced
                 gw = torch.zeros((weight.shape[0], R, S, weight.shape[1]), dtype=torch.float32, device=dev).permute(0, 3, 1, 2)
             wdst = wslot if wslot is not None else gw
-        wf = None
+        wf, wf_os, wf_ts = None, 0, 0
         if need_x:
-            wf = packed_weight(weight, dtype, cout, cin, flip=True)
+            rp = resident_pack(weight, dtype)
+            if rp is not None:
+                wf, wf_os, wf_ts = rp[1], R * S * weight.shape[0], weight.shape[0]
+            else:
+                wf = packed_weight(weight, dtype, cout, cin, flip=True)
             gx = torch.empty_strided(x.shape, (d.H * d.W * cin, 1, d.W * cin, cin), dtype=dtype, device=dev)
         K.call("fs_conv_bn_act_train_bwd", K._stream(), ctypes.byref(d), x.data_ptr(), wf.data_ptr() if need_x else None,
                z.data_ptr(), y.data_ptr() if relu else None, dy.data_ptr(), dy.stride(3), saved.data_ptr(), gamma.data_ptr(),
                red.data_ptr(), gslot.data_ptr() if gslot is not None else None, bslot.data_ptr() if bslot is not None else None,
                dz.data_ptr(), wdst.data_ptr() if need_w else None, wdst.stride(0) if need_w else 0,
-               wdst.stride(1) if need_w else 0, wdst.stride(3) if need_w else 0, gx.data_ptr() if need_x else None, cin)
+               wdst.stride(1) if need_w else 0, wdst.stride(3) if need_w else 0, gx.data_ptr() if need_x else None, cin,
+               wf_os, wf_ts)
         if wslot is not None:
             sink.touched(weight)
         dgamma, dbeta = red[cout:], red[:cout]

@@ -182,8 +182,9 @@ def conv_desc(x_shape, x_cs, cout, R, S, stride, pad, y_cs, dtype, flags=0, out_
 
 
 def conv2d(x, w_packed, cout, R, S, stride, pad, scale=None, shift=None, relu=False, out=None, stats=None,
-           transposed=False, out_hw=None):
-    """y = relu?(conv(x, w) * scale + shift); `out` may be a channel slice of a wider NHWC buffer."""
+           transposed=False, out_hw=None, w_strides=None):
+    """y = relu?(conv(x, w) * scale + shift); `out` may be a channel slice of a wider NHWC buffer.  w_strides = (row, tap)
+    element strides when the filter is the leading block of a wider packed bank."""
     x_cs = require_nhwc(x, "x")
     N, Cin, H, W = x.shape
     flags = (FS_CONV_RELU if relu else 0) | (FS_CONV_TRANSPOSED if transposed else 0)
@@ -194,6 +195,8 @@ def conv2d(x, w_packed, cout, R, S, stride, pad, scale=None, shift=None, relu=Fa
         assert tuple(out.shape) == (N, cout, d.Ho, d.Wo) and out.dtype == x.dtype, (tuple(out.shape), (N, cout, d.Ho, d.Wo))
     d.y_cs = channel_stride(out)
     assert d.y_cs is not None
+    if w_strides is not None:
+        d.w_os, d.w_ts = w_strides
     call("fs_conv2d_fwd", _stream(), ctypes.byref(d), _p(x), _p(w_packed), _p(scale), _p(shift), _p(out), _p(stats))
     return out
 

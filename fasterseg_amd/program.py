@@ -151,7 +151,7 @@ class MixedOpProgram:
         self.n_launches = (len(fwd.words), len(bwd.words))
 
     def valid(self):
-        return all(t.data_ptr() == p for t, p in self.guard)
+        return all(t.data_ptr() == p and (v is None or t._version == v) for t, p, v in self.guard)
 
     def run(self, words, n, blob, slots):
         arr = (ctypes.c_void_p * N_SLOTS)(*slots)
@@ -181,13 +181,29 @@ class _Lowering:
         """Address of p.grad inside the flat buffer (fused accumulation), asserting the sink owns it."""
         g = p.grad
         assert self.sink is not None and g is not None and self.sink.accepts(p), "parameter gradient is not a flat-buffer view"
-        self.guard.append((g, g.data_ptr()))
+        self.guard.append((g, g.data_ptr(), None))
         self.touched.append(p)
         return g
 
     def param(self, t):
-        self.guard.append((t, t.data_ptr()))
+        self.guard.append((t, t.data_ptr(), None))
         return absolute(t)
+
+    def filter(self, lst, slot, w, cout, cin, flip):
+        """Address + (row, tap) strides of the packed [:cout,:cin] filter block: the resident pack kept current by the
+        optimizer when there is one (no launch), else a fs_pack_weight into scratch."""
+        from . import functional as FN
+        O, I, R, S = w.shape
+        rp = FN.resident_pack(w, self.dtype)
+        if rp is not None:
+            self.guard.append((w, w.data_ptr(), w._version))       # resident packs go stale if the parameter is edited in place
+            lead = O if flip else I
+            return absolute(rp[1] if flip else rp[0]), R * S * lead, lead
+        assert w.stride(3) == 1 and w.stride(2) == S
+        self.guard.append((w, w.data_ptr(), None))
+        wp = lst.alloc(slot, cout * R * S * cin * self.esize)
+        lst.emit(OP_PACK_WEIGHT, absolute(w), w.stride(0), w.stride(1), cout, cin, R, S, self.dt, int(flip), wp)
+        return wp, 0, 0
 
     # -- one conv -> BN -> [ReLU] module -----------------------------------------------------------------
     def unit(self, x, conv, bn, relu):
@@ -198,11 +214,10 @@ class _Lowering:
         w = conv.weight
         R, S = w.shape[2], w.shape[3]
         stride, pad = conv.stride[0], conv.padding[0]
-        assert w.stride(3) == 1 and w.stride(2) == S
         Ho, Wo = (x.H + 2 * pad - R) // stride + 1, (x.W + 2 * pad - S) // stride + 1
-        desc = ConvDesc(x.N, x.H, x.W, cin, cout, R, S, stride, pad, Ho, Wo, x.cs, cout, self.dt, K.FS_CONV_RELU if relu else 0)
-        wp = f.alloc(TMPF, cout * R * S * cin * self.esize)
-        f.emit(OP_PACK_WEIGHT, self.param(w), w.stride(0), w.stride(1), cout, cin, R, S, self.dt, 0, wp)
+        wp, w_os, w_ts = self.filter(f, TMPF, w, cout, cin, False)
+        desc = ConvDesc(x.N, x.H, x.W, cin, cout, R, S, stride, pad, Ho, Wo, x.cs, cout, self.dt, K.FS_CONV_RELU if relu else 0,
+                        w_os, w_ts)
         stats = f.alloc(TMPF, 2 * cout * 4, zero=True)
         saved = f.alloc(SAVE, 4 * cout * 4)
         z = self.new(f, SAVE, x.N, cout, Ho, Wo)
@@ -215,10 +230,9 @@ class _Lowering:
             bl = self.b
             red = bl.alloc(TMPB, 2 * cout * 4, zero=True)
             dz = self.new(bl, TMPB, x.N, cout, Ho, Wo)
-            wf = dx = None
+            wf, wf_os, wf_ts, dx = None, 0, 0, None
             if need_x:
-                wf = bl.alloc(TMPB, cout * R * S * cin * self.esize)
-                bl.emit(OP_PACK_WEIGHT, absolute(w), w.stride(0), w.stride(1), cout, cin, R, S, self.dt, 1, wf)
+                wf, wf_os, wf_ts = self.filter(bl, TMPB, w, cout, cin, True)
                 dx = self.new(bl, TMPB, x.N, cin, x.H, x.W)
             if self.want_w:
                 g = self.grad_slot(w)
@@ -230,7 +244,7 @@ class _Lowering:
                 dw, acc = (NULL, 0, 0, 0), (NULL, NULL)
             bl.emit(OP_UNIT_BWD, _Desc(desc), x.ref, wf or NULL, z.ref, y.ref if relu else NULL, dy.ref, dy.cs, saved,
                     absolute(b.weight), red, acc[0], acc[1], dz.ref, dw[0], dw[1], dw[2], dw[3], dx.ref if need_x else NULL,
-                    cin)
+                    cin, wf_os, wf_ts)
             return dx
         return y, backward
 
@@ -266,9 +280,8 @@ class _Lowering:
         descs = []
         for k, (conv, pad) in enumerate(((op.conv1, 0), (op.conv2, -1))):
             w = conv.weight
-            wp = f.alloc(TMPF, half * cin * self.esize)
-            f.emit(OP_PACK_WEIGHT, self.param(w), w.stride(0), w.stride(1), half, cin, 1, 1, self.dt, 0, wp)
-            d = ConvDesc(x.N, x.H, x.W, cin, half, 1, 1, 2, pad, Ho, Wo, x.cs, C2, self.dt, 0)
+            wp, w_os, w_ts = self.filter(f, TMPF, w, half, cin, False)
+            d = ConvDesc(x.N, x.H, x.W, cin, half, 1, 1, 2, pad, Ho, Wo, x.cs, C2, self.dt, 0, w_os, w_ts)
             descs.append(d)
             f.emit(OP_CONV_FWD, _Desc(d), x.ref, wp, NULL, NULL, z.ref + k * half * self.esize, NULL)
         stats = f.alloc(TMPF, 2 * C2 * 4, zero=True)
@@ -296,10 +309,10 @@ class _Lowering:
                     g = self.grad_slot(w)
                     bl.emit(OP_WGRAD_STRIDED, _Desc(descs[k]), x.ref, dzk, absolute(g), g.stride(0), g.stride(1), g.stride(3))
                 if need_x:
-                    wf = bl.alloc(TMPB, half * cin * self.esize)
-                    bl.emit(OP_PACK_WEIGHT, absolute(w), w.stride(0), w.stride(1), half, cin, 1, 1, self.dt, 1, wf)
+                    wf, wf_os, wf_ts = self.filter(bl, TMPB, w, half, cin, True)
                     gk = self.new(bl, TMPB, x.N, cin, x.H, x.W)
-                    g = ConvDesc(x.N, Ho, Wo, half, cin, 1, 1, 1, 0 - descs[k].pad, x.H, x.W, C2, cin, self.dt, K.FS_CONV_TRANSPOSED)
+                    g = ConvDesc(x.N, Ho, Wo, half, cin, 1, 1, 1, 0 - descs[k].pad, x.H, x.W, C2, cin, self.dt, K.FS_CONV_TRANSPOSED,
+                                 wf_os, wf_ts)
                     bl.emit(OP_CONV_FWD, _Desc(g), dzk, wf, NULL, NULL, gk.ref, NULL)
                     if dx is None:
                         dx = gk

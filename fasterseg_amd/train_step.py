@@ -32,7 +32,7 @@ class StudentDistillStep:
         min_kept = int(batch * height * width // 16)                       # train/train.py:62 with gt_down_sampling = 1
         self.ohem = ProbOhemCrossEntropy2d(ignore_label=255, thresh=0.7, min_kept=min_kept, use_weight=False)
         self.sync = FlatGradientSync(self.student.parameters(), bucket_mb=256)
-        self.optimizer = FlatSGD(self.sync, lr, momentum, weight_decay)           # train/train.py:173-176
+        self.optimizer = FlatSGD(self.sync, lr, momentum, weight_decay, pack_dtype=compute_dtype)       # train/train.py:173-176
         self.lamb = 0.2
         self.teacher_engine = None
         if teacher_engine_dtype is not None:        # frozen teacher through the static-plan engine (hipGraph)
@@ -111,7 +111,8 @@ class SupernetStep:
             p.requires_grad_(False)
         self.sync = FlatGradientSync(self.weights, bucket_mb=128)
         # train_search.py:94-98 SGD + :249 clip_grad_norm_(5), one launch over the flat buffers
-        self.optimizer = FlatSGD(self.sync, cfg.lr, cfg.momentum, cfg.weight_decay, max_norm=cfg.grad_clip)
+        self.optimizer = FlatSGD(self.sync, cfg.lr, cfg.momentum, cfg.weight_decay, max_norm=cfg.grad_clip,
+                                 pack_dtype=compute_dtype)
         np.random.seed(seed)
         torch.manual_seed(seed)
         self.architect = None

@@ -45,6 +45,9 @@ typedef struct fs_conv_desc {
     int x_cs, y_cs;         /* channel strides (elements per pixel) of x and y buffers   */
     int dtype;              /* fs_dtype of x, w, y                                       */
     int flags;              /* FS_CONV_*                                                 */
+    int w_os, w_ts;         /* filter strides in elements: row (per output channel) and tap.  0,0 = the dense
+                               [Cout][R][S][Cin] pack; otherwise the filter is the leading [:Cout][..][:Cin] block of
+                               a wider resident pack (USConv2d slices read in place, slimmable_ops.py:42)         */
 } fs_conv_desc;
 
 typedef struct fs_resize_desc {
@@ -161,11 +164,12 @@ fs_status fs_conv_bn_act_train_fwd(void* stream, const fs_conv_desc* d, const vo
  *   red[0..C) = dbeta, red[C..2C) = dgamma (red must be zeroed), optionally accumulated into dgamma_acc/dbeta_acc;
  *   dz (dense NHWC, channel stride Cout) = gradient w.r.t. the conv output;
  *   dw != null: weight gradient accumulated into a strided fp32 tensor (see fs_conv2d_wgrad_strided), needs x;
- *   dx != null: data gradient (N,H,W,Cin) with channel stride dx_cs, needs w_flip = fs_pack_weight(flip=1). */
+ *   dx != null: data gradient (N,H,W,Cin) with channel stride dx_cs, needs w_flip = fs_pack_weight(flip=1), dense
+ *               (wf_os = wf_ts = 0) or the leading block of a wider flipped pack with those row / tap strides. */
 fs_status fs_conv_bn_act_train_bwd(void* stream, const fs_conv_desc* d, const void* x, const void* w_flip, const void* z,
                                    const void* y, const void* dy, int dy_cs, const float* saved, const float* gamma,
                                    float* red, float* dgamma_acc, float* dbeta_acc, void* dz, float* dw, long long o_stride,
-                                   long long i_stride, long long t_stride, void* dx, int dx_cs);
+                                   long long i_stride, long long t_stride, void* dx, int dx_cs, int wf_os, int wf_ts);
 
 /* --- layout / copies ------------------------------------------------------------------------------ */
 /* NCHW contiguous fp32 <-> NHWC (dtype) with channel stride; C arbitrary (zero-fills up to c_pad on the way in). */
@@ -202,18 +206,23 @@ fs_status fs_weighted_sum_dots(void* stream, long long pixels, int C, int n, con
  * order of that slice (taps = R*S, I = in-channels; taps = 1: same order as the parameter).  `chunks` is a DEVICE array of
  * n_chunks (tensor index, chunk index) pairs, chunk = fs_sgd_chunk_elems() consecutive gradient elements.  touched[t]==0
  * skips tensor t (a parameter that received no gradient is left alone, as torch does for grad=None).  grad_scale: device
- * scalar multiplied into every gradient (the clip factor), may be null. */
+ * scalar multiplied into every gradient (the clip factor), may be null.
+ * Resident packs: the same pass rewrites the packed filter copies the conv kernels read (fs_conv_desc.w_os/w_ts), so no
+ * per-forward fs_pack_weight launches are needed; pack_only=1 just (re)builds them from the current parameters. */
 typedef struct fs_sgd_tensor {
     float* p;
     long long g_off;
     long long numel;
     int I;
     int taps;
+    void* pack_fwd;         /* optional resident [O][R][S][I] copy in `pack_dtype`, rewritten whenever p changes ...        */
+    void* pack_flip;        /* ... and the [I][R][S][O] 180-degree-rotated copy the data-gradient conv reads (both nullable) */
 } fs_sgd_tensor;
 int fs_sgd_chunk_elems(void);
 fs_status fs_sgd_momentum_multi(void* stream, const fs_sgd_tensor* tensors, const int* chunks, int n_chunks,
                                 const unsigned char* touched, const float* grads, float* momentum_buf,
-                                const float* grad_scale, float lr, float momentum, float weight_decay);
+                                const float* grad_scale, float lr, float momentum, float weight_decay, int pack_dtype,
+                                int pack_only);
 
 /* --- command-list executor ------------------------------------------------------------------------ */
 /* Replays a pre-built sequence of the launches above from one host call (csrc/program.hip describes the word encoding).

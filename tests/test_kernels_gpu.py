@@ -321,6 +321,33 @@ def test_weighted_sum_fwd_bwd_dots(dtype, n):
     assert float((dots - coef.grad).abs().max()) < 1e-4 * scale + 1e-3
 
 
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("cfg", [-1, 0, 3, 5, 6])
+def test_conv_reads_filter_block_of_wider_pack(dtype, cfg):
+    """fs_conv_desc.w_os / w_ts: the [:cout][..][:cin] block of a full-size packed bank read in place equals the densely
+    re-packed slice (USConv2d widths, slimmable_ops.py:42), forward and flipped (data-gradient) banks."""
+    from fasterseg_amd import _lib
+    k = K()
+    O, I, cout, cin = 96, 64, 48, 40
+    w = q(rnd(O, I, 3, 3, seed=60) * 0.2, dtype).cuda()
+    x = k.to_nhwc(q(rnd(2, cin, 13, 17, seed=61), dtype).cuda(), dtype)
+    full = k.pack_weight(w, dtype)                              # [O][3][3][I]
+    dense = k.pack_weight(w, dtype, cout, cin)
+    _lib.lib().fs_debug_force_conv_cfg(cfg)
+    try:
+        ref = k.conv2d(x, dense, cout, 3, 3, 1, 1)
+        got = k.conv2d(x, full, cout, 3, 3, 1, 1, w_strides=(9 * I, I))
+        assert torch.equal(ref, got)
+        dz = k.to_nhwc(q(rnd(2, cout, 13, 17, seed=62), dtype).cuda(), dtype)
+        full_f = k.pack_weight(w, dtype, flip=True)             # [I][3][3][O]
+        dense_f = k.pack_weight(w, dtype, cout, cin, flip=True)
+        ref = k.conv2d(dz, dense_f, cin, 3, 3, 1, 1)
+        got = k.conv2d(dz, full_f, cin, 3, 3, 1, 1, w_strides=(9 * O, O))
+        assert torch.equal(ref, got)
+    finally:
+        _lib.lib().fs_debug_force_conv_cfg(-1)
+
+
 def test_bn_finalize_counter_and_fused_param_grad_accumulation():
     """num_batches_tracked is bumped by fs_bn_finalize; fs_bn_bwd_apply adds dgamma/dbeta into the given buffers."""
     k = K()

@@ -218,6 +218,46 @@ def test_flat_sgd_matches_torch_sgd_with_clip():
         assert torch.equal(FN.packed_weight(w, torch.float32).reshape(w.shape[0], 3, 3, w.shape[1]), w.detach().permute(0, 2, 3, 1))
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_resident_packs_follow_the_optimizer(dtype):
+    """FlatSGD(pack_dtype=...) rewrites the packed filter copies inside the update kernel: after every step they equal a
+    fresh fs_pack_weight of the updated parameter (forward and flipped), and an in-place edit of the parameter invalidates
+    them."""
+    from fasterseg_amd import archs
+    from fasterseg_amd import functional as FN
+    from fasterseg_amd import kernels as K
+    from fasterseg_amd.optim import FlatSGD
+    from fasterseg_amd.parallel import FlatGradientSync
+    torch.manual_seed(2)
+    net = archs.init_weight(archs.build_derived(1, training=True), 5).cuda().train()
+    sync = FlatGradientSync(net.parameters())
+    opt = FlatSGD(sync, 0.05, 0.9, 5e-4, max_norm=1.0, pack_dtype=dtype)
+    x = torch.randn(2, 3, 64, 128, device="cuda")
+    convs = [p for p in sync.params if p.dim() == 4 and p.shape[0] % 8 == 0 and p.shape[1] % 8 == 0]
+    assert len(convs) > 20
+    FN.set_compute_dtype(dtype)
+    try:
+        for step in range(3):
+            for w in convs[::7]:
+                fwd, flip = FN.resident_pack(w, dtype)
+                assert torch.equal(fwd, K.pack_weight(w.detach(), dtype)) and torch.equal(flip, K.pack_weight(w.detach(), dtype, flip=True))
+            sync.prepare()
+            p8, p16, p32 = net(x)
+            (p8.float().square().mean() + p16.float().square().mean() + p32.float().square().mean()).backward()
+            sync.sync()
+            before = convs[0].detach().clone()
+            opt.step()
+            assert not torch.equal(before, convs[0].detach())
+    finally:
+        FN.set_compute_dtype(torch.float32)
+    convs[0].data.mul_(1.0)                   # out-of-band edit: version bump -> the resident pack is no longer trusted
+    with torch.no_grad():
+        convs[0].add_(0.0)
+    assert FN.resident_pack(convs[0], dtype) is None
+    opt.refresh_packs()
+    assert FN.resident_pack(convs[0], dtype) is not None
+
+
 def test_student_distill_step_runs_and_learns():
     from fasterseg_amd.train_step import StudentDistillStep, synthetic_batch
     st = StudentDistillStep(2, 128, 256, teacher_engine_dtype=torch.bfloat16)
