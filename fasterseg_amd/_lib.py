@@ -30,6 +30,7 @@ SIGNATURES = {
     "fs_pack_weight": [c_vp, c_vp, c_ll, c_ll, c_int, c_int, c_int, c_int, c_int, c_int, c_vp],
     "fs_unpack_weight_grad": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_ll, c_ll, c_int],
     "fs_conv2d_fwd": [c_vp, ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "fs_conv2d_fwd_ws": [c_vp, ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll],
     "fs_conv2d_wgrad": [c_vp, ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp],
     "fs_conv2d_wgrad_strided": [c_vp, ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_ll, c_ll, c_ll],
     "fs_pack_weight_frag": [c_vp, c_vp, c_ll, c_ll, c_int, c_int, c_int, c_vp],
@@ -45,9 +46,9 @@ SIGNATURES = {
     "fs_bn_bwd_apply": [c_vp, c_ll, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_ll, c_int,
                         c_int, c_vp, c_int, c_vp, c_vp],
     "fs_conv_bn_act_train_fwd": [c_vp, ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_float, c_float,
-                                 c_vp, c_vp, c_vp, c_vp],
+                                 c_vp, c_vp, c_vp, c_vp, c_vp, c_ll],
     "fs_conv_bn_act_train_bwd": [c_vp, ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp,
-                                 c_vp, c_vp, c_vp, c_ll, c_ll, c_ll, c_vp, c_int, c_int, c_int],
+                                 c_vp, c_vp, c_vp, c_ll, c_ll, c_ll, c_vp, c_int, c_int, c_int, c_vp, c_ll],
     "fs_nchw_to_nhwc": [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int],
     "fs_nhwc_to_nchw": [c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_int, c_vp],
     "fs_copy_channels": [c_vp, c_ll, c_int, c_vp, c_int, c_vp, c_int, c_int],

@@ -37,6 +37,8 @@ struct ConvArgs {
     int tiles_n;
     unsigned cin_magic;   // ceil(2^32 / Cin): k / Cin == umulhi(k, cin_magic) for k < 2^16
     int w_os, w_tgap;     // filter row stride (elements) and (tap stride - Cin): 0 gap = dense [Cout][R*S][Cin] pack
+    float* ws;            // cross-block split-K: fp32 partial tiles [gridDim.z][M][Cout] (null = whole K in one block)
+    int k_slice;          // K elements per gridDim.z slice (multiple of the config's BKT)
 };
 
 template <typename T> struct Mma;
@@ -121,9 +123,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     }
     // flattened-K position of each A vector this thread stages; (r, s, c) are re-derived from k with a multiply-high
     // (straight-line code: a data-dependent carry loop here makes hipcc emit exec-masked loops with vmcnt(0) joins)
+    // cross-block split-K (launch-latency-sized layers with a long contraction): this block covers K in [k_lo, k_hi)
+    const int k_lo = p.ws ? (int)blockIdx.z * p.k_slice : 0;
+    const int k_hi = p.ws ? (k_lo + p.k_slice < p.K ? k_lo + p.k_slice : p.K) : p.K;
     int ak[A_SUBS];
 #pragma unroll
-    for (int j = 0; j < A_SUBS; ++j) ak[j] = (a_grp + A_GROUPS * j) * BK64 + lvec * VEC;
+    for (int j = 0; j < A_SUBS; ++j) ak[j] = k_lo + (a_grp + A_GROUPS * j) * BK64 + lvec * VEC;
     const int tshift = transposed ? 1 : 0;
     const unsigned char* b_ptr[B_PASS];
     bool b_ok[B_PASS];
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     }
     int bk[B_SUBS];
 #pragma unroll
-    for (int j = 0; j < B_SUBS; ++j) bk[j] = (b_grp + B_GROUPS * j) * BK64 + lvec * VEC;
+    for (int j = 0; j < B_SUBS; ++j) bk[j] = k_lo + (b_grp + B_GROUPS * j) * BK64 + lvec * VEC;
 
     u32x4 a_reg[A_PASS][A_SUBS], b_reg[B_PASS][B_SUBS];
     uint32_t a_keep[A_PASS][A_SUBS], b_keep[B_PASS][B_SUBS];   // zero-masks, applied when the data is consumed (store_chunk)
@@ -143,7 +148,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
         for (int j = 0; j < A_SUBS; ++j) {
             const int k = ak[j];
-            const bool kvalid = k < p.K;
+            const bool kvalid = k < k_hi;
             const int rs = (int)__umulhi((unsigned)k, p.cin_magic);
             const int kc = k - rs * p.Cin;
             const int kr = (p.S == 3) ? ((rs * 11) >> 5) : rs;     // rs / 3 for rs < 9
@@ -167,7 +172,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
         }
 #pragma unroll
         for (int j = 0; j < B_SUBS; ++j) {
-            const bool kvalid = bk[j] < p.K;
+            const bool kvalid = bk[j] < k_hi;
             // a slice of a wider resident pack: taps are w_tgap elements further apart than Cin (0 for a dense pack)
             const long long koff = bk[j] + (long long)__umulhi((unsigned)bk[j], p.cin_magic) * p.w_tgap;
 #pragma unroll
@@ -220,7 +225,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
         ep_sh[j] = (p.shift && cvalid) ? p.shift[co] : 0.f;
     }
 
-    const int niter = (p.K + BKT - 1) / BKT;
+    const int niter = (k_hi - k_lo + BKT - 1) / BKT;
     const unsigned char* fragA = sA + (wm * WM_T * 32 + (lane & 31)) * PITCH + wk * KSUB * 64 + (lane >> 5) * 16;
     const unsigned char* fragB = sB + (wn * WN_T * 32 + (lane & 31)) * PITCH + wk * KSUB * 64 + (lane >> 5) * 16;
 
@@ -270,6 +275,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
         }
     }
     if (wk != 0) return;
+
+    if (p.ws) {        // partial tile of this K slice; scale/shift/ReLU/statistics are applied by splitk_reduce_kernel
+        float* part = p.ws + (long long)blockIdx.z * p.M * p.Cout;
+#pragma unroll
+        for (int j = 0; j < WN_T; ++j) {
+            const int co = n0 + (wn * WN_T + j) * 32 + (lane & 31);
+#pragma unroll
+            for (int i = 0; i < WM_T; ++i) {
+                const int mbase = m0 + (wm * WM_T + i) * 32;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mbase + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (m < p.M && co < p.Cout) part[(long long)m * p.Cout + co] = acc[i][j][r];
+                }
+            }
+        }
+        return;
+    }
 
     // ---- epilogue --------------------------------------------------------------------------------------
     const bool relu = (p.flags & FS_CONV_RELU) != 0;
@@ -342,12 +365,117 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     }
 }
 
+// Second pass of a cross-block split-K conv: y = relu?(sum_z part[z] * scale + shift) in T, plus the per-channel
+// sum / sum-of-squares of the raw conv output for train-mode BN.  Thread t owns vector column t % cv and pixel rows
+// t / cv + k * rpb (same walk as chan_reduce_kernel in elementwise.hip).
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, int M, int C,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            int relu, T* __restrict__ y, int y_cs, float* __restrict__ stats,
+                                                            int rows_per_block) {
+    constexpr int VEC = Elem<T>::VEC;
+    __shared__ float red[2][256][VEC + 1];
+    const int cv = C / VEC;
+    const int rpb = 256 / cv;
+    const int tid = threadIdx.x;
+    const int col = tid % cv, row = tid / cv;
+    float a0[VEC], a1[VEC], sc[VEC], sh[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        a0[i] = 0.f; a1[i] = 0.f;
+        sc[i] = scale ? scale[col * VEC + i] : 1.f;
+        sh[i] = shift ? shift[col * VEC + i] : 0.f;
+    }
+    const int m_begin = blockIdx.x * rows_per_block;
+    int m_end = m_begin + rows_per_block;
+    if (m_end > M) m_end = M;
+    if (row < rpb) {
+        for (int m = m_begin + row; m < m_end; m += rpb) {
+            float v[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) v[i] = 0.f;
+            for (int z = 0; z < splits; ++z) {
+                const float* src = ws + ((long long)z * M + m) * C + col * VEC;
+#pragma unroll
+                for (int q = 0; q < VEC; q += 4) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(src + q);
+                    v[q] += t[0]; v[q + 1] += t[1]; v[q + 2] += t[2]; v[q + 3] += t[3];
+                }
+            }
+            float o[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                a0[i] += v[i];
+                a1[i] += v[i] * v[i];
+                o[i] = v[i] * sc[i] + sh[i];
+                if (relu) o[i] = fmaxf(o[i], 0.f);
+            }
+            stg16(y + (long long)m * y_cs + col * VEC, Elem<T>::pack(o));
+        }
+    }
+    if (!stats) return;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { red[0][tid][i] = a0[i]; red[1][tid][i] = a1[i]; }
+    __syncthreads();
+    for (int k = tid; k < 2 * C; k += 256) {
+        const int which = k / C, c = k - which * C;
+        const int cc = c / VEC, ci = c - cc * VEC;
+        float s = 0.f;
+        for (int r = 0; r < rpb; ++r) s += red[which][r * cv + cc][ci];
+        atomicAdd(stats + which * C + c, s);
+    }
+}
+
+constexpr long long SPLITK_TARGET_BLOCKS = 1024;
+
+// Number of K slices for a 32x32-tile config with `bkt` K elements per iteration (1 = do not split).  Measured on MI355X
+// (scratch/conv_sweep.py): the second launch and the partial-tile traffic only pay off when the tiles cover well under
+// half of the CUs AND the contraction is long - e.g. 384->384 on a 4x8 map (36 tiles, K = 3456): 39.6 -> 14.9 us fp32;
+// with ~150-300 tiles the single-pass kernel is as fast or faster.
+static inline int splitk_slices(const ConvArgs& a, int bkt) {
+    const long long nb = (long long)((a.M + 31) / 32) * ((a.Cout + 31) / 32);
+    const int iters = (a.K + bkt - 1) / bkt;
+    if (!((nb <= 96 && iters >= 6) || (nb <= 160 && iters >= 12))) return 1;
+    long long s = (SPLITK_TARGET_BLOCKS + nb - 1) / nb;
+    if (s > iters / 2) s = iters / 2;          // at least two iterations per slice
+    return s < 2 ? 1 : (int)s;
+}
+
 template <typename T, int WAVES_M, int WAVES_N, int WAVES_K, int WM_T, int WN_T, int KSUB>
-static void launch_cfg(hipStream_t st, ConvArgs& a) {
+static void launch_cfg(hipStream_t st, ConvArgs& a, float* ws = nullptr, long long ws_bytes = 0) {
     constexpr int BM = WAVES_M * WM_T * 32;
     constexpr int BN = WAVES_N * WN_T * 32;
+    constexpr int BKT = WAVES_K * KSUB * 4 * Elem<T>::VEC;
     a.tiles_n = (a.Cout + BN - 1) / BN;
     const int tiles_m = (a.M + BM - 1) / BM;
+    int slices = 1;
+    a.ws = nullptr;
+    a.k_slice = 0;
+    const bool can_split = BM == 32 && BN == 32 && ws && !(a.flags & (FS_CONV_ACCUM | CONV_SCALAR_STORE)) &&
+                           a.Cout % Elem<T>::VEC == 0 && a.Cout / Elem<T>::VEC <= 256;
+    if (can_split) {
+        slices = splitk_slices(a, BKT);
+        if (slices > 1) {
+            const int iters = (a.K + BKT - 1) / BKT;
+            a.k_slice = (iters + slices - 1) / slices * BKT;
+            slices = (a.K + a.k_slice - 1) / a.k_slice;
+            if (slices < 2 || (long long)slices * a.M * a.Cout * 4 > ws_bytes) slices = 1;
+        }
+    }
+    if (slices > 1) {
+        a.ws = ws;
+        hipLaunchKernelGGL((conv_igemm_kernel<T, WAVES_M, WAVES_N, WAVES_K, WM_T, WN_T, KSUB>),
+                           dim3((unsigned)(tiles_m * a.tiles_n), 1, (unsigned)slices), dim3(256), 0, st, a);
+        const int cv = a.Cout / Elem<T>::VEC;
+        const int rpb = 256 / cv;
+        int rows = ((a.M + 511) / 512 + rpb - 1) / rpb * rpb;        // ~512 blocks, whole row groups per block
+        if (rows < rpb) rows = rpb;
+        hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)((a.M + rows - 1) / rows)), dim3(256), 0, st, ws, slices, a.M,
+                           a.Cout, a.scale, a.shift, (a.flags & FS_CONV_RELU) ? 1 : 0, (T*)a.y, a.y_cs, a.stats, rows);
+        return;
+    }
+    a.ws = nullptr;
+    a.k_slice = 0;
     hipLaunchKernelGGL((conv_igemm_kernel<T, WAVES_M, WAVES_N, WAVES_K, WM_T, WN_T, KSUB>),
                        dim3((unsigned)(tiles_m * a.tiles_n)), dim3(256), 0, st, a);
 }
@@ -358,7 +486,7 @@ static inline long long nblocks(const ConvArgs& a, int bm, int bn) {
 
 // Tile choice: the largest tile that still gives every CU at least one block; otherwise 32-wide tiles with the K
 // loop split over the four waves of the block (launch-latency-sized layers).
-template <typename T> static void dispatch(hipStream_t st, ConvArgs& a, int force) {
+template <typename T> static void dispatch(hipStream_t st, ConvArgs& a, int force, float* ws, long long ws_bytes) {
     const long long FILL = 256;
     int cfg;
     if (force >= 0) cfg = force;
@@ -366,7 +494,8 @@ template <typename T> static void dispatch(hipStream_t st, ConvArgs& a, int forc
     else if (a.Cout > 32 && nblocks(a, 128, 64) >= FILL) cfg = 1;
     else if (a.Cout <= 32 && nblocks(a, 128, 32) >= FILL) cfg = 2;
     else if (a.Cout > 32 && nblocks(a, 64, 64) >= FILL) cfg = 3;
-    else if (nblocks(a, 64, 32) >= FILL) cfg = 4;
+    else if (nblocks(a, 64, 32) >= 2 * FILL) cfg = 4;
+    else if (nblocks(a, 32, 32) >= 2 * FILL) cfg = 5;        // 512+ small tiles: the lighter staging keeps more blocks per CU
     else cfg = (a.K > 8 * 64 / (int)sizeof(T)) ? 6 : 5;      // long K: stage 16 sub-chunks per iteration
     switch (cfg) {
         case 0: launch_cfg<T, 2, 2, 1, 2, 2, 2>(st, a); break;   // 128 x 128
@@ -374,8 +503,8 @@ template <typename T> static void dispatch(hipStream_t st, ConvArgs& a, int forc
         case 2: launch_cfg<T, 4, 1, 1, 1, 1, 2>(st, a); break;   // 128 x 32
         case 3: launch_cfg<T, 2, 2, 1, 1, 1, 2>(st, a); break;   // 64 x 64
         case 4: launch_cfg<T, 2, 1, 2, 1, 1, 2>(st, a); break;   // 64 x 32, K split 2
-        case 5: launch_cfg<T, 1, 1, 4, 1, 1, 2>(st, a); break;   // 32 x 32, K split 4, 8 sub-chunks / iteration
-        default: launch_cfg<T, 1, 1, 4, 1, 1, 4>(st, a); break;  // 32 x 32, K split 4, 16 sub-chunks / iteration
+        case 5: launch_cfg<T, 1, 1, 4, 1, 1, 2>(st, a, ws, ws_bytes); break;   // 32 x 32, K split 4, 8 sub-chunks / iteration
+        default: launch_cfg<T, 1, 1, 4, 1, 1, 4>(st, a, ws, ws_bytes); break;  // 32 x 32, K split 4, 16 sub-chunks / iteration
     }
 }
 
@@ -389,7 +518,15 @@ extern "C" void fs_debug_force_conv_cfg(int cfg) { g_force_cfg = cfg; }
 
 extern "C" fs_status fs_conv2d_fwd(void* stream, const fs_conv_desc* d, const void* x, const void* w_packed,
                                    const float* scale, const float* shift, void* y, float* stats) {
+    return fs_conv2d_fwd_ws(stream, d, x, w_packed, scale, shift, y, stats, nullptr, 0);
+}
+
+extern "C" fs_status fs_conv2d_fwd_ws(void* stream, const fs_conv_desc* d, const void* x, const void* w_packed,
+                                      const float* scale, const float* shift, void* y, float* stats, void* workspace,
+                                      long long workspace_bytes) {
     FS_REQUIRE(d && x && w_packed && y, FS_ERR_INVALID, "fs_conv2d_fwd: null argument");
+    FS_REQUIRE(workspace == nullptr || (aligned16(workspace) && workspace_bytes >= 0), FS_ERR_INVALID,
+               "fs_conv2d_fwd_ws: workspace must be 16-byte aligned");
     FS_REQUIRE(d->dtype == FS_F32 || d->dtype == FS_BF16, FS_ERR_INVALID, "fs_conv2d_fwd: bad dtype %d", d->dtype);
     const int vec = vec_elems(d->dtype);
     FS_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->Ho > 0 && d->Wo > 0, FS_ERR_INVALID,
@@ -433,7 +570,7 @@ extern "C" fs_status fs_conv2d_fwd(void* stream, const fs_conv_desc* d, const vo
     }
     // 16-byte epilogue stores need an aligned slice; otherwise every tile takes the element-wise path
     if (!(aligned16(y) && (d->y_cs % vec == 0))) a.flags |= CONV_SCALAR_STORE;
-    if (d->dtype == FS_F32) dispatch<float>((hipStream_t)stream, a, g_force_cfg);
-    else dispatch<bf16_t>((hipStream_t)stream, a, g_force_cfg);
+    if (d->dtype == FS_F32) dispatch<float>((hipStream_t)stream, a, g_force_cfg, (float*)workspace, workspace_bytes);
+    else dispatch<bf16_t>((hipStream_t)stream, a, g_force_cfg, (float*)workspace, workspace_bytes);
     return check_launch("fs_conv2d_fwd");
 }

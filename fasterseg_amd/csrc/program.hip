@@ -20,7 +20,7 @@
 
 namespace {
 
-constexpr int MAX_ARGS = 24;
+constexpr int MAX_ARGS = 28;
 constexpr int MAX_ARRAYS = 4;
 
 struct Args {
@@ -107,19 +107,19 @@ extern "C" fs_status fs_exec_program(void* stream, const long long* words, long 
                 st = fs_pack_weight(stream, PF(0), L(1), L(2), I(3), I(4), I(5), I(6), I(7), I(8), P(9));
                 break;
             case FS_OP_CONV_FWD:
-                NEED(7);
-                st = fs_conv2d_fwd(stream, (const fs_conv_desc*)P(0), P(1), P(2), PF(3), PF(4), P(5), PF(6));
+                NEED(9);
+                st = fs_conv2d_fwd_ws(stream, (const fs_conv_desc*)P(0), P(1), P(2), PF(3), PF(4), P(5), PF(6), P(7), L(8));
                 break;
             case FS_OP_UNIT_FWD:
-                NEED(14);
+                NEED(16);
                 st = fs_conv_bn_act_train_fwd(stream, (const fs_conv_desc*)P(0), P(1), P(2), PF(3), PF(4), PF(5), PF(6),
-                                              (long long*)P(7), F(8), F(9), PF(10), PF(11), P(12), P(13));
+                                              (long long*)P(7), F(8), F(9), PF(10), PF(11), P(12), P(13), P(14), L(15));
                 break;
             case FS_OP_UNIT_BWD:
-                NEED(21);
+                NEED(23);
                 st = fs_conv_bn_act_train_bwd(stream, (const fs_conv_desc*)P(0), P(1), P(2), P(3), P(4), P(5), I(6), PF(7), PF(8),
                                               PF(9), PF(10), PF(11), P(12), PF(13), L(14), L(15), L(16), P(17), I(18), I(19),
-                                              I(20));
+                                              I(20), P(21), L(22));
                 break;
             case FS_OP_WGRAD_STRIDED:
                 NEED(7);

@@ -11,11 +11,12 @@
 extern "C" fs_status fs_conv_bn_act_train_fwd(void* stream, const fs_conv_desc* d, const void* x, const void* w_packed,
                                               const float* gamma, const float* beta, float* running_mean,
                                               float* running_var, long long* num_batches_tracked, float eps,
-                                              float momentum, float* stats, float* saved, void* z, void* y) {
+                                              float momentum, float* stats, float* saved, void* z, void* y, void* workspace,
+                                              long long workspace_bytes) {
     FS_REQUIRE(d && x && w_packed && stats && saved && z && y, FS_ERR_INVALID, "fs_conv_bn_act_train_fwd: null argument");
     fs_conv_desc c = *d;
     c.flags &= ~FS_CONV_RELU;          // the conv writes the raw pre-normalisation map z (+ per-channel sum / sumsq)
-    fs_status s = fs_conv2d_fwd(stream, &c, x, w_packed, nullptr, nullptr, z, stats);
+    fs_status s = fs_conv2d_fwd_ws(stream, &c, x, w_packed, nullptr, nullptr, z, stats, workspace, workspace_bytes);
     if (s != FS_OK) return s;
     const int C = d->Cout;
     const long long count = (long long)d->N * d->Ho * d->Wo;
@@ -30,7 +31,8 @@ extern "C" fs_status fs_conv_bn_act_train_bwd(void* stream, const fs_conv_desc* 
                                               const void* z, const void* y, const void* dy, int dy_cs, const float* saved,
                                               const float* gamma, float* red, float* dgamma_acc, float* dbeta_acc,
                                               void* dz, float* dw, long long o_stride, long long i_stride,
-                                              long long t_stride, void* dx, int dx_cs, int wf_os, int wf_ts) {
+                                              long long t_stride, void* dx, int dx_cs, int wf_os, int wf_ts, void* workspace,
+                                              long long workspace_bytes) {
     FS_REQUIRE(d && z && dy && saved && gamma && red && dz, FS_ERR_INVALID, "fs_conv_bn_act_train_bwd: null argument");
     const int relu = (d->flags & FS_CONV_RELU) ? 1 : 0;
     FS_REQUIRE(!relu || y, FS_ERR_INVALID, "fs_conv_bn_act_train_bwd: ReLU unit needs its output y");
@@ -63,7 +65,7 @@ extern "C" fs_status fs_conv_bn_act_train_bwd(void* stream, const fs_conv_desc* 
         g.x_cs = C; g.y_cs = dx_cs;
         g.dtype = d->dtype;
         g.flags = d->stride == 2 ? FS_CONV_TRANSPOSED : 0;
-        s = fs_conv2d_fwd(stream, &g, dz, w_flip, nullptr, nullptr, dx, nullptr);
+        s = fs_conv2d_fwd_ws(stream, &g, dz, w_flip, nullptr, nullptr, dx, nullptr, workspace, workspace_bytes);
         if (s != FS_OK) return s;
     }
     return FS_OK;

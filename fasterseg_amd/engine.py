@@ -284,6 +284,14 @@ class InferenceEngine:
             for d in c["waits"]:
                 self.calls[d]["signal"] = True
         self.lane_tails = tails
+        # one split-K scratch buffer per lane (calls of a lane are ordered, lanes run concurrently): the implicit-GEMM conv
+        # splits long contractions of launch-latency-sized layers across blocks when it gets a workspace
+        if bool(int(os.environ.get("FS_ENGINE_SPLITK", "1"))):
+            self._workspaces = [torch.empty(K.WORKSPACE_BYTES, dtype=torch.uint8, device=self.device) for _ in range(n_lanes)]
+            for c in self.calls:
+                if c["fn"] == "fs_conv2d_fwd":
+                    c["fn"] = "fs_conv2d_fwd_ws"
+                    c["args"] = c["args"] + (ctypes.c_void_p(self._workspaces[c["lane"]].data_ptr()), K.WORKSPACE_BYTES)
 
     # ---- 4. run ----------------------------------------------------------------------------------------
     def _launch_all(self):

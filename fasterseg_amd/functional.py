@@ -226,11 +226,12 @@ class _ConvBNAct(torch.autograd.Function):
         y = torch.empty_strided((N, cout, Ho, Wo), strides, dtype=dtype, device=dev)
         saved = torch.empty(4 * cout, dtype=torch.float32, device=dev)      # mean | invstd | scale | shift
         stats = K.zeros_f32(2 * cout, dev)
+        ws, ws_bytes = K.stream_workspace(dev)
         K.call("fs_conv_bn_act_train_fwd", K._stream(), ctypes.byref(d), x.data_ptr(), wp.data_ptr(), gamma.data_ptr(),
                beta.data_ptr(), running_mean.data_ptr() if running_mean is not None else None,
                running_var.data_ptr() if running_var is not None else None,
                num_batches_tracked.data_ptr() if num_batches_tracked is not None else None, eps, momentum,
-               stats.data_ptr(), saved.data_ptr(), z.data_ptr(), y.data_ptr())
+               stats.data_ptr(), saved.data_ptr(), z.data_ptr(), y.data_ptr(), ws, ws_bytes)
         ctx.eval_mode = False
         ctx.cfg = cfg
         ctx.desc = d
@@ -279,7 +280,7 @@ class _ConvBNAct(torch.autograd.Function):
                red.data_ptr(), gslot.data_ptr() if gslot is not None else None, bslot.data_ptr() if bslot is not None else None,
                dz.data_ptr(), wdst.data_ptr() if need_w else None, wdst.stride(0) if need_w else 0,
                wdst.stride(1) if need_w else 0, wdst.stride(3) if need_w else 0, gx.data_ptr() if need_x else None, cin,
-               wf_os, wf_ts)
+               wf_os, wf_ts, *K.stream_workspace(dev))
         if wslot is not None:
             sink.touched(weight)
         dgamma, dbeta = red[cout:], red[:cout]
@@ -657,7 +658,8 @@ class _MixedOpProgram(torch.autograd.Function):
         N, C, H, W = prog.out_shape
         out = torch.empty_strided((N, C, H, W), (H * W * C, 1, W * C, C), dtype=x.dtype, device=dev)
         prog.run(prog.f_words, prog.f_n, prog.f_blob,
-                 (None, x.data_ptr(), c.data_ptr(), out.data_ptr(), save.data_ptr(), None, None, None, tmp.data_ptr()))
+                 (None, x.data_ptr(), c.data_ptr(), out.data_ptr(), save.data_ptr(), None, None, None, tmp.data_ptr(),
+                  K.stream_workspace(dev)[0]))
         ctx.prog = prog
         ctx.save_for_backward(x, c, save)
         return out
@@ -676,7 +678,7 @@ class _MixedOpProgram(torch.autograd.Function):
             gx = torch.empty_strided((n, ci, h, w), (h * w * ci, 1, w * ci, ci), dtype=x.dtype, device=x.device)
         prog.run(prog.b_words, prog.b_n, prog.b_blob,
                  (None, x.data_ptr(), c.data_ptr(), None, save.data_ptr(), dy.data_ptr(), tmp.data_ptr(),
-                  gx.data_ptr() if gx is not None else None, None))
+                  gx.data_ptr() if gx is not None else None, None, K.stream_workspace(x.device)[0]))
         if prog.touched:
             sink = _grad_sink
             for p in prog.touched:

@@ -171,6 +171,20 @@ def unpack_weight_grad(dw_packed, grad, cout, cin, accumulate=False):
 # ---------------------------------------------------------------------------------------------------
 # convolution
 # ---------------------------------------------------------------------------------------------------
+WORKSPACE_BYTES = 16 << 20          # FS_CONV_WORKSPACE_BYTES
+_workspaces = {}
+
+
+def stream_workspace(device):
+    """(address, bytes) of the split-K scratch buffer of the current stream: convs that share a workspace must be ordered,
+    which holds for everything issued on one stream (inside a capture too: one buffer per forked lane)."""
+    raw = torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+    ws = _workspaces.get(raw)
+    if ws is None:
+        ws = _workspaces[raw] = torch.empty(WORKSPACE_BYTES, dtype=torch.uint8, device=device)
+    return ws.data_ptr(), WORKSPACE_BYTES
+
+
 def conv_desc(x_shape, x_cs, cout, R, S, stride, pad, y_cs, dtype, flags=0, out_hw=None):
     N, Cin, H, W = x_shape
     if out_hw is None:
@@ -182,9 +196,10 @@ def conv_desc(x_shape, x_cs, cout, R, S, stride, pad, y_cs, dtype, flags=0, out_
 
 
 def conv2d(x, w_packed, cout, R, S, stride, pad, scale=None, shift=None, relu=False, out=None, stats=None,
-           transposed=False, out_hw=None, w_strides=None):
+           transposed=False, out_hw=None, w_strides=None, workspace=True):
     """y = relu?(conv(x, w) * scale + shift); `out` may be a channel slice of a wider NHWC buffer.  w_strides = (row, tap)
-    element strides when the filter is the leading block of a wider packed bank."""
+    element strides when the filter is the leading block of a wider packed bank; workspace=False keeps the whole contraction
+    in one block per tile (no cross-block split-K)."""
     x_cs = require_nhwc(x, "x")
     N, Cin, H, W = x.shape
     flags = (FS_CONV_RELU if relu else 0) | (FS_CONV_TRANSPOSED if transposed else 0)
@@ -197,7 +212,9 @@ def conv2d(x, w_packed, cout, R, S, stride, pad, scale=None, shift=None, relu=Fa
     assert d.y_cs is not None
     if w_strides is not None:
         d.w_os, d.w_ts = w_strides
-    call("fs_conv2d_fwd", _stream(), ctypes.byref(d), _p(x), _p(w_packed), _p(scale), _p(shift), _p(out), _p(stats))
+    ws, ws_bytes = stream_workspace(x.device) if workspace else (None, 0)
+    call("fs_conv2d_fwd_ws", _stream(), ctypes.byref(d), _p(x), _p(w_packed), _p(scale), _p(shift), _p(out), _p(stats), ws,
+         ws_bytes)
     return out
 
 

@@ -12,6 +12,7 @@ gradients are wanted) into two command lists, forward and backward, whose pointe
     slot 2  COEF       the 5 mixing coefficients         slot 6  TMPB  backward scratch (zero region first)
     slot 3  OUT        the mixed output                  slot 7  GX    gradient w.r.t. X
     slot 4  SAVE       activations kept for backward     slot 8  TMPF  forward scratch (zero region first)
+                                                         slot 9  WS    the stream's split-K conv workspace
 
 Per call the autograd Function (functional._MixedOpProgram) allocates three arenas and the output and crosses the FFI once
 per direction.  The per-module path in functional.py computes exactly the same thing and remains the reference
@@ -27,8 +28,8 @@ from . import _lib
 from . import kernels as K
 from ._lib import ConvDesc, ResizeDesc
 
-ABS, X, COEF, OUT, SAVE, DY, TMPB, GX, TMPF = range(9)
-N_SLOTS = 9
+ABS, X, COEF, OUT, SAVE, DY, TMPB, GX, TMPF, WS = range(10)
+N_SLOTS = 10
 _ALIGN = 256
 
 (OP_MEMSET, OP_PACK_WEIGHT, OP_CONV_FWD, OP_UNIT_FWD, OP_UNIT_BWD, OP_WGRAD_STRIDED, OP_CHANNEL_STATS, OP_BN_FINALIZE,
@@ -224,7 +225,8 @@ class _Lowering:
         y = self.new(f, SAVE, x.N, cout, Ho, Wo)
         momentum = 0.1 if b.momentum is None else float(b.momentum)
         f.emit(OP_UNIT_FWD, _Desc(desc), x.ref, wp, self.param(b.weight), self.param(b.bias), self.param(b.running_mean),
-               self.param(b.running_var), self.param(b.num_batches_tracked), float(b.eps), momentum, stats, saved, z.ref, y.ref)
+               self.param(b.running_var), self.param(b.num_batches_tracked), float(b.eps), momentum, stats, saved, z.ref, y.ref,
+               Ref(WS, 0), K.WORKSPACE_BYTES)
 
         def backward(dy, need_x):
             bl = self.b
@@ -244,7 +246,7 @@ class _Lowering:
                 dw, acc = (NULL, 0, 0, 0), (NULL, NULL)
             bl.emit(OP_UNIT_BWD, _Desc(desc), x.ref, wf or NULL, z.ref, y.ref if relu else NULL, dy.ref, dy.cs, saved,
                     absolute(b.weight), red, acc[0], acc[1], dz.ref, dw[0], dw[1], dw[2], dw[3], dx.ref if need_x else NULL,
-                    cin, wf_os, wf_ts)
+                    cin, wf_os, wf_ts, Ref(WS, 0), K.WORKSPACE_BYTES)
             return dx
         return y, backward
 
@@ -283,7 +285,7 @@ class _Lowering:
             wp, w_os, w_ts = self.filter(f, TMPF, w, half, cin, False)
             d = ConvDesc(x.N, x.H, x.W, cin, half, 1, 1, 2, pad, Ho, Wo, x.cs, C2, self.dt, 0, w_os, w_ts)
             descs.append(d)
-            f.emit(OP_CONV_FWD, _Desc(d), x.ref, wp, NULL, NULL, z.ref + k * half * self.esize, NULL)
+            f.emit(OP_CONV_FWD, _Desc(d), x.ref, wp, NULL, NULL, z.ref + k * half * self.esize, NULL, Ref(WS, 0), K.WORKSPACE_BYTES)
         stats = f.alloc(TMPF, 2 * C2 * 4, zero=True)
         saved = f.alloc(SAVE, 4 * C2 * 4)
         momentum = 0.1 if b.momentum is None else float(b.momentum)
@@ -313,7 +315,7 @@ class _Lowering:
                     gk = self.new(bl, TMPB, x.N, cin, x.H, x.W)
                     g = ConvDesc(x.N, Ho, Wo, half, cin, 1, 1, 1, 0 - descs[k].pad, x.H, x.W, C2, cin, self.dt, K.FS_CONV_TRANSPOSED,
                                  wf_os, wf_ts)
-                    bl.emit(OP_CONV_FWD, _Desc(g), dzk, wf, NULL, NULL, gk.ref, NULL)
+                    bl.emit(OP_CONV_FWD, _Desc(g), dzk, wf, NULL, NULL, gk.ref, NULL, Ref(WS, 0), K.WORKSPACE_BYTES)
                     if dx is None:
                         dx = gk
                     else:       # the second branch touches only odd (h, w): disjoint from the first one's even taps

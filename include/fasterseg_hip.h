@@ -86,6 +86,14 @@ fs_status fs_unpack_weight_grad(void* stream, const float* dw_packed, int Cout, 
  * stats[0..Cout) and stats[Cout..2*Cout) with atomics (caller zeroes it). */
 fs_status fs_conv2d_fwd(void* stream, const fs_conv_desc* d, const void* x, const void* w_packed,
                         const float* scale, const float* shift, void* y, float* stats);
+/* Same, with a caller-provided scratch buffer (16-byte aligned, FS_CONV_WORKSPACE_BYTES is always enough).  Layers whose
+ * 32x32 tiles cannot fill the chip but have a long contraction (e.g. 384->384 channels on a 4x8 map: 36 tiles, K = 3456)
+ * are then split over K across blocks: partial fp32 tiles go to the workspace and a second launch reduces them, applies
+ * scale/shift/ReLU and the BN statistics.  Calls that share a workspace must be ordered on one stream. */
+#define FS_CONV_WORKSPACE_BYTES (16ll << 20)
+fs_status fs_conv2d_fwd_ws(void* stream, const fs_conv_desc* d, const void* x, const void* w_packed,
+                           const float* scale, const float* shift, void* y, float* stats, void* workspace,
+                           long long workspace_bytes);
 
 /* 3x3 / stride 1 / pad 1 convolution with an LDS-staged input halo tile (conv3x3_halo.hip): same contract as
  * fs_conv2d_fwd (flags: FS_CONV_RELU only) but the filter must be packed in MFMA fragment order by fs_pack_weight_frag
@@ -155,11 +163,12 @@ fs_status fs_bn_bwd_apply(void* stream, long long pixels, int C, const void* x, 
  *   (ConvNorm, search/operations.py:42-128; the conv+bn(+relu) pairs of BasicResidual*, :131-262).
  *   z (raw conv output) and y (normalised output) are NHWC buffers with channel stride d->y_cs; `stats` is 2*Cout zeroed
  *   floats of scratch; `saved` receives 4*Cout floats: mean, invstd, scale, shift (mean/invstd are needed by the
- *   backward).  Running statistics and num_batches_tracked (both may be null) are updated as by nn.BatchNorm2d. */
+ *   backward).  Running statistics and num_batches_tracked (both may be null) are updated as by nn.BatchNorm2d.
+ *   `workspace` (nullable, see fs_conv2d_fwd_ws) lets the convs of both directions split K across blocks. */
 fs_status fs_conv_bn_act_train_fwd(void* stream, const fs_conv_desc* d, const void* x, const void* w_packed,
                                    const float* gamma, const float* beta, float* running_mean, float* running_var,
                                    long long* num_batches_tracked, float eps, float momentum, float* stats, float* saved,
-                                   void* z, void* y);
+                                   void* z, void* y, void* workspace, long long workspace_bytes);
 /* Backward of the same unit (replaces the autograd of F.conv2d + F.batch_norm + relu): given dy (channel stride dy_cs)
  *   red[0..C) = dbeta, red[C..2C) = dgamma (red must be zeroed), optionally accumulated into dgamma_acc/dbeta_acc;
  *   dz (dense NHWC, channel stride Cout) = gradient w.r.t. the conv output;
@@ -169,7 +178,8 @@ fs_status fs_conv_bn_act_train_fwd(void* stream, const fs_conv_desc* d, const vo
 fs_status fs_conv_bn_act_train_bwd(void* stream, const fs_conv_desc* d, const void* x, const void* w_flip, const void* z,
                                    const void* y, const void* dy, int dy_cs, const float* saved, const float* gamma,
                                    float* red, float* dgamma_acc, float* dbeta_acc, void* dz, float* dw, long long o_stride,
-                                   long long i_stride, long long t_stride, void* dx, int dx_cs, int wf_os, int wf_ts);
+                                   long long i_stride, long long t_stride, void* dx, int dx_cs, int wf_os, int wf_ts,
+                                   void* workspace, long long workspace_bytes);
 
 /* --- layout / copies ------------------------------------------------------------------------------ */
 /* NCHW contiguous fp32 <-> NHWC (dtype) with channel stride; C arbitrary (zero-fills up to c_pad on the way in). */

@@ -348,6 +348,37 @@ def test_conv_reads_filter_block_of_wider_pack(dtype, cfg):
         _lib.lib().fs_debug_force_conv_cfg(-1)
 
 
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(3, 384, 384, 4, 8), (2, 192, 96, 7, 14), (1, 256, 64, 16, 32), (3, 96, 96, 16, 32)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_conv_split_k_matches_single_pass(shape, relu, dtype):
+    """fs_conv2d_fwd_ws: long contractions of small maps are split over K across blocks (partial tiles in the workspace +
+    reduce/epilogue launch).  Same result as the single-pass kernel (up to fp32 summation order), same BN statistics, and
+    both agree with the fp32 CPU convolution."""
+    k = K()
+    N, cin, cout, H, W = shape
+    x = q(rnd(N, cin, H, W, seed=70), dtype)
+    w = q(rnd(cout, cin, 3, 3, seed=71) * (2.0 / (9 * cin)) ** 0.5, dtype)
+    scale, shift = (rnd(cout, seed=72).abs() + 0.5), rnd(cout, seed=73)
+    ref = F.conv2d(x, w, padding=1)
+    want = ref * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    want = F.relu(want) if relu else want
+    xd = k.to_nhwc(x.cuda(), dtype)
+    wp = k.pack_weight(w.cuda(), dtype)
+    outs, stats = [], []
+    for workspace in (False, True):
+        st = torch.zeros(2 * cout, device="cuda")
+        outs.append(k.conv2d(xd, wp, cout, 3, 3, 1, 1, scale.cuda(), shift.cuda(), relu, stats=st, workspace=workspace))
+        stats.append(st.cpu())
+    check(outs[1], want, dtype, "split-K conv vs CPU")
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert float((outs[0].float() - outs[1].float()).abs().max()) <= tol * max(1.0, float(want.abs().max()))
+    cnt = N * H * W
+    assert torch.allclose(stats[1][:cout] / cnt, ref.mean((0, 2, 3)), atol=2e-3, rtol=1e-3)
+    assert torch.allclose(stats[1][cout:] / cnt, ref.square().mean((0, 2, 3)), atol=2e-3, rtol=2e-3)
+    assert torch.allclose(stats[0], stats[1], atol=1e-2 * cnt ** 0.5, rtol=2e-3)
+
+
 def test_bn_finalize_counter_and_fused_param_grad_accumulation():
     """num_batches_tracked is bumped by fs_bn_finalize; fs_bn_bwd_apply adds dgamma/dbeta into the given buffers."""
     k = K()

@@ -8,7 +8,7 @@ import torch
 from fasterseg_amd import model_search, program
 from fasterseg_amd.parallel import FlatGradientSync
 
-NARGS = {program.OP_MEMSET: 2, program.OP_PACK_WEIGHT: 10, program.OP_CONV_FWD: 7, program.OP_UNIT_FWD: 14, program.OP_UNIT_BWD: 21,
+NARGS = {program.OP_MEMSET: 2, program.OP_PACK_WEIGHT: 10, program.OP_CONV_FWD: 9, program.OP_UNIT_FWD: 16, program.OP_UNIT_BWD: 23,
          program.OP_WGRAD_STRIDED: 7, program.OP_CHANNEL_STATS: 6, program.OP_BN_FINALIZE: 14, program.OP_AFFINE_ACT: 10,
          program.OP_BN_BWD_REDUCE: 13, program.OP_BN_BWD_APPLY: 19, program.OP_BILINEAR_FWD: 3, program.OP_BILINEAR_BWD: 4,
          program.OP_WSUM: 9, program.OP_WSUM_BWD: 9, program.OP_WSUM_DOTS: 9, program.OP_AXPY: 9}
