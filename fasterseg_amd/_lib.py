@@ -40,6 +40,8 @@ SIGNATURES = {
     "fs_bilinear_bwd": [c_vp, ctypes.POINTER(ResizeDesc), c_vp, c_vp, c_vp],
     "fs_bilinear_bwd_nchw": [c_vp, ctypes.POINTER(ResizeDesc), c_vp, c_vp, c_vp],
     "fs_bn_finalize": [c_vp, c_int, c_ll, c_vp, c_vp, c_vp, c_float, c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "fs_bn_train_apply": [c_vp, c_ll, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_float, c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_int,
+                          c_int, c_int],
     "fs_affine_act": [c_vp, c_ll, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int],
     "fs_channel_stats": [c_vp, c_ll, c_int, c_vp, c_int, c_int, c_vp],
     "fs_bn_bwd_reduce": [c_vp, c_ll, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_vp],

@@ -151,6 +151,54 @@ __global__ void ew_kernel(long long pixels, int cv, const T* __restrict__ x, int
     }
 }
 
+// Train-mode BN normalise pass with the statistics finalisation folded in: every thread derives scale/shift of its channel
+// vector from the raw (sum, sumsq) - a few flops - so the separate bn_finalize launch disappears; block 0 also publishes
+// mean / invstd / scale / shift for the backward and updates running statistics and num_batches_tracked.
+template <typename T>
+__global__ void bn_train_apply_kernel(long long pixels, int cv, const T* __restrict__ x, int x_cs, const float* __restrict__ stats,
+                                      float count, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                      float momentum, float* running_mean, float* running_var, long long* num_batches_tracked,
+                                      float* __restrict__ saved, T* __restrict__ y, int y_cs, int relu) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int C = cv * VEC;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0 && num_batches_tracked) *num_batches_tracked += 1;
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            const float m = stats[c] / count;
+            const float var = fmaxf(stats[C + c] / count - m * m, 0.f);
+            const float is = 1.0f / sqrtf(var + eps);
+            const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+            saved[c] = m;
+            saved[C + c] = is;
+            saved[2 * C + c] = g * is;
+            saved[3 * C + c] = b - m * g * is;
+            if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+            if (running_var) {
+                const float unbiased = count > 1.f ? var * (count / (count - 1.f)) : var;
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+            }
+        }
+    }
+    const long long total = pixels * cv;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const long long pix = idx / cv;
+        const int c = (int)(idx - pix * cv) * VEC;
+        float f[VEC];
+        Elem<T>::unpack(ldg16(x + pix * x_cs + c), f);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            const float m = stats[c + i] / count;
+            const float var = fmaxf(stats[C + c + i] / count - m * m, 0.f);
+            const float is = 1.0f / sqrtf(var + eps);
+            const float sc = (gamma ? gamma[c + i] : 1.f) * is;
+            const float o = f[i] * sc + ((beta ? beta[c + i] : 0.f) - m * sc);
+            f[i] = relu ? fmaxf(o, 0.f) : o;
+        }
+        stg16(y + pix * y_cs + c, Elem<T>::pack(f));
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // per-channel reductions over pixels.  Thread t owns vector column (t % cv) and pixel rows t/cv + k*rpb.
 // MODE 0: stats  -> out[c] += sum x, out[C+c] += sum x^2
@@ -625,4 +673,19 @@ extern "C" fs_status fs_weighted_sum_dots(void* stream, long long pixels, int C,
     DT_DISPATCH(dtype, hipLaunchKernelGGL((wsum_dot_kernel<T>), dim3(grid_for(pixels * cv, 256, 1024)), dim3(256), 0,
                                           (hipStream_t)stream, pixels, cv, (const T*)dy, dy_cs, a, out);)
     return check_launch("fs_weighted_sum_dots");
+}
+
+extern "C" fs_status fs_bn_train_apply(void* stream, long long pixels, int C, const void* x, int x_cs, const float* stats,
+                                       const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                                       float* running_var, long long* num_batches_tracked, float* saved, void* y, int y_cs,
+                                       int dtype, int relu) {
+    fs_status s;
+    if ((s = check_slice("fs_bn_train_apply", x, x_cs, C, dtype)) != FS_OK) return s;
+    if ((s = check_slice("fs_bn_train_apply", y, y_cs, C, dtype)) != FS_OK) return s;
+    FS_REQUIRE(stats && saved && pixels > 0, FS_ERR_INVALID, "fs_bn_train_apply: bad argument");
+    const int cv = C / vec_elems(dtype);
+    DT_DISPATCH(dtype, hipLaunchKernelGGL((bn_train_apply_kernel<T>), dim3(grid_for(pixels * cv)), dim3(256), 0, (hipStream_t)stream,
+                                          pixels, cv, (const T*)x, x_cs, stats, (float)pixels, gamma, beta, eps, momentum,
+                                          running_mean, running_var, num_batches_tracked, saved, (T*)y, y_cs, relu);)
+    return check_launch("fs_bn_train_apply");
 }

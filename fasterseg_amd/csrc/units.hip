@@ -20,11 +20,8 @@ extern "C" fs_status fs_conv_bn_act_train_fwd(void* stream, const fs_conv_desc* 
     if (s != FS_OK) return s;
     const int C = d->Cout;
     const long long count = (long long)d->N * d->Ho * d->Wo;
-    s = fs_bn_finalize(stream, C, count, stats, gamma, beta, eps, momentum, running_mean, running_var, saved, saved + C,
-                       saved + 2 * C, saved + 3 * C, num_batches_tracked);
-    if (s != FS_OK) return s;
-    return fs_affine_act(stream, count, C, z, d->y_cs, saved + 2 * C, saved + 3 * C, y, d->y_cs, d->dtype,
-                         (d->flags & FS_CONV_RELU) ? 1 : 0);
+    return fs_bn_train_apply(stream, count, C, z, d->y_cs, stats, gamma, beta, eps, momentum, running_mean, running_var,
+                             num_batches_tracked, saved, y, d->y_cs, d->dtype, (d->flags & FS_CONV_RELU) ? 1 : 0);
 }
 
 extern "C" fs_status fs_conv_bn_act_train_bwd(void* stream, const fs_conv_desc* d, const void* x, const void* w_flip,

@@ -185,12 +185,18 @@ class SupernetStep:
         torch.cuda.synchronize()
         fresh()
         g = torch.cuda.CUDAGraph()
+        from . import kernels as K
         with torch.cuda.graph(g, stream=side):
-            loss = self._run_pass(spec, imgs, target)
-            loss.backward()
+            K.zero_pool.begin_capture(imgs.device)          # one captured fill instead of two per conv-BN module
+            try:
+                loss = self._run_pass(spec, imgs, target)
+                loss.backward()
+            finally:
+                arena = K.zero_pool.end_capture()
         touched = self.sync.touched_indices() if phase == "w" else None
         if phase == "w":
             self.sync.sync()
+        self._graph_arenas.append(arena)
         return g, loss.detach(), touched
 
     def _capture(self, batches):
@@ -201,6 +207,7 @@ class SupernetStep:
             pass
         self.static = {ph: (i.clone(), t.clone()) for ph, (i, t) in batches.items()}
         self.graphs = {}
+        self._graph_arenas = []
         from . import model_search
         side = torch.cuda.Stream()
         model_search.branch_lanes(side)           # MixedOp forks its five primitives onto these inside the capture

@@ -138,6 +138,13 @@ fs_status fs_bilinear_bwd_nchw(void* stream, const fs_resize_desc* d, const floa
 fs_status fs_bn_finalize(void* stream, int C, long long count, const float* stats, const float* gamma,
                          const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                          float* mean, float* invstd, float* scale, float* shift, long long* num_batches_tracked);
+/* fs_bn_finalize + fs_affine_act in ONE launch for an NHWC tensor of `pixels` pixels whose (sum, sumsq) are in `stats`:
+ * y = relu?(gamma*(x-mean)*invstd + beta); `saved` receives 4*C floats (mean, invstd, scale, shift), running statistics
+ * and num_batches_tracked (nullable) are updated as by fs_bn_finalize. */
+fs_status fs_bn_train_apply(void* stream, long long pixels, int C, const void* x, int x_cs, const float* stats,
+                            const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                            float* running_var, long long* num_batches_tracked, float* saved, void* y, int y_cs, int dtype,
+                            int relu);
 /* y = relu?(x*scale[c]+shift[c]) over an NHWC tensor (in place allowed). */
 fs_status fs_affine_act(void* stream, long long pixels, int C, const void* x, int x_cs, const float* scale,
                         const float* shift, void* y, int y_cs, int dtype, int relu);

@@ -267,6 +267,14 @@ def test_batchnorm_train_fwd_bwd(shape, relu, dtype):
     check(out, yr, dtype, "bn fwd")
     assert torch.allclose(rm_d.cpu(), rm_ref, atol=1e-4, rtol=1e-4)
     assert torch.allclose(rv_d.cpu(), rv_ref, atol=1e-4, rtol=1e-3)
+    # the one-launch form (finalize folded into the normalise pass) gives the same output, saved statistics and buffers
+    rm_f, rv_f, nbt = rm.cuda(), rv.cuda(), torch.tensor(3, dtype=torch.long, device="cuda")
+    out_f, saved = k.bn_train_apply(zd, stats, gamma.detach().cuda(), beta.detach().cuda(), 1e-5, 0.1, rm_f, rv_f, nbt, relu)
+    assert int(nbt) == 4
+    tol = 1e-5 if dtype == torch.float32 else 1e-2          # same math, different association of the shift term
+    assert torch.allclose(out_f.float(), out.float(), atol=tol, rtol=tol)
+    assert torch.allclose(saved, torch.cat([mean, invstd, scale, shift]), atol=1e-6, rtol=1e-5)
+    assert torch.allclose(rm_f, rm_d, atol=1e-6, rtol=1e-6) and torch.allclose(rv_f, rv_d, atol=1e-6, rtol=1e-6)
     if dtype == torch.float32:
         dz, dg, db = k.bn_backward(zd, k.to_nhwc(dy.cuda(), dtype), out, mean, invstd, gamma.detach().cuda(), relu)
         check(dz, z.grad, dtype, "bn dz")
