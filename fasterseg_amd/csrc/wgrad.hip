@@ -3,9 +3,13 @@
 // Replaces conv2d backward-weight (the autograd of F.conv2d at reference slimmable_ops.py:47 and of every
 // nn.Conv2d in operations.py / seg_oprs.py).  GEMM view per filter tap (r,s): D[co][ci], contraction over the
 // output pixels m (split across blocks, fp32 atomics into the packed gradient).  Both operands are NHWC, i.e.
-// "k-major": a chunk of 32 pixels is staged as [pixel][channel] rows in LDS (fp32, bf16 inputs are widened while
-// staging so the accumulation is exact-fp32 MFMA) and the v_mfma_f32_32x32x2_f32 operands are single ds_read_b32
-// per lane (lanes 0-31 = 32 consecutive channels of pixel k, lanes 32-63 of pixel k+1: conflict free).
+// "k-major": a chunk of 32 pixels is staged as [pixel][channel] rows in LDS.
+//   fp32: v_mfma_f32_32x32x2_f32 operands are single ds_read_b32 per lane (lanes 0-31 = 32 consecutive channels of pixel
+//         k, lanes 32-63 of pixel k+1: conflict free); exact fp32 products.
+//   bf16: tiles stay bf16 in LDS and feed v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate); an operand is 8 consecutive
+//         PIXELS of one channel, i.e. a column of the staged tile, gathered with 8 ds_read_u16 (row pitch 144 B: the two
+//         half-waves land on disjoint banks).  The kernel is then LDS-issue bound, still several times faster than
+//         widening to fp32.
 #include "common.h"
 
 namespace fs {
@@ -25,14 +29,21 @@ struct WgradArgs {
 constexpr int KC = 32;      // pixels per chunk
 constexpr int BCH = 64;     // channels per block tile (both operands)
 constexpr int PITCH = BCH + 4;
+constexpr int PITCH16 = BCH + 8;     // bf16 tile: 144-byte rows
+
+template <typename T> struct Stage { typedef float elem; static constexpr int pitch = PITCH; };
+template <> struct Stage<bf16_t> { typedef bf16_t elem; static constexpr int pitch = PITCH16; };
 
 template <typename T>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
     constexpr int VEC = Elem<T>::VEC;
     constexpr int VR = BCH / VEC;                 // vectors per staged row
     constexpr int NV = (KC * VR + 255) / 256;     // vectors per thread per operand
-    __shared__ __attribute__((aligned(16))) float sA[KC][PITCH];   // dY  [pixel][co]
-    __shared__ __attribute__((aligned(16))) float sB[KC][PITCH];   // X   [pixel][ci]
+    typedef typename Stage<T>::elem LT;
+    constexpr int LP = Stage<T>::pitch;
+    constexpr bool NATIVE = sizeof(LT) == 2;                       // bf16 tiles feed the bf16 MFMA directly
+    __shared__ __attribute__((aligned(16))) LT sA[KC][LP];         // dY  [pixel][co]
+    __shared__ __attribute__((aligned(16))) LT sB[KC][LP];         // X   [pixel][ci]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -76,13 +87,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
                 u32x4 va = ra[i], vb = rb[i];
                 va[0] &= ka[i]; va[1] &= ka[i]; va[2] &= ka[i]; va[3] &= ka[i];
                 vb[0] &= kb[i]; vb[1] &= kb[i]; vb[2] &= kb[i]; vb[3] &= kb[i];
+                if (NATIVE) {
+                    *reinterpret_cast<u32x4*>(&sA[row][cvec]) = va;
+                    *reinterpret_cast<u32x4*>(&sB[row][cvec]) = vb;
+                    continue;
+                }
                 float fa[VEC], fb[VEC];
                 Elem<T>::unpack(va, fa);
                 Elem<T>::unpack(vb, fb);
 #pragma unroll
                 for (int q = 0; q < VEC; q += 4) {
-                    *reinterpret_cast<f32x4*>(&sA[row][cvec + q]) = f32x4{fa[q], fa[q + 1], fa[q + 2], fa[q + 3]};
-                    *reinterpret_cast<f32x4*>(&sB[row][cvec + q]) = f32x4{fb[q], fb[q + 1], fb[q + 2], fb[q + 3]};
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(&sA[row][0]) + cvec + q) = f32x4{fa[q], fa[q + 1], fa[q + 2], fa[q + 3]};
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(&sB[row][0]) + cvec + q) = f32x4{fb[q], fb[q + 1], fb[q + 2], fb[q + 3]};
                 }
             }
         }
@@ -98,10 +114,27 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
             store_chunk();
             __syncthreads();
             if (mc + KC < m_end) load_chunk(mc + KC);
-            const float* pa = &sA[lane >> 5][wm * 32 + (lane & 31)];
-            const float* pb = &sB[lane >> 5][wn * 32 + (lane & 31)];
+            if (NATIVE) {
+                // operand = 8 consecutive pixels (k) of one channel: a strided column of the [pixel][channel] tile
+                const bf16_t* pa = reinterpret_cast<const bf16_t*>(&sA[(lane >> 5) * 8][wm * 32 + (lane & 31)]);
+                const bf16_t* pb = reinterpret_cast<const bf16_t*>(&sB[(lane >> 5) * 8][wn * 32 + (lane & 31)]);
 #pragma unroll
-            for (int k = 0; k < KC; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[k * PITCH], pb[k * PITCH], acc, 0, 0, 0);
+                for (int k = 0; k < KC; k += 16) {
+                    u32x4 a, b;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        a[j] = (uint32_t)pa[(k + 2 * j) * LP] | ((uint32_t)pa[(k + 2 * j + 1) * LP] << 16);
+                        b[j] = (uint32_t)pb[(k + 2 * j) * LP] | ((uint32_t)pb[(k + 2 * j + 1) * LP] << 16);
+                    }
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc,
+                                                                  0, 0, 0);
+                }
+            } else {
+                const float* pa = reinterpret_cast<const float*>(&sA[lane >> 5][0]) + wm * 32 + (lane & 31);
+                const float* pb = reinterpret_cast<const float*>(&sB[lane >> 5][0]) + wn * 32 + (lane & 31);
+#pragma unroll
+                for (int k = 0; k < KC; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[k * PITCH], pb[k * PITCH], acc, 0, 0, 0);
+            }
             __syncthreads();
         }
     }
