@@ -187,9 +187,12 @@ def test_conv2d_dgrad_and_wgrad(case, dtype):
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("cout", [32, 48, 24])
-def test_stem_conv(cout, dtype):
+@pytest.mark.parametrize("hw", [(34, 52), (33, 50), (26, 264), (17, 136)], ids=lambda v: "%dx%d" % v)
+def test_stem_conv(cout, dtype, hw):
+    """(34,52)/(26,264)/(17,136): W % 4 == 0 -> LDS-tiled kernel (partial tiles, several tiles per row, odd H);
+    (33,50): gather kernel."""
     k = K()
-    x = rnd(2, 3, 34, 52, seed=7)
+    x = rnd(2, 3, hw[0], hw[1], seed=7)
     w = rnd(cout, 3, 3, 3, seed=8, scale=0.3)
     scale, shift = rnd(cout, seed=9).abs() + 0.5, rnd(cout, seed=10)
     ref = F.relu(F.conv2d(x, w, None, 2, 1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))

@@ -14,7 +14,7 @@ import csv
 import json
 import sys
 
-FAMILY = [("conv3x3_halo_kernel", "conv"), ("conv_igemm_kernel", "conv"), ("stem_conv_kernel", "stem"),
+FAMILY = [("conv3x3_halo_kernel", "conv"), ("conv_igemm_kernel", "conv"), ("stem_conv_kernel", "stem"), ("stem_lds_kernel", "stem"),
           ("bilinear_fwd_nchw_kernel", "resize_nchw"), ("bilinear_fwd_kernel", "resize")]
 
 
