@@ -60,6 +60,7 @@ SIGNATURES = {
     "fs_weighted_sum_bwd": [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_int],
     "fs_weighted_sum_dots": [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_vp],
     "fs_exec_program": [c_vp, c_vp, c_ll, c_vp, c_vp, c_int],
+    "fs_exec_program_streams": [c_vp, c_int, c_vp, c_ll, c_vp, c_vp, c_int],
     "fs_sgd_momentum_multi": [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_float, c_float, c_float, c_int, c_int],
 }
 _SPECIAL = {
@@ -69,6 +70,8 @@ _SPECIAL = {
     "fs_debug_force_conv_cfg": ([c_int], None),
     "fs_packed_weight_frag_elems": ([c_int, c_int, c_int], c_ll),
     "fs_sgd_chunk_elems": ([], c_int),
+    "fs_event_create": ([], c_vp),
+    "fs_event_destroy": ([c_vp], None),
 }
 ALL_SYMBOLS = sorted(list(SIGNATURES) + list(_SPECIAL))
 

@@ -42,14 +42,38 @@ struct Args {
 
 extern "C" fs_status fs_exec_program(void* stream, const long long* words, long long n_words, const unsigned char* blob,
                                      void* const* slots, int n_slots) {
-    FS_REQUIRE(words && n_words >= 0 && slots && n_slots > 0, FS_ERR_INVALID, "fs_exec_program: bad argument");
+    void* streams[1] = {stream};
+    return fs_exec_program_streams(streams, 1, words, n_words, blob, slots, n_slots);
+}
+
+extern "C" void* fs_event_create(void) {
+    hipEvent_t ev = nullptr;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return nullptr;
+    return (void*)ev;
+}
+
+extern "C" void fs_event_destroy(void* ev) {
+    if (ev) (void)hipEventDestroy((hipEvent_t)ev);
+}
+
+// Multi-stream form: bits 16.. of every op word select the stream the command is enqueued on; FS_OP_EVENT_RECORD /
+// FS_OP_EVENT_WAIT express the cross-stream edges.  This is the inference engine's alternative to hipGraph replay: on ROCm
+// a graph launch costs ~5 us of host time per kernel node, a direct launch from here ~2 us, and with 71 nodes per frame the
+// graph replay can become host-bound on a slow host core.
+extern "C" fs_status fs_exec_program_streams(void* const* streams, int n_streams, const long long* words, long long n_words,
+                                             const unsigned char* blob, void* const* slots, int n_slots) {
+    FS_REQUIRE(streams && n_streams > 0 && words && n_words >= 0 && slots && n_slots > 0, FS_ERR_INVALID,
+               "fs_exec_program: bad argument");
     long long pos = 0;
     int index = 0;
     while (pos < n_words) {
         FS_REQUIRE(pos + 2 <= n_words, FS_ERR_INVALID, "fs_exec_program: truncated command %d", index);
-        const int op = (int)words[pos];
+        const int op = (int)(words[pos] & 0xffff);
+        const int lane = (int)(words[pos] >> 16);
         const int nargs = (int)words[pos + 1];
         pos += 2;
+        FS_REQUIRE(lane >= 0 && lane < n_streams, FS_ERR_INVALID, "fs_exec_program: command %d on stream %d of %d", index, lane, n_streams);
+        void* const stream = streams[lane];
         FS_REQUIRE(nargs >= 0 && nargs <= MAX_ARGS, FS_ERR_INVALID, "fs_exec_program: command %d has %d arguments", index, nargs);
         Args a;
         int narr = 0;
@@ -171,6 +195,27 @@ extern "C" fs_status fs_exec_program(void* stream, const long long* words, long 
             case FS_OP_AXPY:
                 NEED(9);
                 st = fs_axpy_channels(stream, L(0), I(1), P(2), I(3), PF(4), P(5), I(6), I(7), I(8));
+                break;
+            case FS_OP_CONV3X3_S1:
+                NEED(7);
+                st = fs_conv3x3_s1_fwd(stream, (const fs_conv_desc*)P(0), P(1), P(2), PF(3), PF(4), P(5), PF(6));
+                break;
+            case FS_OP_STEM:
+                NEED(12);
+                st = fs_conv_stem_fwd(stream, I(0), I(1), I(2), I(3), PF(4), PF(5), PF(6), PF(7), P(8), I(9), I(10), I(11));
+                break;
+            case FS_OP_COPY_CHANNELS:
+                NEED(7);
+                st = fs_copy_channels(stream, L(0), I(1), P(2), I(3), P(4), I(5), I(6));
+                break;
+            case FS_OP_EVENT_RECORD:
+                NEED(1);
+                FS_REQUIRE(hipEventRecord((hipEvent_t)P(0), (hipStream_t)stream) == hipSuccess, FS_ERR_LAUNCH, "fs_exec_program: event record failed");
+                break;
+            case FS_OP_EVENT_WAIT:
+                NEED(1);
+                FS_REQUIRE(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)P(0), 0) == hipSuccess, FS_ERR_LAUNCH,
+                           "fs_exec_program: event wait failed");
                 break;
             default:
                 FS_REQUIRE(false, FS_ERR_INVALID, "fs_exec_program: unknown op %d (command %d)", op, index);

@@ -74,7 +74,8 @@ template <> struct Quad<bf16_t> {
 };
 template <typename TO> __device__ __forceinline__ void store4(TO* dst, const float* v);
 template <> __device__ __forceinline__ void store4<float>(float* dst, const float* v) {
-    *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+    // the logits are written once and not read again by this graph: stream them past the caches
+    __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4*>(dst));
 }
 template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* dst, const float* v) {
     uint2 o;

@@ -16,6 +16,7 @@ import os
 
 import torch
 
+from . import _lib
 from . import functional as FN
 from . import kernels as K
 from ._lib import FS_CONV_RELU, ConvDesc, ResizeDesc, call
@@ -184,7 +185,7 @@ class InferenceEngine:
         flops = 2.0 * N * Ho * Wo * cout * cin * k * k
         nbytes = es * (N * H * W * cin + cout * cin * k * k + N * Ho * Wo * cout)
         args = (ctypes.byref(d), ctypes.c_void_p(xp), ctypes.c_void_p(wp.data_ptr()), K._p(scale), K._p(shift), ctypes.c_void_p(yp), None)
-        self.calls.append(dict(fn="fs_conv3x3_s1_fwd" if use_halo else "fs_conv2d_fwd", args=args, family="conv%dx%d" % (k, k), flops=flops, bytes=nbytes,
+        self.calls.append(dict(fn="fs_conv3x3_s1_fwd" if use_halo else "fs_conv2d_fwd", args=args, desc=d, family="conv%dx%d" % (k, k), flops=flops, bytes=nbytes,
                                label="%s %dx%d s%d %d->%d @%dx%d" % (label, k, k, stride, cin, cout, H, W)))
 
     def _ready(self, sym):
@@ -236,7 +237,7 @@ class InferenceEngine:
                 d = ResizeDesc(N, Hi, Wi, Ho, Wo, C, x_cs, y_cs, K.dtype_code(self.dtype), int(op["relu"]), onchw)
                 self._keep.append(d)
                 args = (ctypes.byref(d), ctypes.c_void_p(xp), ctypes.c_void_p(yp))
-                self.calls.append(dict(fn="fs_bilinear_fwd", args=args, family="resize_nchw" if onchw else "resize", flops=0.0,
+                self.calls.append(dict(fn="fs_bilinear_fwd", args=args, desc=d, family="resize_nchw" if onchw else "resize", flops=0.0,
                                        bytes=es * N * Hi * Wi * C + out_es * N * Ho * Wo * C,
                                        label="resize %dx%d->%dx%d C%d%s" % (Hi, Wi, Ho, Wo, C, " nchw" if onchw else "")))
             elif kind == "cat":
@@ -321,6 +322,73 @@ class InferenceEngine:
             ev.record(s_)
             main.wait_event(ev)
 
+    # ---- 4b. the plan as one multi-stream launch program (fs_exec_program_streams) ---------------------------------
+    _OPS = {"fs_conv2d_fwd_ws": "OP_CONV_FWD", "fs_conv2d_fwd": "OP_CONV_FWD", "fs_conv3x3_s1_fwd": "OP_CONV3X3_S1",
+            "fs_conv_stem_fwd": "OP_STEM", "fs_bilinear_fwd": "OP_BILINEAR_FWD", "fs_copy_channels": "OP_COPY_CHANNELS"}
+
+    def _build_program(self):
+        """Same launches, lanes and cross-lane edges as `_launch_all_lanes`, as a relocatable-free command list (all
+        addresses absolute) that the C executor issues from one FFI call: lane 0 = the caller's stream."""
+        from . import program as P
+        lst = P._List()
+        lib = _lib.lib()
+        self._events = []
+
+        def event():
+            ev = lib.fs_event_create()
+            if not ev:
+                raise RuntimeError("fs_event_create failed")
+            self._events.append(ev)
+            return P.Ref(P.ABS, ev)
+
+        def arg(a):
+            if a is None:
+                return P.NULL
+            if isinstance(a, ctypes.c_void_p):
+                return P.Ref(P.ABS, a.value or 0)
+            return a
+        n_lanes = self.n_lanes
+        if n_lanes > 1:
+            fork = event()
+            lst.emit(P.OP_EVENT_RECORD, fork, lane=0)
+            for lane in range(1, n_lanes):
+                lst.emit(P.OP_EVENT_WAIT, fork, lane=lane)
+        signals = {}
+        for i, c in enumerate(self.calls):
+            lane = c["lane"]
+            for d in c["waits"]:
+                lst.emit(P.OP_EVENT_WAIT, signals[d], lane=lane)
+            args = [arg(a) for a in c["args"]]
+            if "desc" in c:
+                args[0] = P._Desc(c["desc"])
+            if c["fn"] == "fs_conv2d_fwd":                      # no workspace assigned: whole contraction in one block
+                args += [P.NULL, 0]
+            lst.emit(getattr(P, self._OPS[c["fn"]]), *args, lane=lane)
+            if c["signal"]:
+                signals[i] = event()
+                lst.emit(P.OP_EVENT_RECORD, signals[i], lane=lane)
+        for lane in range(1, n_lanes):
+            ev = event()
+            lst.emit(P.OP_EVENT_RECORD, ev, lane=lane)
+            lst.emit(P.OP_EVENT_WAIT, ev, lane=0)
+        self._prog_words, self._prog_n, self._prog_blob, _ = lst.finish()
+        self._prog_slots = (ctypes.c_void_p * P.N_SLOTS)()
+        self._prog_side = [torch.cuda.Stream() for _ in range(n_lanes - 1)]
+
+    def _run_program(self):
+        streams = (ctypes.c_void_p * self.n_lanes)(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()),
+                                                   *[s_.cuda_stream for s_ in self._prog_side])
+        call("fs_exec_program_streams", streams, self.n_lanes, self._prog_words, self._prog_n, self._prog_blob, self._prog_slots,
+             len(self._prog_slots))
+
+    def __del__(self):
+        try:
+            lib = _lib.lib()
+            for ev in getattr(self, "_events", []):
+                lib.fs_event_destroy(ev)
+        except Exception:
+            pass
+
     def _capture_once(self, lanes):
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -370,10 +438,28 @@ class InferenceEngine:
             if best is None or ms < best[0]:
                 best = (ms, g, lanes, self._side_streams)
         self.graph, self.graph_lanes, self._side_streams = best[1], best[2], best[3]
+        # the same plan issued directly from the C executor (no hipGraph): cheaper on the host per launch
+        self.use_program = False
+        if bool(int(os.environ.get("FS_ENGINE_PROGRAM", "1"))):
+            self._build_program()
+            for _ in range(5):
+                self._run_program()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(40):
+                self._run_program()
+            e1.record()
+            e1.synchronize()
+            ms = e0.elapsed_time(e1) / 40
+            self.capture_log.append(("program", round(ms, 4)))
+            self.use_program = ms < best[0]
 
     def run(self):
         """One forward on the current contents of `self.input`; result in `self.output` (contiguous NCHW logits)."""
-        if self.graph is not None:
+        if getattr(self, "use_program", False):
+            self._run_program()
+        elif self.graph is not None:
             self.graph.replay()
         else:
             self._launch_all()

@@ -266,10 +266,22 @@ enum {
     FS_OP_WSUM_BWD,
     FS_OP_WSUM_DOTS,
     FS_OP_AXPY,
+    FS_OP_CONV3X3_S1,        /* fs_conv3x3_s1_fwd */
+    FS_OP_STEM,              /* fs_conv_stem_fwd */
+    FS_OP_COPY_CHANNELS,
+    FS_OP_EVENT_RECORD,      /* (event)  record on the command's stream   (fs_exec_program_streams)      */
+    FS_OP_EVENT_WAIT,        /* (event)  make the command's stream wait for the event                     */
     FS_OP_COUNT
 };
 fs_status fs_exec_program(void* stream, const long long* words, long long n_words, const unsigned char* blob,
                           void* const* slots, int n_slots);
+/* Multi-stream form: every op word carries its stream index in bits 16 and up (`op | lane << 16`); the inference engine
+ * issues a whole frame (71 launches on 3 streams with event edges) through one call instead of a hipGraph launch, whose
+ * host cost per kernel node is higher.  Events are created / destroyed with fs_event_create / fs_event_destroy. */
+fs_status fs_exec_program_streams(void* const* streams, int n_streams, const long long* words, long long n_words,
+                                  const unsigned char* blob, void* const* slots, int n_slots);
+void* fs_event_create(void);
+void fs_event_destroy(void* event);
 
 #ifdef __cplusplus
 }
