@@ -18,7 +18,7 @@ c_int, c_ll, c_float, c_vp = ctypes.c_int, ctypes.c_longlong, ctypes.c_float, ct
 
 class ConvDesc(ctypes.Structure):
     _fields_ = [(n, c_int) for n in ("N", "H", "W", "Cin", "Cout", "R", "S", "stride", "pad", "Ho", "Wo",
-                                     "x_cs", "y_cs", "dtype", "flags", "w_os", "w_ts")]
+                                     "x_cs", "y_cs", "dtype", "flags", "w_os", "w_ts", "vr_H", "vr_W", "vr_relu")]
 
 
 class ResizeDesc(ctypes.Structure):

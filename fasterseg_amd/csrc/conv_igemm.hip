@@ -37,6 +37,9 @@ struct ConvArgs {
     int tiles_n;
     unsigned cin_magic;   // ceil(2^32 / Cin): k / Cin == umulhi(k, cin_magic) for k < 2^16
     int w_os, w_tgap;     // filter row stride (elements) and (tap stride - Cin): 0 gap = dense [Cout][R*S][Cin] pack
+    int vr_H, vr_W;       // virtual-resize input (VRES kernels): x is a (vr_H, vr_W) map, bilinearly resampled
+    float vr_rh, vr_rw;   //   (align_corners=True) to the (H, W) map the convolution reads; scale = (vr-1)/(H-1)
+    int vr_relu;          //   ReLU applied to the resampled value (zoomed-conv up-sample, operations.py:275-276)
     float* ws;            // cross-block split-K: fp32 partial tiles [gridDim.z][M][Cout] (null = whole K in one block)
     int k_slice;          // K elements per gridDim.z slice (multiple of the config's BKT)
 };
@@ -59,7 +62,7 @@ template <> struct Mma<bf16_t> {
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 constexpr int CONV_SCALAR_STORE = 0x100;   // internal flag: output slice not 16-byte aligned -> element-wise epilogue
 
-template <typename T, int WAVES_M, int WAVES_N, int WAVES_K, int WM_T, int WN_T, int KSUB>
+template <typename T, int WAVES_M, int WAVES_N, int WAVES_K, int WM_T, int WN_T, int KSUB, bool VRES = false>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     constexpr int BM = WAVES_M * WM_T * 32;
     constexpr int BN = WAVES_N * WN_T * 32;
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
             const int ow = rem - oh * p.Wo;
             a_ih0[ps] = oh * p.stride - p.pad;
             a_iw0[ps] = ow * p.stride - p.pad;
-            a_base[ps] = (long long)n * p.H * p.W;
+            a_base[ps] = VRES ? (long long)n * p.vr_H * p.vr_W : (long long)n * p.H * p.W;
         } else {
             a_ih0[ps] = -(1 << 24);
             a_iw0[ps] = 0;
@@ -143,6 +146,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     for (int j = 0; j < B_SUBS; ++j) bk[j] = k_lo + (b_grp + B_GROUPS * j) * BK64 + lvec * VEC;
 
     u32x4 a_reg[A_PASS][A_SUBS], b_reg[B_PASS][B_SUBS];
+    // VRES: the three other bilinear taps of every A vector and the two interpolation fractions (zero-sized otherwise)
+    constexpr int VR = VRES ? 1 : 0;
+    u32x4 a_t01[A_PASS * VR + 1][A_SUBS], a_t10[A_PASS * VR + 1][A_SUBS], a_t11[A_PASS * VR + 1][A_SUBS];
+    float a_lh[A_PASS * VR + 1][A_SUBS], a_lw[A_PASS * VR + 1][A_SUBS];
     uint32_t a_keep[A_PASS][A_SUBS], b_keep[B_PASS][B_SUBS];   // zero-masks, applied when the data is consumed (store_chunk)
     auto load_chunk = [&]() {
 #pragma unroll
@@ -150,7 +157,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
             const int k = ak[j];
             const bool kvalid = k < k_hi;
             const int rs = (int)__umulhi((unsigned)k, p.cin_magic);
-            const int kc = k - rs * p.Cin;
+            const int kc = (VRES && !kvalid) ? 0 : k - rs * p.Cin;
             const int kr = (p.S == 3) ? ((rs * 11) >> 5) : rs;     // rs / 3 for rs < 9
             const int ks = rs - kr * p.S;
 #pragma unroll
@@ -161,12 +168,26 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
                 ih >>= tshift;
                 iw >>= tshift;
                 ok = ok && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
-                // branch-free: invalid lanes read the (always valid) tensor base and are masked to zero afterwards, so
-                // all gathers of an iteration are in flight together
-                const long long pix = a_base[ps] + (long long)ih * p.W + iw;
-                const long long off = ok ? (pix * p.x_cs + kc) * (long long)sizeof(T) : 0ll;
                 a_keep[ps][j] = ok ? 0xffffffffu : 0u;
-                a_reg[ps][j] = ldg16(p.x + off);
+                if constexpr (VRES) {
+                    // (ih, iw) address the RESAMPLED map; fetch the four source pixels it interpolates (resize.hip arithmetic)
+                    const Tap th = make_tap(p.vr_rh, ok ? ih : 0, p.vr_H), tw = make_tap(p.vr_rw, ok ? iw : 0, p.vr_W);
+                    const long long r0 = (a_base[ps] + (long long)th.i0 * p.vr_W) * p.x_cs + kc;
+                    const long long r1 = (a_base[ps] + (long long)th.i1 * p.vr_W) * p.x_cs + kc;
+                    const long long c0 = (long long)tw.i0 * p.x_cs, c1 = (long long)tw.i1 * p.x_cs;
+                    a_reg[ps][j] = ldg16(p.x + (r0 + c0) * (long long)sizeof(T));
+                    a_t01[ps][j] = ldg16(p.x + (r0 + c1) * (long long)sizeof(T));
+                    a_t10[ps][j] = ldg16(p.x + (r1 + c0) * (long long)sizeof(T));
+                    a_t11[ps][j] = ldg16(p.x + (r1 + c1) * (long long)sizeof(T));
+                    a_lh[ps][j] = th.l1;
+                    a_lw[ps][j] = tw.l1;
+                } else {
+                    // branch-free: invalid lanes read the (always valid) tensor base and are masked to zero afterwards, so
+                    // all gathers of an iteration are in flight together
+                    const long long pix = a_base[ps] + (long long)ih * p.W + iw;
+                    const long long off = ok ? (pix * p.x_cs + kc) * (long long)sizeof(T) : 0ll;
+                    a_reg[ps][j] = ldg16(p.x + off);
+                }
             }
             ak[j] = k + BKT;
         }
@@ -191,6 +212,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
             for (int j = 0; j < A_SUBS; ++j)
             {
                 u32x4 v = a_reg[ps][j];
+                if constexpr (VRES) {
+                    constexpr int VEC_ = Elem<T>::VEC;
+                    float p00[VEC_], p01[VEC_], p10[VEC_], p11[VEC_];
+                    Elem<T>::unpack(v, p00);
+                    Elem<T>::unpack(a_t01[ps][j], p01);
+                    Elem<T>::unpack(a_t10[ps][j], p10);
+                    Elem<T>::unpack(a_t11[ps][j], p11);
+                    const float h1 = a_lh[ps][j], h0 = 1.f - h1, w1 = a_lw[ps][j], w0 = 1.f - w1;
+#pragma unroll
+                    for (int e = 0; e < VEC_; ++e) {
+                        const float o = h0 * (w0 * p00[e] + w1 * p01[e]) + h1 * (w0 * p10[e] + w1 * p11[e]);
+                        p00[e] = p.vr_relu ? fmaxf(o, 0.f) : o;
+                    }
+                    v = Elem<T>::pack(p00);
+                }
                 const uint32_t keep = a_keep[ps][j];
                 v[0] &= keep; v[1] &= keep; v[2] &= keep; v[3] &= keep;
                 *reinterpret_cast<u32x4*>(sA + (ps * A_RPP + a_row) * PITCH + (a_grp + A_GROUPS * j) * 64 + lvec * 16) = v;
@@ -441,7 +477,7 @@ static inline int splitk_slices(const ConvArgs& a, int bkt) {
     return s < 2 ? 1 : (int)s;
 }
 
-template <typename T, int WAVES_M, int WAVES_N, int WAVES_K, int WM_T, int WN_T, int KSUB>
+template <typename T, int WAVES_M, int WAVES_N, int WAVES_K, int WM_T, int WN_T, int KSUB, bool VRES = false>
 static void launch_cfg(hipStream_t st, ConvArgs& a, float* ws = nullptr, long long ws_bytes = 0) {
     constexpr int BM = WAVES_M * WM_T * 32;
     constexpr int BN = WAVES_N * WN_T * 32;
@@ -464,7 +500,7 @@ static void launch_cfg(hipStream_t st, ConvArgs& a, float* ws = nullptr, long lo
     }
     if (slices > 1) {
         a.ws = ws;
-        hipLaunchKernelGGL((conv_igemm_kernel<T, WAVES_M, WAVES_N, WAVES_K, WM_T, WN_T, KSUB>),
+        hipLaunchKernelGGL((conv_igemm_kernel<T, WAVES_M, WAVES_N, WAVES_K, WM_T, WN_T, KSUB, VRES>),
                            dim3((unsigned)(tiles_m * a.tiles_n), 1, (unsigned)slices), dim3(256), 0, st, a);
         const int cv = a.Cout / Elem<T>::VEC;
         const int rpb = 256 / cv;
@@ -476,7 +512,7 @@ static void launch_cfg(hipStream_t st, ConvArgs& a, float* ws = nullptr, long lo
     }
     a.ws = nullptr;
     a.k_slice = 0;
-    hipLaunchKernelGGL((conv_igemm_kernel<T, WAVES_M, WAVES_N, WAVES_K, WM_T, WN_T, KSUB>),
+    hipLaunchKernelGGL((conv_igemm_kernel<T, WAVES_M, WAVES_N, WAVES_K, WM_T, WN_T, KSUB, VRES>),
                        dim3((unsigned)(tiles_m * a.tiles_n)), dim3(256), 0, st, a);
 }
 
@@ -497,6 +533,16 @@ template <typename T> static void dispatch(hipStream_t st, ConvArgs& a, int forc
     else if (nblocks(a, 64, 32) >= 2 * FILL) cfg = 4;
     else if (nblocks(a, 32, 32) >= 2 * FILL) cfg = 5;        // 512+ small tiles: the lighter staging keeps more blocks per CU
     else cfg = (a.K > 8 * 64 / (int)sizeof(T)) ? 6 : 5;      // long K: stage 16 sub-chunks per iteration
+    if (a.vr_H > 0) {        // resampled input: only the small-map configurations carry the interpolating gather
+        if (cfg < 3) cfg = 3;
+        switch (cfg) {
+            case 3: launch_cfg<T, 2, 2, 1, 1, 1, 2, true>(st, a); break;
+            case 4: launch_cfg<T, 2, 1, 2, 1, 1, 2, true>(st, a); break;
+            case 5: launch_cfg<T, 1, 1, 4, 1, 1, 2, true>(st, a, ws, ws_bytes); break;
+            default: launch_cfg<T, 1, 1, 4, 1, 1, 4, true>(st, a, ws, ws_bytes); break;
+        }
+        return;
+    }
     switch (cfg) {
         case 0: launch_cfg<T, 2, 2, 1, 2, 2, 2>(st, a); break;   // 128 x 128
         case 1: launch_cfg<T, 2, 2, 1, 2, 1, 2>(st, a); break;   // 128 x 64
@@ -561,6 +607,16 @@ extern "C" fs_status fs_conv2d_fwd_ws(void* stream, const fs_conv_desc* d, const
     a.flags = d->flags;
     a.tiles_n = 1;
     a.cin_magic = (unsigned)(((1ull << 32) + (unsigned)d->Cin - 1) / (unsigned)d->Cin);
+    a.vr_H = a.vr_W = a.vr_relu = 0;
+    a.vr_rh = a.vr_rw = 0.f;
+    if (d->vr_H > 0 || d->vr_W > 0) {
+        FS_REQUIRE(d->vr_H > 0 && d->vr_W > 0 && !(d->flags & FS_CONV_TRANSPOSED), FS_ERR_INVALID,
+                   "fs_conv2d_fwd: bad virtual-resize source size %dx%d", d->vr_H, d->vr_W);
+        FS_REQUIRE((long long)d->N * d->vr_H * d->vr_W * d->x_cs < (1ll << 40), FS_ERR_UNSUPPORTED, "fs_conv2d_fwd: tensor too large");
+        a.vr_H = d->vr_H; a.vr_W = d->vr_W; a.vr_relu = d->vr_relu ? 1 : 0;
+        a.vr_rh = d->H > 1 ? (float)(d->vr_H - 1) / (float)(d->H - 1) : 0.f;      // ATen: scale = (in-1)/(out-1), 0 when out == 1
+        a.vr_rw = d->W > 1 ? (float)(d->vr_W - 1) / (float)(d->W - 1) : 0.f;
+    }
     if (d->w_os == 0 && d->w_ts == 0) {
         a.w_os = a.K; a.w_tgap = 0;
     } else {          // filter = leading block of a wider resident pack

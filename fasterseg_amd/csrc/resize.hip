@@ -12,19 +12,6 @@
 
 namespace fs {
 
-struct Tap {
-    int i0, i1;
-    float l0, l1;
-};
-__device__ __forceinline__ Tap make_tap(float scale, int dst, int in_size) {
-    Tap t;
-    const float src = scale * (float)dst;
-    t.i0 = (int)src;
-    t.i1 = t.i0 + ((t.i0 < in_size - 1) ? 1 : 0);
-    t.l1 = src - (float)t.i0;
-    t.l0 = 1.f - t.l1;
-    return t;
-}
 static inline float host_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
 
 template <typename T>

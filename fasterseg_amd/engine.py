@@ -81,6 +81,7 @@ class InferenceEngine:
         self.input = torch.zeros(self.input_shape, dtype=torch.float32, device=self.device)
         self._keep = []            # tensors referenced by raw pointers in the plan
         self._trace(net)
+        self._fuse_resizes()
         self._assign_buffers()
         self._lower()
         self.graph = None
@@ -101,6 +102,41 @@ class InferenceEngine:
         assert isinstance(out, FN.SymTensor) and out.nchw, "network must end in the NCHW logits up-sample"
         self.ops = tracer.ops
         self.out_sym = out
+
+    # ---- 1b. fold bilinear resamples into the gather of the conv that consumes them -----------------------------
+    def _fuse_resizes(self):
+        """A zoomed conv is resize(1/2) -> conv [-> conv] -> resize(x2)+ReLU (operations.py:203-277,362-446) and the x2 map is
+        usually read by exactly one conv of the next cell.  On the maps where that happens every launch is latency-sized, so a
+        resize whose only consumer is an implicit-GEMM conv is not materialised: the conv interpolates its input on the fly
+        (fs_conv_desc.vr_*).  Measured: this only pays for 1x1 consumers - an implicit-GEMM 3x3 conv re-gathers (and would
+        re-interpolate) every input pixel for each of its 9 taps and each 32-wide output tile, which made the 14 fusable 3x3
+        convs of the student 6.7 us slower each while saving 3 us per resize (2197 -> 1929 fps) - so 3x3 consumers keep the
+        materialised resize unless FS_ENGINE_FUSE_RESIZE=2.  Resizes feeding a concat, several consumers or the logits stay
+        launches too."""
+        self.fused_resizes = 0
+        mode = int(os.environ.get("FS_ENGINE_FUSE_RESIZE", "1"))          # 0 off, 1 into 1x1 convs, 2 into any implicit-GEMM conv
+        if not mode:
+            return
+        consumers = {}
+        for idx, op in enumerate(self.ops):
+            for s_ in (op["inputs"] if op["kind"] == "cat" else [op["x"]]):
+                consumers.setdefault(s_.id, []).append(idx)
+        for rop in self.ops:
+            if rop["kind"] != "resize" or rop["out_nchw"] or rop["out"] is self.out_sym:
+                continue
+            cons = consumers.get(rop["out"].id, [])
+            if len(cons) != 1:
+                continue
+            cop = self.ops[cons[0]]
+            if cop["kind"] != "conv" or cop.get("vres") is not None or (cop["k"] != 1 and mode < 2):
+                continue
+            N, C, H, W = rop["out"].shape
+            if cop["k"] == 3 and cop["stride"] == 1 and cop["pad"] == 1 and N * H * W >= self.halo_min_pixels:
+                continue                                     # that conv runs on the halo kernel
+            cop["vres"] = (H, W, bool(rop["relu"]))
+            cop["x"] = rop["x"]
+            rop["dead"] = True
+            self.fused_resizes += 1
 
     # ---- 2. buffers: one NHWC buffer per feature map; cat operands alias slices of the cat buffer ------
     def _new_buffer(self, N, H, W, cs, zero=False):
@@ -131,7 +167,7 @@ class InferenceEngine:
                 off += s.shape[1]
         for idx, op in enumerate(self.ops):
             out = op["out"]
-            if out.storage is not None:
+            if out.storage is not None or op.get("dead"):
                 continue
             N, C, H, W = out.shape
             if out.nchw:
@@ -167,10 +203,14 @@ class InferenceEngine:
         self._keep += [scale, shift]
         return scale, shift
 
-    def _add_conv(self, x, out, weight, scale, shift, k, stride, pad, relu, cout, cin, out_off=0, label="conv"):
+    def _add_conv(self, x, out, weight, scale, shift, k, stride, pad, relu, cout, cin, out_off=0, label="conv", vres=None):
         N, _, H, W = x.shape
+        src_hw = None
+        if vres is not None:                      # x is the un-resampled source; the conv reads its (H, W) resampling
+            src_hw, (H, W) = (H, W), vres[:2]
+            label = "%s[<-%dx%d%s]" % (label, src_hw[0], src_hw[1], "+relu" if vres[2] else "")
         _, _, Ho, Wo = out.shape
-        use_halo = (k == 3 and stride == 1 and pad == 1 and N * H * W >= self.halo_min_pixels)
+        use_halo = (k == 3 and stride == 1 and pad == 1 and N * H * W >= self.halo_min_pixels and vres is None)
         if use_halo:        # LDS-halo 3x3 kernel with the fragment-packed filter bank
             wp = K.pack_weight_frag(weight.detach().to(self.device), self.dtype, cout, cin)
         else:
@@ -180,10 +220,13 @@ class InferenceEngine:
         yp, y_cs = self._ptr(out)
         yp += out_off * (2 if self.dtype == torch.bfloat16 else 4)
         d = ConvDesc(N, H, W, cin, cout, k, k, stride, pad, Ho, Wo, x_cs, y_cs, K.dtype_code(self.dtype), FS_CONV_RELU if relu else 0)
+        if vres is not None:
+            d.vr_H, d.vr_W, d.vr_relu = src_hw[0], src_hw[1], int(vres[2])
         self._keep.append(d)
         es = 2 if self.dtype == torch.bfloat16 else 4
         flops = 2.0 * N * Ho * Wo * cout * cin * k * k
-        nbytes = es * (N * H * W * cin + cout * cin * k * k + N * Ho * Wo * cout)
+        in_px = N * (src_hw[0] * src_hw[1] if src_hw else H * W)
+        nbytes = es * (in_px * cin + cout * cin * k * k + N * Ho * Wo * cout)
         args = (ctypes.byref(d), ctypes.c_void_p(xp), ctypes.c_void_p(wp.data_ptr()), K._p(scale), K._p(shift), ctypes.c_void_p(yp), None)
         self.calls.append(dict(fn="fs_conv3x3_s1_fwd" if use_halo else "fs_conv2d_fwd", args=args, desc=d, family="conv%dx%d" % (k, k), flops=flops, bytes=nbytes,
                                label="%s %dx%d s%d %d->%d @%dx%d" % (label, k, k, stride, cin, cout, H, W)))
@@ -197,6 +240,8 @@ class InferenceEngine:
         self._sym_ready = {}
         es = 2 if self.dtype == torch.bfloat16 else 4
         for idx, op in enumerate(self.ops):
+            if op.get("dead"):
+                continue
             kind, out = op["kind"], op["out"]
             first_call = len(self.calls)
             in_syms = op["inputs"] if kind == "cat" else [op["x"]]
@@ -217,7 +262,7 @@ class InferenceEngine:
             elif kind == "conv":
                 scale, shift = self._fold(op["bn"], op["bias"], op["cout"])
                 self._add_conv(op["x"], out, op["weight"], scale, shift, op["k"], op["stride"], op["pad"], op["relu"], op["cout"],
-                               op["cin"])
+                               op["cin"], vres=op.get("vres"))
             elif kind == "fr":
                 half = op["half"]
                 for j, (w, pad) in enumerate(((op["w1"], 0), (op["w2"], -1))):

@@ -213,14 +213,17 @@ def conv_desc(x_shape, x_cs, cout, R, S, stride, pad, y_cs, dtype, flags=0, out_
 
 
 def conv2d(x, w_packed, cout, R, S, stride, pad, scale=None, shift=None, relu=False, out=None, stats=None,
-           transposed=False, out_hw=None, w_strides=None, workspace=True):
+           transposed=False, out_hw=None, w_strides=None, workspace=True, vres=None):
     """y = relu?(conv(x, w) * scale + shift); `out` may be a channel slice of a wider NHWC buffer.  w_strides = (row, tap)
     element strides when the filter is the leading block of a wider packed bank; workspace=False keeps the whole contraction
-    in one block per tile (no cross-block split-K)."""
+    in one block per tile (no cross-block split-K).  vres = (H, W, relu): the convolution reads x bilinearly resampled
+    (align_corners=True, optional ReLU after the interpolation) to H x W without materialising that map."""
     x_cs = require_nhwc(x, "x")
     N, Cin, H, W = x.shape
     flags = (FS_CONV_RELU if relu else 0) | (FS_CONV_TRANSPOSED if transposed else 0)
-    d = conv_desc(x.shape, x_cs, cout, R, S, stride, pad, 0, x.dtype, flags, out_hw)
+    d = conv_desc((N, Cin, vres[0], vres[1]) if vres else x.shape, x_cs, cout, R, S, stride, pad, 0, x.dtype, flags, out_hw)
+    if vres:
+        d.vr_H, d.vr_W, d.vr_relu = H, W, int(bool(vres[2]))
     if out is None:
         out = empty_nhwc(N, cout, d.Ho, d.Wo, x.dtype, x.device)
     else:

@@ -48,6 +48,11 @@ typedef struct fs_conv_desc {
     int w_os, w_ts;         /* filter strides in elements: row (per output channel) and tap.  0,0 = the dense
                                [Cout][R][S][Cin] pack; otherwise the filter is the leading [:Cout][..][:Cin] block of
                                a wider resident pack (USConv2d slices read in place, slimmable_ops.py:42)         */
+    int vr_H, vr_W;         /* virtual resize (fs_conv2d_fwd[_ws] only): when > 0, x is a (N, vr_H, vr_W, Cin) map and the
+                               convolution reads its bilinear (align_corners=True) resampling to (H, W), with ReLU after the
+                               interpolation if vr_relu - the F.interpolate of the zoomed convs (operations.py:271,275,437,444)
+                               folded into the gather instead of materialised by fs_bilinear_fwd                 */
+    int vr_relu;
 } fs_conv_desc;
 
 typedef struct fs_resize_desc {

@@ -390,6 +390,38 @@ def test_conv_split_k_matches_single_pass(shape, relu, dtype):
     assert torch.allclose(stats[0], stats[1], atol=1e-2 * cnt ** 0.5, rtol=2e-3)
 
 
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("cfg", [-1, 3, 4, 5, 6])
+@pytest.mark.parametrize("case", [((2, 32, 18, 40), (9, 20), False, 3, 1), ((1, 64, 8, 12), (16, 24), True, 3, 1),
+                                  ((2, 40, 7, 9), (14, 18), True, 1, 0), ((1, 32, 33, 17), (16, 8), False, 3, 1)],
+                         ids=["down", "up_relu", "up_1x1", "down_odd"])
+def test_conv_virtual_resize(case, cfg, dtype):
+    """fs_conv_desc.vr_*: conv(F.interpolate(x, size, bilinear, align_corners=True) [-> ReLU]) with the resampling folded
+    into the gather == the two-launch path (the resampled map is rounded to the storage dtype in both)."""
+    from fasterseg_amd import _lib
+    k = K()
+    (N, C, Hs, Ws), (Hv, Wv), vrelu, ksz, pad = case
+    cout = 48
+    x = q(rnd(N, C, Hs, Ws, seed=80), dtype)
+    w = q(rnd(cout, C, ksz, ksz, seed=81) * (2.0 / (ksz * ksz * C)) ** 0.5, dtype)
+    scale, shift = rnd(cout, seed=82).abs() + 0.5, rnd(cout, seed=83)
+    mid = F.interpolate(x, size=(Hv, Wv), mode="bilinear", align_corners=True)
+    mid = q(F.relu(mid) if vrelu else mid, dtype)
+    want = F.relu(F.conv2d(mid, w, padding=pad) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    xd = k.to_nhwc(x.cuda(), dtype)
+    wp = k.pack_weight(w.cuda(), dtype)
+    _lib.lib().fs_debug_force_conv_cfg(cfg)
+    try:
+        got = k.conv2d(xd, wp, cout, ksz, ksz, 1, pad, scale.cuda(), shift.cuda(), True, vres=(Hv, Wv, vrelu))
+        two = k.conv2d(k.bilinear(xd, (Hv, Wv), relu=vrelu), wp, cout, ksz, ksz, 1, pad, scale.cuda(), shift.cuda(), True)
+    finally:
+        _lib.lib().fs_debug_force_conv_cfg(-1)
+    assert got.shape == (N, cout, Hv, Wv)
+    check(got, want, dtype, "virtual-resize conv vs CPU")
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert float((got.float() - two.float()).abs().max()) <= tol * max(1.0, float(want.abs().max()))
+
+
 def test_bn_finalize_counter_and_fused_param_grad_accumulation():
     """num_batches_tracked is bumped by fs_bn_finalize; fs_bn_bwd_apply adds dgamma/dbeta into the given buffers."""
     k = K()
