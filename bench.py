@@ -165,9 +165,10 @@ def run_student_infer(args, world, rank):
         "config": {"workload": "student fps: searched arch_1 (eval build, branches 1/32+1/16) inference %dx3x%dx%d, 19 classes, "
                                "fp32 logits at input resolution" % (shape[0], shape[2], shape[3]),
                    "weights": "random kaiming init, seed 12345", "parallelism": "replicas x%d (no collective)" % world,
-                   "engine": "static plan of %d launches in one hipGraph (%d stream lanes; candidate instantiations timed at "
-                             "build, ms/frame: %s)" % (len(eng.calls), getattr(eng, "graph_lanes", 1),
-                                                       getattr(eng, "capture_log", [])),
+                   "engine": "static plan of %d launches in one hipGraph (%d stream lanes; %d duplicate resamples shared, %d folded "
+                             "into 1x1 convs; candidate instantiations timed at build, ms/frame: %s)" % (
+                                 len(eng.calls), getattr(eng, "graph_lanes", 1), eng.shared_resizes, eng.fused_resizes,
+                                 getattr(eng, "capture_log", [])),
                    "vs_baseline_note": "per-GPU fps / 163.9 FPS published on GTX 1080Ti+TensorRT fp32 (nearest-resample "
                                        "latency/ variant); this run is the bilinear train/ network"},
         "alg_gflop_per_frame": round(eng.total_flops / batch / 1e9, 3), "alg_mb_per_frame": round(eng.total_bytes / batch / 1e6, 1),

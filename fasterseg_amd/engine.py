@@ -114,15 +114,36 @@ class InferenceEngine:
         materialised resize unless FS_ENGINE_FUSE_RESIZE=2.  Resizes feeding a concat, several consumers or the logits stay
         launches too."""
         self.fused_resizes = 0
+        self.shared_resizes = 0
+        # identical resamples of one feature map (two cells zooming the same input) are computed once
+        seen = {}
+        for rop in self.ops:
+            if rop["kind"] != "resize" or rop["out_nchw"]:
+                continue
+            key = (rop["x"].id, tuple(rop["out"].shape), bool(rop["relu"]))
+            first = seen.setdefault(key, rop)
+            if first is rop:
+                continue
+            dup, keep = rop["out"], first["out"]
+            for op in self.ops:
+                if op["kind"] == "cat":
+                    op["inputs"] = [keep if s_ is dup else s_ for s_ in op["inputs"]]
+                elif op.get("x") is dup:
+                    op["x"] = keep
+            if dup is not self.out_sym:
+                rop["dead"] = True
+                self.shared_resizes += 1
         mode = int(os.environ.get("FS_ENGINE_FUSE_RESIZE", "1"))          # 0 off, 1 into 1x1 convs, 2 into any implicit-GEMM conv
         if not mode:
             return
         consumers = {}
         for idx, op in enumerate(self.ops):
+            if op.get("dead"):
+                continue
             for s_ in (op["inputs"] if op["kind"] == "cat" else [op["x"]]):
                 consumers.setdefault(s_.id, []).append(idx)
         for rop in self.ops:
-            if rop["kind"] != "resize" or rop["out_nchw"] or rop["out"] is self.out_sym:
+            if rop["kind"] != "resize" or rop["out_nchw"] or rop["out"] is self.out_sym or rop.get("dead"):
                 continue
             cons = consumers.get(rop["out"].id, [])
             if len(cons) != 1:
