@@ -1,8 +1,56 @@
-"""Step glue that stays on PyTorch ops (not part of the conv hot path, used as-is so the backward
-signal of the benchmarked steps matches the reference): OHEM cross-entropy and the KL distillation term."""
+"""Losses of the train steps: OHEM cross-entropy and the KL distillation term.
+
+On CPU tensors both are the reference's own PyTorch op chain.  On the GPU the OHEM criterion runs on two HIP kernels
+(fs_ohem_ce_fwd / fs_ohem_ce_bwd): at 12 x 19 x 512 x 1024 the logits are 478 MB per head and the ATen chain (softmax,
+transposed copy, log_softmax, nll and their backwards) moves that tensor about ten times per head and synchronises the
+host twice; the fused form reads it once forward and once backward and keeps the threshold logic on the device."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+
+class _OhemCE(torch.autograd.Function):
+    """loss = mean over kept pixels of -log softmax(pred)[target];  kept = valid & (p_target <= max(thresh, k-th smallest
+    p_target)) when at least min_kept pixels are valid, else kept = valid (loss_opr.py:70-93)."""
+
+    @staticmethod
+    def forward(ctx, pred, target, thresh, min_kept, ignore):
+        from . import kernels as K
+        B, C, H, W = pred.shape
+        HW, P = H * W, B * H * W
+        logits = pred.detach().contiguous()
+        tgt = target.reshape(-1).contiguous()
+        buf = torch.empty((3, P), dtype=torch.float32, device=pred.device)
+        true_prob, nll, lse = buf[0], buf[1], buf[2]
+        K.call("fs_ohem_ce_fwd", K._stream(), logits.data_ptr(), tgt.data_ptr(), B, C, HW, int(ignore), true_prob.data_ptr(),
+               nll.data_ptr(), lse.data_ptr())
+        valid = tgt.ne(ignore)
+        num_valid = valid.sum()
+        kept = valid
+        if min_kept > 0 or thresh < 1.0:
+            threshold = torch.full((), float(thresh), dtype=torch.float32, device=pred.device)
+            if min_kept > 0:
+                kth = torch.sort(true_prob).values[min(P, min_kept) - 1]
+                threshold = torch.maximum(threshold, kth)
+            # OHEM only applies when enough valid pixels exist (loss_opr.py:74-76); decided on the device, no host sync
+            apply = (num_valid >= min_kept) & (num_valid > 0)
+            kept = valid & (true_prob.le(threshold) | ~apply)
+        count = kept.sum()
+        loss = (nll * kept).sum() / count
+        ctx.save_for_backward(logits, tgt, lse, kept.to(torch.uint8), count)
+        ctx.shape = (B, C, H, W)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import kernels as K
+        logits, tgt, lse, kept, count = ctx.saved_tensors
+        B, C, H, W = ctx.shape
+        scale = (g.float() / count).reshape(1).contiguous()
+        d = torch.empty_like(logits)
+        K.call("fs_ohem_ce_bwd", K._stream(), logits.data_ptr(), tgt.data_ptr(), lse.data_ptr(), kept.data_ptr(), scale.data_ptr(),
+               B, C, H * W, d.data_ptr())
+        return d, None, None, None, None
 
 
 class ProbOhemCrossEntropy2d(nn.Module):
@@ -20,6 +68,8 @@ class ProbOhemCrossEntropy2d(nn.Module):
         self.criterion = nn.CrossEntropyLoss(reduction=reduction, ignore_index=ignore_label)
 
     def forward(self, pred, target):
+        if pred.is_cuda and pred.dtype == torch.float32 and self.criterion.reduction == "mean" and target.dtype == torch.long:
+            return _OhemCE.apply(pred, target, self.thresh, self.min_kept, self.ignore_label)
         b, c, h, w = pred.size()
         flat = target.reshape(-1)
         valid = flat.ne(self.ignore_label)

@@ -246,6 +246,17 @@ fs_status fs_sgd_momentum_multi(void* stream, const fs_sgd_tensor* tensors, cons
                                 const float* grad_scale, float lr, float momentum, float weight_decay, int pack_dtype,
                                 int pack_only);
 
+/* --- OHEM cross-entropy on NCHW fp32 logits ------------------------- */
+/* Forward pass of ProbOhemCrossEntropy2d (tools/seg_opr/loss_opr.py:63-93) without materialising softmax / log_softmax:
+ * per pixel p of the (B, C, HW) logits: lse[p] = logsumexp_c, nll[p] = lse - logit[target] (0 for ignored pixels),
+ * true_prob[p] = softmax probability of the target class (1 for ignored pixels).  The caller picks the hard-example
+ * threshold from true_prob and reduces nll over the kept pixels. */
+fs_status fs_ohem_ce_fwd(void* stream, const float* logits, const long long* target, long long B, int C, long long HW, int ignore,
+                         float* true_prob, float* nll, float* lse);
+/* dlogits[b][c][hw] = kept[p] ? (exp(logit - lse[p]) - [c == target[p]]) * (*scale) : 0   (scale: device scalar) */
+fs_status fs_ohem_ce_bwd(void* stream, const float* logits, const long long* target, const float* lse, const unsigned char* kept,
+                         const float* scale, long long B, int C, long long HW, float* dlogits);
+
 /* --- command-list executor ------------------------------------------------------------------------ */
 /* Replays a pre-built sequence of the launches above from one host call (csrc/program.hip describes the word encoding).
  * A supernet MixedOp (model_search.py:46-99) with given widths is a fixed sequence of ~60 launches forward and ~90
