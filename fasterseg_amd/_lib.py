@@ -61,6 +61,8 @@ SIGNATURES = {
     "fs_weighted_sum_dots": [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_vp],
     "fs_ohem_ce_fwd": [c_vp, c_vp, c_vp, c_ll, c_int, c_ll, c_int, c_vp, c_vp, c_vp],
     "fs_ohem_ce_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_int, c_ll, c_vp],
+    "fs_kl_distill_fwd": [c_vp, c_vp, c_vp, c_ll, c_int, c_ll, c_vp, c_vp, c_vp],
+    "fs_kl_distill_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_int, c_ll, c_vp],
     "fs_exec_program": [c_vp, c_vp, c_ll, c_vp, c_vp, c_int],
     "fs_exec_program_streams": [c_vp, c_int, c_vp, c_ll, c_vp, c_vp, c_int],
     "fs_sgd_momentum_multi": [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_float, c_float, c_float, c_int, c_int],

@@ -93,6 +93,36 @@ class ProbOhemCrossEntropy2d(nn.Module):
         return self.criterion(pred, flat.view(b, h, w))
 
 
+class _DistillKL(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, student, teacher):
+        from . import kernels as K
+        B, C, H, W = student.shape
+        P = B * H * W
+        s, t = student.detach().contiguous(), teacher.detach().contiguous()
+        buf = torch.empty((3, P), dtype=torch.float32, device=s.device)
+        K.call("fs_kl_distill_fwd", K._stream(), s.data_ptr(), t.data_ptr(), B, C, H * W, buf[0].data_ptr(), buf[1].data_ptr(),
+               buf[2].data_ptr())
+        ctx.save_for_backward(s, t, buf)
+        ctx.dims = (B, C, H * W)
+        return buf[0].sum() / (P * C)
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import kernels as K
+        s, t, buf = ctx.saved_tensors
+        B, C, HW = ctx.dims
+        scale = (g.float() / (B * C * HW)).reshape(1).contiguous()
+        d = torch.empty_like(s)
+        K.call("fs_kl_distill_bwd", K._stream(), s.data_ptr(), t.data_ptr(), buf[1].data_ptr(), buf[2].data_ptr(), scale.data_ptr(),
+               B, C, HW, d.data_ptr())
+        return d, None
+
+
 def distill_kl(student_logits, teacher_logits):
-    """nn.KLDivLoss()(softmax(student).log(), softmax(teacher)) with the default 'mean' reduction (train/train.py:64,260)."""
+    """nn.KLDivLoss()(softmax(student).log(), softmax(teacher)) with the default 'mean' reduction (train/train.py:64,260).
+    CUDA fp32 logits take the two-kernel fused form (the teacher receives no gradient, as in the reference's no_grad forward)."""
+    if (student_logits.is_cuda and student_logits.dtype == torch.float32 and teacher_logits.dtype == torch.float32
+            and student_logits.shape == teacher_logits.shape and not teacher_logits.requires_grad):
+        return _DistillKL.apply(student_logits, teacher_logits)
     return F.kl_div(F.log_softmax(student_logits, dim=1), F.softmax(teacher_logits, dim=1), reduction='mean')

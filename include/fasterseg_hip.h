@@ -257,6 +257,14 @@ fs_status fs_ohem_ce_fwd(void* stream, const float* logits, const long long* tar
 fs_status fs_ohem_ce_bwd(void* stream, const float* logits, const long long* target, const float* lse, const unsigned char* kept,
                          const float* scale, long long B, int C, long long HW, float* dlogits);
 
+/* KL distillation term nn.KLDivLoss()(log_softmax(student), softmax(teacher)) (train/train.py:64,260) on (B, C, HW) fp32
+ * logits: kl[p] = sum_c p_t (log p_t - log p_s) per pixel plus both log-sum-exps; the caller sums kl and divides by the
+ * element count ('mean' reduction).  Backward: d_student = (softmax(student) - softmax(teacher)) * (*scale). */
+fs_status fs_kl_distill_fwd(void* stream, const float* student, const float* teacher, long long B, int C, long long HW,
+                            float* kl, float* lse_s, float* lse_t);
+fs_status fs_kl_distill_bwd(void* stream, const float* student, const float* teacher, const float* lse_s, const float* lse_t,
+                            const float* scale, long long B, int C, long long HW, float* d_student);
+
 /* --- command-list executor ------------------------------------------------------------------------ */
 /* Replays a pre-built sequence of the launches above from one host call (csrc/program.hip describes the word encoding).
  * A supernet MixedOp (model_search.py:46-99) with given widths is a fixed sequence of ~60 launches forward and ~90

@@ -33,3 +33,18 @@ def test_fused_ohem_matches_torch_chain(case):
     pred_t = pred.detach().cuda().permute(0, 1, 3, 2).contiguous().permute(0, 1, 3, 2).requires_grad_(True)
     (crit(pred_t, target.cuda()) * 0.2).backward()
     assert float((pred_t.grad.cpu() - 0.2 * pred.grad).abs().max()) <= 1e-6 + 1e-4 * float(pred.grad.abs().max())
+
+
+def test_fused_kl_distillation_matches_torch_chain():
+    from fasterseg_amd.losses import distill_kl
+    g = torch.Generator().manual_seed(6)
+    s = (torch.randn(2, 19, 24, 40, generator=g) * 2.0).requires_grad_(True)
+    t = torch.randn(2, 19, 24, 40, generator=g) * 3.0
+    ref = distill_kl(s, t)
+    ref.backward()
+    sd = s.detach().cuda().requires_grad_(True)
+    got = distill_kl(sd, t.cuda())
+    assert type(got.grad_fn).__name__ == "_DistillKLBackward"
+    (got * 3.0).backward()
+    assert abs(float(got) - float(ref)) <= 1e-5 * abs(float(ref)) + 1e-8
+    assert float((sd.grad.cpu() - 3.0 * s.grad).abs().max()) <= 1e-9 + 1e-4 * float(s.grad.abs().max()) * 3.0
