@@ -1,13 +1,21 @@
 """bench.py — headline benchmark of the FasterSeg hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|fp32] [--workload student_infer|student_train]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|fp32]
+                    [--workload student_infer|student_train|supernet_pretrain|supernet_search]
 
 Default workload = BASELINE.json configs[1]: searched student (arch_1) inference at 1x3x1024x2048, bf16 storage /
-fp32 accumulate, one frame per step, input already resident in HBM, whole forward replayed from one hipGraph
-(fasterseg_amd.engine).  N>1 (launched by torch.distributed.run, one rank per GPU) runs one replica per GPU — inference
-does not shard, so there is no data-path collective; value = frames of all ranks / max-over-ranks time ("weak").
-`--workload student_train` runs BASELINE configs[3]-shaped student KL-distillation steps (teacher eval forward + student
-train forward/backward + RCCL gradient all-reduce + SGD) and reports images/s.
+fp32 accumulate, one frame per step, input already resident in HBM, the whole forward replayed from one hipGraph
+(fasterseg_amd.engine; the engine times a few instantiations of the plan at build and keeps the fastest, the candidates
+are listed in config.engine).  N>1 (launched by torch.distributed.run, one rank per GPU) runs one replica per GPU —
+inference does not shard, so there is no data-path collective; value = frames of all ranks / max-over-ranks time ("weak").
+
+The other workloads are the train steps of BASELINE configs[2..4] restated in fasterseg_amd/train_step.py (images/s):
+  student_train      teacher eval forward (engine) + student train forward/backward (3 heads, fused OHEM-CE + KL) + RCCL
+                     all-reduce of the flat gradient buffer + one-launch SGD, 12 x 3x512x1024 per GPU
+  supernet_pretrain  `_loss(pretrain=True)`: max / min / random / random width passes + clip + SGD, 3 x 3x256x512
+  supernet_search    Architect.step on a search batch + the weight step, 2 x 3x224x448 per GPU
+--dtype selects the activation / MFMA operand type of all of them (bf16: fp32 accumulate, fp32 BN statistics, fp32 master
+weights and parameter gradients; fp32: exact-fp32 MFMA).
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel family of the step, from per-launch HIP-event
 timings taken live on the launch stream (engine.profile()); `cpu_baseline` is the CPU oracle (oracle/ref_ops.py, a

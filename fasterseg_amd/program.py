@@ -24,7 +24,6 @@ import struct
 
 import torch
 
-from . import _lib
 from . import kernels as K
 from ._lib import ConvDesc, ResizeDesc
 
