@@ -465,7 +465,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 constexpr long long SPLITK_TARGET_BLOCKS = 1024;
 
 // Number of K slices for a 32x32-tile config with `bkt` K elements per iteration (1 = do not split).  Measured on MI355X
-// (scratch/conv_sweep.py): the second launch and the partial-tile traffic only pay off when the tiles cover well under
+// (tools/conv_sweep.py): the second launch and the partial-tile traffic only pay off when the tiles cover well under
 // half of the CUs AND the contraction is long - e.g. 384->384 on a 4x8 map (36 tiles, K = 3456): 39.6 -> 14.9 us fp32;
 // with ~150-300 tiles the single-pass kernel is as fast or faster.
 static inline int splitk_slices(const ConvArgs& a, int bkt) {
