@@ -77,6 +77,10 @@ class InferenceEngine:
         self.vec = K.vec_of(dtype)
         # 3x3/s1 layers with at least this many output pixels run on the LDS-halo kernel (conv3x3_halo.hip)
         self.halo_min_pixels = int(os.environ.get("FS_HALO_MIN_PIXELS", halo_min_pixels))
+        # per-layer halo vs implicit-GEMM choice by timing both at build: measured on the student it moves 7 layers and
+        # saves ~6 us of 447 per frame - within run-to-run noise - so it is opt-in
+        self.autotune = bool(int(os.environ.get("FS_ENGINE_AUTOTUNE", "0")))
+        self.autotuned = []
         self.n_lanes = max(1, int(os.environ.get("FS_ENGINE_LANES", lanes)))
         self.input = torch.zeros(self.input_shape, dtype=torch.float32, device=self.device)
         self._keep = []            # tensors referenced by raw pointers in the plan
@@ -231,12 +235,8 @@ class InferenceEngine:
             src_hw, (H, W) = (H, W), vres[:2]
             label = "%s[<-%dx%d%s]" % (label, src_hw[0], src_hw[1], "+relu" if vres[2] else "")
         _, _, Ho, Wo = out.shape
-        use_halo = (k == 3 and stride == 1 and pad == 1 and N * H * W >= self.halo_min_pixels and vres is None)
-        if use_halo:        # LDS-halo 3x3 kernel with the fragment-packed filter bank
-            wp = K.pack_weight_frag(weight.detach().to(self.device), self.dtype, cout, cin)
-        else:
-            wp = K.pack_weight(weight.detach().to(self.device), self.dtype, cout, cin)
-        self._keep.append(wp)
+        halo_ok = k == 3 and stride == 1 and pad == 1 and vres is None
+        use_halo = halo_ok and N * H * W >= self.halo_min_pixels
         xp, x_cs = self._ptr(x)
         yp, y_cs = self._ptr(out)
         yp += out_off * (2 if self.dtype == torch.bfloat16 else 4)
@@ -244,13 +244,56 @@ class InferenceEngine:
         if vres is not None:
             d.vr_H, d.vr_W, d.vr_relu = src_hw[0], src_hw[1], int(vres[2])
         self._keep.append(d)
+
+        def variant(halo):
+            if halo:        # LDS-halo 3x3 kernel with the fragment-packed filter bank
+                wp = K.pack_weight_frag(weight.detach().to(self.device), self.dtype, cout, cin)
+            else:
+                wp = K.pack_weight(weight.detach().to(self.device), self.dtype, cout, cin)
+            args = (ctypes.byref(d), ctypes.c_void_p(xp), ctypes.c_void_p(wp.data_ptr()), K._p(scale), K._p(shift), ctypes.c_void_p(yp), None)
+            return "fs_conv3x3_s1_fwd" if halo else "fs_conv2d_fwd", args, wp
+        fn, args, wp = variant(use_halo)
+        # near the threshold neither kernel wins consistently (the halo kernel needs enough tiles, the implicit GEMM re-gathers
+        # every pixel nine times): time both on the device and keep the faster one for this layer
+        if halo_ok and self.autotune and self.halo_min_pixels // 8 <= N * H * W <= self.halo_min_pixels * 4:
+            other = variant(not use_halo)
+            t_cur, t_other = self._time_call(fn, args), self._time_call(other[0], other[1])
+            self.autotuned.append((label, N * H * W, cin, cout, fn, round(t_cur * 1e3, 2), round(t_other * 1e3, 2)))
+            if t_other < 0.97 * t_cur:
+                fn, args, wp = other
+        self._keep.append(wp)
         es = 2 if self.dtype == torch.bfloat16 else 4
         flops = 2.0 * N * Ho * Wo * cout * cin * k * k
         in_px = N * (src_hw[0] * src_hw[1] if src_hw else H * W)
         nbytes = es * (in_px * cin + cout * cin * k * k + N * Ho * Wo * cout)
-        args = (ctypes.byref(d), ctypes.c_void_p(xp), ctypes.c_void_p(wp.data_ptr()), K._p(scale), K._p(shift), ctypes.c_void_p(yp), None)
-        self.calls.append(dict(fn="fs_conv3x3_s1_fwd" if use_halo else "fs_conv2d_fwd", args=args, desc=d, family="conv%dx%d" % (k, k), flops=flops, bytes=nbytes,
+        self.calls.append(dict(fn=fn, args=args, desc=d, family="conv%dx%d" % (k, k), flops=flops, bytes=nbytes,
                                label="%s %dx%d s%d %d->%d @%dx%d" % (label, k, k, stride, cin, cout, H, W)))
+
+    def _time_call(self, fn, args, reps=20):
+        """Device time (ms) of one launch, replayed back-to-back from a small hipGraph (same method as profile())."""
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            st = ctypes.c_void_p(side.cuda_stream)
+            call(fn, st, *args)
+            side.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+                for _ in range(reps):
+                    call(fn, st, *args)
+            g.replay()
+            best = None
+            for _ in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                g.replay()
+                e1.record()
+                e1.synchronize()
+                t = e0.elapsed_time(e1) / reps
+                best = t if best is None or t < best else best
+        torch.cuda.current_stream().wait_stream(side)
+        return best
 
     def _ready(self, sym):
         """call indices that must have completed before `sym` is fully written"""
