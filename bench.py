@@ -41,8 +41,8 @@ PUBLISHED_STUDENT_FPS = 163.9                        # BASELINE.md §1 (GTX 1080
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 1000 inference frames / 10 train steps)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default: 100 inference / 3 train)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--workload", default="student_infer", choices=["student_infer", "student_train", "supernet_pretrain", "supernet_search"])
     ap.add_argument("--height", type=int, default=1024)
@@ -52,7 +52,13 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU budget of the cpu_baseline sample")
     ap.add_argument("--dump-plan", default=None, help="write the per-launch table (json) here")
-    return ap.parse_args()
+    args = ap.parse_args()
+    infer = args.workload == "student_infer"
+    if args.steps is None:
+        args.steps = 1000 if infer else 10
+    if args.warmup is None:
+        args.warmup = 100 if infer else 3
+    return args
 
 
 def dist_setup(args):
