@@ -14,4 +14,4 @@ void set_error(const char* fmt, ...) {
 }  // namespace fs
 
 extern "C" const char* fs_last_error(void) { return fs::g_err; }
-extern "C" int fs_version(void) { return 100; }
+extern "C" int fs_version(void) { return 130; }

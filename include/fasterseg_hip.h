@@ -65,7 +65,7 @@ typedef struct fs_resize_desc {
 
 const char* fs_last_error(void);
 int fs_version(void);
-/* test hook: force the tile configuration of fs_conv2d_fwd (0..5; -1 = heuristic).  Not for production use. */
+/* test hook: force the tile configuration of fs_conv2d_fwd (0..6; -1 = heuristic).  Not for production use. */
 void fs_debug_force_conv_cfg(int cfg);
 /* number of elements of a packed filter bank for (Cout,R,S,Cin) */
 long long fs_packed_weight_elems(int Cout, int R, int S, int Cin);
