@@ -90,6 +90,45 @@ def test_mixed_op_lowering_structure(stride, want_w):
     assert prog.valid()
 
 
+def test_lowering_reads_resident_packs_in_place():
+    """With packed copies registered for every filter (what optim.FlatSGD does) the programs contain no fs_pack_weight
+    commands and the conv descriptors carry the row / tap strides of the full-size packs."""
+    import ctypes
+    from fasterseg_amd import functional as FN
+    from fasterseg_amd._lib import ConvDesc
+    torch.manual_seed(0)
+    m = model_search.MixedOp(48, 48, stride=1, width_mult_list=WIDTHS).train()
+    for p in m.parameters():
+        p.requires_grad_(False)
+    packs = []
+    for p in m.parameters():
+        if p.dim() == 4:
+            O, I, R, S = p.shape
+            fwd, flip = torch.zeros(O, R, S, I), torch.zeros(I, R, S, O)
+            packs.append((fwd, flip))
+            FN.register_resident_pack(p, fwd, flip)
+    m.set_prun_ratio((8. / 12, 10. / 12))
+    prog = program.lower_mixed_op(m, (2, 32, 16, 24), 32, torch.float32, torch.device("cpu"), need_x=True, need_coef=True,
+                                  want_w=False, sink=None)
+    fwd = decode(prog.f_words, prog.f_n, {program.SAVE: prog.save_bytes, program.TMPF: prog.tmpf_bytes})
+    bwd = decode(prog.b_words, prog.b_n, {program.SAVE: prog.save_bytes, program.TMPB: prog.tmpb_bytes})
+    assert all(op != program.OP_PACK_WEIGHT for op, _ in fwd + bwd)
+    units = [args for op, args in fwd if op == program.OP_UNIT_FWD]
+    assert len(units) == 7
+    blob = bytes(prog.f_blob)
+    for args in units:
+        d = ConvDesc.from_buffer_copy(blob[args[0][1]:args[0][1] + ctypes.sizeof(ConvDesc)])
+        assert d.w_ts == 48 and d.w_os == d.R * d.S * 48 and d.Cin in (32, 40) and d.Cout == 40       # full-width pack, sliced conv
+    # an in-place edit of a parameter invalidates its pack: the next lowering packs that filter again
+    w = m._ops[1].conv1.weight
+    with torch.no_grad():
+        w.add_(0.0)
+    prog2 = program.lower_mixed_op(m, (2, 32, 16, 24), 32, torch.float32, torch.device("cpu"), need_x=True, need_coef=True,
+                                   want_w=False, sink=None)
+    ops2 = [op for op, _ in decode(prog2.f_words, prog2.f_n, {program.SAVE: prog2.save_bytes, program.TMPF: prog2.tmpf_bytes})]
+    assert ops2.count(program.OP_PACK_WEIGHT) == 1
+
+
 def test_executor_rejects_malformed_programs():
     """fs_exec_program validates before it launches: unknown ops / wrong arity are status codes, not crashes."""
     import ctypes
