@@ -21,6 +21,10 @@ class ConvDesc(ctypes.Structure):
                                      "x_cs", "y_cs", "dtype", "flags", "w_os", "w_ts", "vr_H", "vr_W", "vr_relu")]
 
 
+class ZoomDesc(ctypes.Structure):
+    _fields_ = [(n, c_int) for n in ("N", "H", "W", "Cin", "Cmid", "Cout", "h", "w", "Ho", "Wo", "x_cs", "y_cs", "dtype", "down", "up")]
+
+
 class ResizeDesc(ctypes.Structure):
     _fields_ = [(n, c_int) for n in ("N", "Hi", "Wi", "Ho", "Wo", "C", "x_cs", "y_cs", "dtype", "relu", "out_nchw")]
 
@@ -35,6 +39,7 @@ SIGNATURES = {
     "fs_conv2d_wgrad_strided": [c_vp, ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_ll, c_ll, c_ll],
     "fs_pack_weight_frag": [c_vp, c_vp, c_ll, c_ll, c_int, c_int, c_int, c_vp],
     "fs_conv3x3_s1_fwd": [c_vp, ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "fs_zoom_cell_fwd": [c_vp, ctypes.POINTER(ZoomDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "fs_conv_stem_fwd": [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int],
     "fs_bilinear_fwd": [c_vp, ctypes.POINTER(ResizeDesc), c_vp, c_vp],
     "fs_bilinear_bwd": [c_vp, ctypes.POINTER(ResizeDesc), c_vp, c_vp, c_vp],
@@ -74,6 +79,7 @@ _SPECIAL = {
     "fs_debug_force_conv_cfg": ([c_int], None),
     "fs_packed_weight_frag_elems": ([c_int, c_int, c_int], c_ll),
     "fs_sgd_chunk_elems": ([], c_int),
+    "fs_zoom_cell_supported": ([ctypes.POINTER(ZoomDesc)], c_int),
     "fs_event_create": ([], c_vp),
     "fs_event_destroy": ([c_vp], None),
 }

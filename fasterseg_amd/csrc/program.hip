@@ -200,6 +200,10 @@ extern "C" fs_status fs_exec_program_streams(void* const* streams, int n_streams
                 NEED(7);
                 st = fs_conv3x3_s1_fwd(stream, (const fs_conv_desc*)P(0), P(1), P(2), PF(3), PF(4), P(5), PF(6));
                 break;
+            case FS_OP_ZOOM_CELL:
+                NEED(9);
+                st = fs_zoom_cell_fwd(stream, (const fs_zoom_desc*)P(0), P(1), P(2), PF(3), PF(4), P(5), PF(6), PF(7), P(8));
+                break;
             case FS_OP_STEM:
                 NEED(12);
                 st = fs_conv_stem_fwd(stream, I(0), I(1), I(2), I(3), PF(4), PF(5), PF(6), PF(7), P(8), I(9), I(10), I(11));

@@ -68,7 +68,7 @@ class _Tracer:
 
 class InferenceEngine:
     def __init__(self, net, input_shape, dtype=torch.bfloat16, logits_dtype=torch.float32, device="cuda", use_graph=True,
-                 halo_min_pixels=16384, lanes=3):
+                 halo_min_pixels=16384, lanes=3, fuse_cells=None):
         assert not net.training, "call net.eval() first"
         self.dtype = dtype
         self.device = torch.device(device)
@@ -84,7 +84,12 @@ class InferenceEngine:
         self.n_lanes = max(1, int(os.environ.get("FS_ENGINE_LANES", lanes)))
         self.input = torch.zeros(self.input_shape, dtype=torch.float32, device=self.device)
         self._keep = []            # tensors referenced by raw pointers in the plan
+        # whole zoomed-conv cells (resize -> conv -> conv -> resize) as ONE launch (zoom_cell.hip): 0 off, 1 always when
+        # the geometry is supported, "auto" (default) = time the fused launch against the separate launches per cell at build
+        self.fuse_cells = os.environ.get("FS_ENGINE_FUSE_CELLS", "auto" if fuse_cells is None else str(fuse_cells))
+        self.cell_log = []
         self._trace(net)
+        self._fuse_cells()
         self._fuse_resizes()
         self._assign_buffers()
         self._lower()
@@ -107,6 +112,82 @@ class InferenceEngine:
         self.ops = tracer.ops
         self.out_sym = out
 
+    # ---- 1a. whole zoomed-conv cells -> one fused launch ---------------------------------------------------------------
+    def _consumers(self):
+        consumers = {}
+        for idx, op in enumerate(self.ops):
+            if op.get("dead"):
+                continue
+            for s_ in (op["inputs"] if op["kind"] == "cat" else [op["x"]]):
+                consumers.setdefault(s_.id, []).append(idx)
+        return consumers
+
+    def _fuse_cells(self):
+        """BasicResidual_downup_2x (operations.py:435-446) traces as resize(1/2) -> conv3x3+BN+ReLU -> conv3x3+BN ->
+        resize(x2)+ReLU (or, at stride 2, conv3x3+BN+ReLU with no up-sample); BasicResidual2x at stride 1 (:352-359) as
+        the two convs alone.  Each such chain whose intermediates have no other reader becomes one "zoom" op (zoom_cell.hip)."""
+        self.fused_cells = 0
+        if self.fuse_cells in ("0", "off"):
+            return
+        plain_too = bool(int(os.environ.get("FS_ENGINE_FUSE_PLAIN_2X", "1")))
+        consumers = self._consumers()
+        by_out = {op["out"].id: i for i, op in enumerate(self.ops)}
+
+        def is_c3(op):
+            return (op["kind"] == "conv" and op["k"] == 3 and op["stride"] == 1 and op["pad"] == 1 and op["bn"] is not None
+                    and op["bias"] is None and not op.get("dead"))
+        for ia, A in enumerate(self.ops):
+            if not is_c3(A) or not A["relu"] or A["out"] is self.out_sym:
+                continue
+            cons = consumers.get(A["out"].id, [])
+            if len(cons) != 1 or not is_c3(self.ops[cons[0]]):
+                continue
+            ib = cons[0]
+            B = self.ops[ib]
+            if B["cin"] != A["cout"] or B["cout"] != A["cout"]:
+                continue
+            # input side: a 1/2 resample feeding A?
+            src, down, r1 = A["x"], False, None
+            ir = by_out.get(A["x"].id)
+            if ir is not None and self.ops[ir]["kind"] == "resize":
+                R1 = self.ops[ir]
+                Hs, Ws = R1["x"].shape[2], R1["x"].shape[3]
+                if (not R1["relu"] and not R1["out_nchw"] and not R1.get("dead")
+                        and tuple(R1["out"].shape[2:]) == (Hs // 2, Ws // 2) and Hs % 2 == 0 and Ws % 2 == 0):
+                    src, down, r1 = R1["x"], True, ir
+            # output side: ReLU in conv2 (no up-sample) or resize(x2)+ReLU as its only reader
+            last, up = ib, False
+            if not B["relu"]:
+                cb = consumers.get(B["out"].id, [])
+                if len(cb) != 1 or B["out"] is self.out_sym:
+                    continue
+                R2 = self.ops[cb[0]]
+                h, w = B["out"].shape[2], B["out"].shape[3]
+                if not (R2["kind"] == "resize" and R2["relu"] and not R2["out_nchw"] and tuple(R2["out"].shape[2:]) == (2 * h, 2 * w)):
+                    continue
+                last, up = cb[0], True
+            if up and not down:
+                continue
+            if not down and not up and not plain_too:
+                continue
+            N, _, H, W = src.shape
+            d = K.zoom_desc((N, A["cin"], H, W), K.round_up(A["cin"], self.vec), A["cout"], B["cout"], down, up,
+                            K.round_up(B["cout"], self.vec), self.dtype)
+            if not K.zoom_cell_supported(d):
+                continue
+            out = self.ops[last]["out"]
+            chain = [dict(self.ops[i]) for i in ([r1] if down else []) + [ia, ib] + ([last] if up else [])]
+            zoom = dict(kind="zoom", out=out, x=src, A=A, B=B, down=down, up=up, chain=chain)
+            A["dead"] = B["dead"] = True
+            if up:
+                self.ops[last]["dead"] = True
+            self.ops[last] = zoom                      # out.producer keeps pointing at this index
+            if down and consumers.get(self.ops[r1]["out"].id, []) == [ia]:
+                self.ops[r1]["dead"] = True
+            self.fused_cells += 1
+            consumers = self._consumers()
+            by_out = {op["out"].id: i for i, op in enumerate(self.ops)}
+
     # ---- 1b. fold bilinear resamples into the gather of the conv that consumes them -----------------------------
     def _fuse_resizes(self):
         """A zoomed conv is resize(1/2) -> conv [-> conv] -> resize(x2)+ReLU (operations.py:203-277,362-446) and the x2 map is
@@ -122,7 +203,7 @@ class InferenceEngine:
         # identical resamples of one feature map (two cells zooming the same input) are computed once
         seen = {}
         for rop in self.ops:
-            if rop["kind"] != "resize" or rop["out_nchw"]:
+            if rop["kind"] != "resize" or rop["out_nchw"] or rop.get("dead"):
                 continue
             key = (rop["x"].id, tuple(rop["out"].shape), bool(rop["relu"]))
             first = seen.setdefault(key, rop)
@@ -184,7 +265,7 @@ class InferenceEngine:
             off = 0
             for s in op["inputs"]:
                 can_alias = (s.storage is None and s.producer is not None and off % self.vec == 0
-                             and self.ops[s.producer]["kind"] in ("conv", "resize", "stem", "fr") and not s.nchw)
+                             and self.ops[s.producer]["kind"] in ("conv", "resize", "stem", "fr", "zoom") and not s.nchw)
                 if can_alias:
                     s.storage = (bid, off)
                 else:
@@ -269,6 +350,97 @@ class InferenceEngine:
         self.calls.append(dict(fn=fn, args=args, desc=d, family="conv%dx%d" % (k, k), flops=flops, bytes=nbytes,
                                label="%s %dx%d s%d %d->%d @%dx%d" % (label, k, k, stride, cin, cout, H, W)))
 
+    # ---- 3a. a zoomed-conv cell: one fused launch, or (when that measures slower) its separate launches -----------------
+    def _tmp_sym(self, shape):
+        N, C, H, W = shape
+        sym = FN.SymTensor(shape, self.dtype)
+        bid = "tmp%d" % sym.id
+        self.buffers[bid] = self._new_buffer(N, H, W, K.round_up(C, self.vec))
+        sym.storage = (bid, 0)
+        return sym
+
+    def _resize_call(self, x, out, relu):
+        es = 2 if self.dtype == torch.bfloat16 else 4
+        N, C, Hi, Wi = x.shape
+        Ho, Wo = out.shape[2], out.shape[3]
+        xp, x_cs = self._ptr(x)
+        yp, y_cs = self._ptr(out)
+        d = ResizeDesc(N, Hi, Wi, Ho, Wo, C, x_cs, y_cs, K.dtype_code(self.dtype), int(relu), 0)
+        self._keep.append(d)
+        return dict(fn="fs_bilinear_fwd", args=(ctypes.byref(d), ctypes.c_void_p(xp), ctypes.c_void_p(yp)), desc=d, family="resize",
+                    flops=0.0, bytes=es * N * C * (Hi * Wi + Ho * Wo), label="resize %dx%d->%dx%d C%d" % (Hi, Wi, Ho, Wo, C))
+
+    def _time_calls(self, calls, reps=20):
+        """Device time (ms) of a dependent sequence of launches, replayed `reps` times from one hipGraph."""
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            st = ctypes.c_void_p(side.cuda_stream)
+            for c in calls:
+                call(c["fn"], st, *c["args"])
+            side.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+                for _ in range(reps):
+                    for c in calls:
+                        call(c["fn"], st, *c["args"])
+            g.replay()
+            best = None
+            for _ in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                g.replay()
+                e1.record()
+                e1.synchronize()
+                t = e0.elapsed_time(e1) / reps
+                best = t if best is None or t < best else best
+        torch.cuda.current_stream().wait_stream(side)
+        return best
+
+    def _add_zoom(self, op, out):
+        A, B, x, down, up = op["A"], op["B"], op["x"], op["down"], op["up"]
+        es = 2 if self.dtype == torch.bfloat16 else 4
+        N, _, H, W = x.shape
+        cin, cmid, cout = A["cin"], A["cout"], B["cout"]
+        xp, x_cs = self._ptr(x)
+        yp, y_cs = self._ptr(out)
+        d = K.zoom_desc((N, cin, H, W), x_cs, cmid, cout, down, up, y_cs, self.dtype)
+        sc1, sh1 = self._fold(A["bn"], None, cmid)
+        sc2, sh2 = self._fold(B["bn"], None, cout)
+        w1 = K.pack_weight_frag(A["weight"].detach().to(self.device), self.dtype, cmid, cin)
+        w2 = K.pack_weight_frag(B["weight"].detach().to(self.device), self.dtype, cout, cmid)
+        self._keep += [d, w1, w2]
+        args = (ctypes.byref(d), ctypes.c_void_p(xp), ctypes.c_void_p(w1.data_ptr()), K._p(sc1), K._p(sh1), ctypes.c_void_p(w2.data_ptr()),
+                K._p(sc2), K._p(sh2), ctypes.c_void_p(yp))
+        flops = 2.0 * N * d.h * d.w * 9 * (cin * cmid + cmid * cout)
+        nbytes = es * (N * H * W * cin + 9 * (cin * cmid + cmid * cout) + N * d.Ho * d.Wo * cout)
+        fused = dict(fn="fs_zoom_cell_fwd", args=args, desc=d, family="zoomcell", flops=flops, bytes=nbytes,
+                     label="cell[%s%s] %d->%d->%d conv@%dx%d" % ("dn " if down else "", "up" if up else "", cin, cmid, cout, d.h, d.w))
+        if self.fuse_cells != "auto":
+            self.calls.append(fused)
+            self.cell_log.append((fused["label"], "fused", None, None))
+            return
+        # the same cell as separate launches through temporaries, timed against the fused launch
+        first = len(self.calls)
+        cur = x
+        if down:
+            t0 = self._tmp_sym((N, cin, d.h, d.w))
+            self.calls.append(self._resize_call(cur, t0, False))
+            cur = t0
+        t1 = self._tmp_sym((N, cmid, d.h, d.w))
+        self._add_conv(cur, t1, A["weight"], sc1, sh1, 3, 1, 1, True, cmid, cin)
+        t2 = self._tmp_sym((N, cout, d.h, d.w)) if up else out
+        self._add_conv(t1, t2, B["weight"], sc2, sh2, 3, 1, 1, not up, cout, cmid)
+        if up:
+            self.calls.append(self._resize_call(t2, out, True))
+        chain = self.calls[first:]
+        del self.calls[first:]
+        t_fused, t_chain = self._time_calls([fused]), self._time_calls(chain)
+        keep_fused = t_fused <= t_chain
+        self.cell_log.append((fused["label"], "fused" if keep_fused else "split", round(t_fused * 1e3, 2), round(t_chain * 1e3, 2)))
+        self.calls += [fused] if keep_fused else chain
+
     def _time_call(self, fn, args, reps=20):
         """Device time (ms) of one launch, replayed back-to-back from a small hipGraph (same method as profile())."""
         side = torch.cuda.Stream()
@@ -327,6 +499,8 @@ class InferenceEngine:
                 scale, shift = self._fold(op["bn"], op["bias"], op["cout"])
                 self._add_conv(op["x"], out, op["weight"], scale, shift, op["k"], op["stride"], op["pad"], op["relu"], op["cout"],
                                op["cin"], vres=op.get("vres"))
+            elif kind == "zoom":
+                self._add_zoom(op, out)
             elif kind == "fr":
                 half = op["half"]
                 for j, (w, pad) in enumerate(((op["w1"], 0), (op["w2"], -1))):
@@ -362,6 +536,11 @@ class InferenceEngine:
             new_calls = list(range(first_call, len(self.calls)))
             for ci in new_calls:
                 self.calls[ci]["deps"] = deps
+            if kind == "zoom" and len(new_calls) > 1:        # the un-fused form of a cell is a dependent chain of launches
+                for ci in new_calls[1:]:
+                    self.calls[ci]["deps"] = [ci - 1]
+                self._sym_ready[out.id] = [new_calls[-1]]
+                continue
             # a cat output is ready when its aliased producers and its copy calls are; other outputs when their calls are
             self._sym_ready[out.id] = (deps + new_calls) if kind == "cat" else new_calls
         self._assign_lanes()
@@ -432,7 +611,7 @@ class InferenceEngine:
             main.wait_event(ev)
 
     # ---- 4b. the plan as one multi-stream launch program (fs_exec_program_streams) ---------------------------------
-    _OPS = {"fs_conv2d_fwd_ws": "OP_CONV_FWD", "fs_conv2d_fwd": "OP_CONV_FWD", "fs_conv3x3_s1_fwd": "OP_CONV3X3_S1",
+    _OPS = {"fs_zoom_cell_fwd": "OP_ZOOM_CELL", "fs_conv2d_fwd_ws": "OP_CONV_FWD", "fs_conv2d_fwd": "OP_CONV_FWD", "fs_conv3x3_s1_fwd": "OP_CONV3X3_S1",
             "fs_conv_stem_fwd": "OP_STEM", "fs_bilinear_fwd": "OP_BILINEAR_FWD", "fs_copy_channels": "OP_COPY_CHANNELS"}
 
     def _build_program(self):

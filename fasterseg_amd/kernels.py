@@ -9,7 +9,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import FS_BF16, FS_CONV_RELU, FS_CONV_TRANSPOSED, FS_F32, ConvDesc, ResizeDesc, call
+from ._lib import FS_BF16, FS_CONV_RELU, FS_CONV_TRANSPOSED, FS_F32, ConvDesc, ResizeDesc, ZoomDesc, call
 
 _DT = {torch.float32: FS_F32, torch.bfloat16: FS_BF16}
 
@@ -259,6 +259,32 @@ def conv3x3_halo(x, w_frag, cout, scale=None, shift=None, relu=False, out=None, 
         out = empty_nhwc(N, cout, H, W, x.dtype, x.device)
     d.y_cs = channel_stride(out)
     call("fs_conv3x3_s1_fwd", _stream(), ctypes.byref(d), _p(x), _p(w_frag), _p(scale), _p(shift), _p(out), _p(stats))
+    return out
+
+
+def zoom_desc(x_shape, x_cs, cmid, cout, down, up, y_cs, dtype):
+    N, Cin, H, W = x_shape
+    h, w = (H // 2, W // 2) if down else (H, W)
+    Ho, Wo = (2 * h, 2 * w) if up else (h, w)
+    return ZoomDesc(N, H, W, Cin, cmid, cout, h, w, Ho, Wo, x_cs, y_cs, dtype_code(dtype), int(bool(down)), int(bool(up)))
+
+
+def zoom_cell_supported(d):
+    return bool(_lib.lib().fs_zoom_cell_supported(ctypes.byref(d)))
+
+
+def zoom_cell(x, w1_frag, scale1, shift1, w2_frag, scale2, shift2, cmid, cout, down=True, up=True, out=None):
+    """A whole zoomed-conv cell in one launch (zoom_cell.hip): [1/2 bilinear] -> conv3x3*s1+b1, ReLU -> conv3x3*s2+b2 ->
+    [x2 bilinear] -> ReLU.  Filters in fragment order (pack_weight_frag)."""
+    x_cs = require_nhwc(x, "x")
+    d = zoom_desc(x.shape, x_cs, cmid, cout, down, up, 0, x.dtype)
+    if out is None:
+        out = empty_nhwc(d.N, cout, d.Ho, d.Wo, x.dtype, x.device)
+    else:
+        assert tuple(out.shape) == (d.N, cout, d.Ho, d.Wo) and out.dtype == x.dtype
+    d.y_cs = channel_stride(out)
+    call("fs_zoom_cell_fwd", _stream(), ctypes.byref(d), _p(x), _p(w1_frag), _p(scale1), _p(shift1), _p(w2_frag), _p(scale2),
+         _p(shift2), _p(out))
     return out
 
 

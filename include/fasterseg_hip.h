@@ -109,6 +109,27 @@ fs_status fs_pack_weight_frag(void* stream, const float* w_oihw, long long o_str
 fs_status fs_conv3x3_s1_fwd(void* stream, const fs_conv_desc* d, const void* x, const void* w_frag, const float* scale,
                             const float* shift, void* y, float* stats);
 
+/* One launch for a whole zoomed-conv cell in inference form (zoom_cell.hip):
+ *   x (N,H,W,Cin) -[bilinear 1/2 if down]-> (h,w) -conv3x3 * scale1 + shift1, ReLU-> Cmid -conv3x3 * scale2 + shift2-> Cout
+ *     -[bilinear x2 if up]-> ReLU -> y (N,Ho,Wo,Cout)
+ * Replaces BasicResidual_downup_2x.forward (search/operations.py:435-446; F.interpolate :437, conv1/bn1/relu :438-440,
+ * conv2/bn2 :441-442, F.interpolate :444, relu :445) and, with down = up = 0, the stride-1 BasicResidual2x.forward
+ * (:352-359).  Both filter banks in fragment order (fs_pack_weight_frag).  The intermediate maps never leave the CU: no
+ * workspace.  fs_zoom_cell_supported tells whether a geometry is handled (Cmid == Cout <= 256 (bf16) / 128 (fp32), even H, W
+ * when resampling); callers fall back to the separate launches otherwise. */
+typedef struct fs_zoom_desc {
+    int N, H, W, Cin;       /* input map                                                        */
+    int Cmid, Cout;         /* conv1: Cin -> Cmid, conv2: Cmid -> Cout                          */
+    int h, w;               /* resolution both convolutions run at: (H/2, W/2) if down else (H, W) */
+    int Ho, Wo;             /* output resolution: (2h, 2w) if up else (h, w)                    */
+    int x_cs, y_cs;         /* channel strides of x and y                                       */
+    int dtype;
+    int down, up;
+} fs_zoom_desc;
+int fs_zoom_cell_supported(const fs_zoom_desc* d);
+fs_status fs_zoom_cell_fwd(void* stream, const fs_zoom_desc* d, const void* x, const void* w1_frag, const float* scale1,
+                           const float* shift1, const void* w2_frag, const float* scale2, const float* shift2, void* y);
+
 /* Replaces conv2d backward-weight: dw[co][r][s][ci] = sum_pixels dy[p][co] * x[p@(r,s)][ci], fp32 packed
  * output (caller zeroes; split-K atomics).  `d` is the forward descriptor. */
 fs_status fs_conv2d_wgrad(void* stream, const fs_conv_desc* d, const void* x, const void* dy, float* dw_packed);
@@ -295,6 +316,7 @@ enum {
     FS_OP_COPY_CHANNELS,
     FS_OP_EVENT_RECORD,      /* (event)  record on the command's stream   (fs_exec_program_streams)      */
     FS_OP_EVENT_WAIT,        /* (event)  make the command's stream wait for the event                     */
+    FS_OP_ZOOM_CELL,         /* fs_zoom_cell_fwd */
     FS_OP_COUNT
 };
 fs_status fs_exec_program(void* stream, const long long* words, long long n_words, const unsigned char* blob,
