@@ -10,6 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfasterseg_hip.so")
 
+EXPECTED_ABI = 200          # FS_ABI_VERSION of include/fasterseg_hip.h these bindings were written against
 FS_F32, FS_BF16 = 0, 1
 FS_CONV_RELU, FS_CONV_TRANSPOSED, FS_CONV_ACCUM = 1, 2, 4
 
@@ -27,6 +28,10 @@ class ZoomDesc(ctypes.Structure):
 
 class ResizeDesc(ctypes.Structure):
     _fields_ = [(n, c_int) for n in ("N", "Hi", "Wi", "Ho", "Wo", "C", "x_cs", "y_cs", "dtype", "relu", "out_nchw")]
+
+
+class SgdTensor(ctypes.Structure):
+    _fields_ = [("p", c_vp), ("g_off", c_ll), ("numel", c_ll), ("I", c_int), ("taps", c_int), ("pack_fwd", c_vp), ("pack_flip", c_vp)]
 
 
 # name -> argtypes (restype is int status unless listed in _SPECIAL); order = include/fasterseg_hip.h
@@ -75,6 +80,7 @@ SIGNATURES = {
 _SPECIAL = {
     "fs_last_error": ([], ctypes.c_char_p),
     "fs_version": ([], c_int),
+    "fs_struct_size": ([c_int], c_int),
     "fs_packed_weight_elems": ([c_int, c_int, c_int, c_int], c_ll),
     "fs_debug_force_conv_cfg": ([c_int], None),
     "fs_packed_weight_frag_elems": ([c_int, c_int, c_int], c_ll),
@@ -108,6 +114,14 @@ def lib():
             fn = getattr(handle, name)
             fn.argtypes = argtypes
             fn.restype = restype
+        got = handle.fs_version()
+        if got != EXPECTED_ABI:
+            raise ImportError("libfasterseg_hip.so has ABI %d, these bindings expect %d: rebuild with `python -m fasterseg_amd.build "
+                              "--force`" % (got, EXPECTED_ABI))
+        for which, struct in enumerate((ConvDesc, ResizeDesc, ZoomDesc, SgdTensor)):
+            if handle.fs_struct_size(which) != ctypes.sizeof(struct):
+                raise ImportError("libfasterseg_hip.so: sizeof(%s) is %d in the library, %d in the bindings - stale build" % (
+                    struct.__name__, handle.fs_struct_size(which), ctypes.sizeof(struct)))
         _lib = handle
     return _lib
 

@@ -14,4 +14,15 @@ void set_error(const char* fmt, ...) {
 }  // namespace fs
 
 extern "C" const char* fs_last_error(void) { return fs::g_err; }
-extern "C" int fs_version(void) { return 130; }
+extern "C" int fs_version(void) { return FS_ABI_VERSION; }
+/* sizeof of the descriptor structs this library was compiled with (0: conv, 1: resize, 2: zoom, 3: sgd tensor): a binding whose
+ * struct layout differs from the header it was written against must fail at load, not read garbage fields. */
+extern "C" int fs_struct_size(int which) {
+    switch (which) {
+        case 0: return (int)sizeof(fs_conv_desc);
+        case 1: return (int)sizeof(fs_resize_desc);
+        case 2: return (int)sizeof(fs_zoom_desc);
+        case 3: return (int)sizeof(fs_sgd_tensor);
+        default: return -1;
+    }
+}

@@ -39,11 +39,15 @@ inline int vec_elems(int dtype) { return 16 / elem_size(dtype); }
 
 // ---- bf16 <-> f32 ------------------------------------------------------------------------------
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {   // round-to-nearest-even, NaN preserved
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+// round-to-nearest-even through the hardware converter (v_cvt_pk_bf16_f32 on gfx950): one instruction per PAIR instead of
+// the ~6-instruction integer sequence - the epilogues and resamplers are issue-bound on these conversions
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
+    bf16x2_t v;
+    v[0] = (__bf16)lo;
+    v[1] = (__bf16)hi;
+    return __builtin_bit_cast(uint32_t, v);
 }
 
 template <typename T> struct Elem;
@@ -77,8 +81,7 @@ template <> struct Elem<bf16_t> {
     __device__ static __forceinline__ u32x4 pack(const float* in) {
         u32x4 v;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            v[i] = (uint32_t)f32_to_bf16(in[2 * i]) | ((uint32_t)f32_to_bf16(in[2 * i + 1]) << 16);
+        for (int i = 0; i < 4; ++i) v[i] = pack2_bf16(in[2 * i], in[2 * i + 1]);
         return v;
     }
 };

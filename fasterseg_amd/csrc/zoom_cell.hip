@@ -38,7 +38,16 @@ struct ZoomArgs {
     int tiles_x, tiles_y;
     int nch1, nch2;
     float rh_dn, rw_dn, rh_up, rw_up;
+#ifdef FS_ZOOM_TIMING
+    unsigned long long* dbg;      // tools/zoom_timing.hip: shader-clock stamps of block 0 / wave 0 at the phase boundaries
+#endif
 };
+
+#ifdef FS_ZOOM_TIMING
+#define ZT(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) p.dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ZT(i) do { } while (0)
+#endif
 
 constexpr int ZW0 = 18;                         // R0 width
 constexpr int ZR1 = 8;                          // R1 rows (4 m-tiles, one per wave)
@@ -81,12 +90,16 @@ __global__ __launch_bounds__(256) void zoom_cell_kernel(ZoomArgs p) {
     constexpr int OUT_BYTES = Z_R2_PIX * OUT_PITCH;
     constexpr int MID_OFF = 2 * Z_IN_BYTES;
     constexpr int SMEM = zmax(MID_OFF + NCH2_MAX * Z_MID_CHUNK, OUT_BYTES);
-    // conv2 work split over the 4 waves: (m-tiles, n-tiles) per wave
+    // work split over the 4 waves: (m-tiles, n-tiles) per wave in conv1 (4 m-tiles x NT) and conv2 (3 m-tiles x NT)
+    constexpr int MT1 = NT == 1 ? 1 : (NT == 2 || NT == 6) ? 2 : 4;
+    constexpr int NJ1 = NT == 6 ? 3 : NT == 8 ? 2 : 1;
     constexpr int MT2 = NT >= 3 ? 3 : NT == 2 ? 2 : 1;
     constexpr int NJ2 = NT >= 3 ? (NT + 3) / 4 : 1;
-    constexpr int RK1 = zring(NT);
+    constexpr int APF = 3;                                       // A-fragment prefetch distance in k-steps
+    constexpr int RK1 = zring(NJ1);
     constexpr int RK2 = zring(NJ2);
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+    ZT(7);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31;
     int b = blockIdx.x;
@@ -100,7 +113,7 @@ __global__ __launch_bounds__(256) void zoom_cell_kernel(ZoomArgs p) {
     // ---- R0 staging map: slot v -> (R0 pixel, 16-byte part of the chunk); 4 bilinear taps each when `down` ----------
     const unsigned char* xb = p.x + (long long)img * p.H * p.W * p.x_cs * ES;
     int a_off[Z_IN_ITEMS][4];
-    float a_l[Z_IN_ITEMS][4];            // th.l0, th.l1, tw.l0, tw.l1
+    float a_l[Z_IN_ITEMS][4];            // the four tap weights th.l{0,1} * tw.l{0,1}
     uint32_t a_keep[Z_IN_ITEMS];
     int a_lds[Z_IN_ITEMS];
 #pragma unroll
@@ -119,7 +132,7 @@ __global__ __launch_bounds__(256) void zoom_cell_kernel(ZoomArgs p) {
             a_off[i][1] = ((th.i0 * p.W + tw.i1) * p.x_cs + slot * VEC) * ES;
             a_off[i][2] = ((th.i1 * p.W + tw.i0) * p.x_cs + slot * VEC) * ES;
             a_off[i][3] = ((th.i1 * p.W + tw.i1) * p.x_cs + slot * VEC) * ES;
-            a_l[i][0] = th.l0; a_l[i][1] = th.l1; a_l[i][2] = tw.l0; a_l[i][3] = tw.l1;
+            a_l[i][0] = th.l0 * tw.l0; a_l[i][1] = th.l0 * tw.l1; a_l[i][2] = th.l1 * tw.l0; a_l[i][3] = th.l1 * tw.l1;
         } else {
             a_off[i][0] = ((cy * p.W + cx) * p.x_cs + slot * VEC) * ES;
             a_off[i][1] = a_off[i][2] = a_off[i][3] = 0;
@@ -157,8 +170,8 @@ __global__ __launch_bounds__(256) void zoom_cell_kernel(ZoomArgs p) {
                     Elem<T>::unpack(a_reg[i][2], p10);
                     Elem<T>::unpack(a_reg[i][3], p11);
 #pragma unroll
-                    for (int k = 0; k < VEC; ++k)      // same expression as bilinear_fwd_kernel (resize.hip)
-                        p00[k] = a_l[i][0] * (a_l[i][2] * p00[k] + a_l[i][3] * p01[k]) + a_l[i][1] * (a_l[i][2] * p10[k] + a_l[i][3] * p11[k]);
+                    for (int k = 0; k < VEC; ++k)      // four multiply-adds per element (weights combined once per pixel)
+                        p00[k] = fmaf(a_l[i][3], p11[k], fmaf(a_l[i][2], p10[k], fmaf(a_l[i][1], p01[k], a_l[i][0] * p00[k])));
                     v = Elem<T>::pack(p00);
                 }
                 const uint32_t k = a_cmask[i];
@@ -168,89 +181,159 @@ __global__ __launch_bounds__(256) void zoom_cell_kernel(ZoomArgs p) {
         }
     };
 
-    // =================================== conv1: wave = m-tile `wave`, all NT n-tiles ===================================
+    // =================================== wave -> (m-tiles, n-tiles) maps ===============================================
+    // Filter fragments come straight from global/L2 and are not shared between waves, so the maps give every n-tile to as
+    // few waves as possible (the per-CU vector-memory path, ~64 B/clk, is what bounds these phases); A fragments come from
+    // LDS and may be read by every wave.
+    int m1[MT1], n1[NJ1], m2[MT2], n2[NJ2];
+    bool m2_ok[MT2];
+    if constexpr (NT == 1) {
+        m1[0] = wave; n1[0] = 0;
+        m2_ok[0] = wave < 3; m2[0] = m2_ok[0] ? wave : 0; n2[0] = 0;
+    } else if constexpr (NT == 2) {
+        m1[0] = 2 * (wave >> 1); m1[1] = m1[0] + 1; n1[0] = wave & 1;
+        m2[0] = wave >> 1; m2_ok[0] = true;                 // 6 (m, n) jobs: waves 0,1 take m-tiles {0, 2}, waves 2,3 m-tile 1
+        m2_ok[1] = (wave >> 1) == 0; m2[1] = m2_ok[1] ? 2 : 0; n2[0] = wave & 1;
+    } else {
+        if constexpr (NT == 6) {                            // 24 jobs: m-pair (wave>>1) x three n-tiles
+            m1[0] = 2 * (wave >> 1); m1[1] = m1[0] + 1;
+#pragma unroll
+            for (int j = 0; j < NJ1; ++j) n1[j] = 3 * (wave & 1) + j;
+        } else {                                            // NT = 3, 4, 8: all four m-tiles x n-tiles {wave, wave + 4}
+#pragma unroll
+            for (int i = 0; i < MT1; ++i) m1[i] = i;
+#pragma unroll
+            for (int j = 0; j < NJ1; ++j) n1[j] = wave + 4 * j;
+        }
+#pragma unroll
+        for (int i = 0; i < MT2; ++i) { m2[i] = i; m2_ok[i] = true; }
+#pragma unroll
+        for (int j = 0; j < NJ2; ++j) n2[j] = wave + 4 * j;          // may run past NT: those banks are zero-filled, nothing is stored
+    }
+    // folded BatchNorm of both convolutions, fetched before anything waits on memory
+    float sc1[NJ1], sh1[NJ1], sc2[NJ2], sh2[NJ2];
+#pragma unroll
+    for (int j = 0; j < NJ1; ++j) {
+        const int co = n1[j] * 32 + l31;
+        const bool cvalid = co < p.Cmid;
+        sc1[j] = (p.sc1 && cvalid) ? p.sc1[co] : 1.f;
+        sh1[j] = (p.sh1 && cvalid) ? p.sh1[co] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < NJ2; ++j) {
+        const int co = n2[j] * 32 + l31;
+        const bool cvalid = co < p.Cout;
+        sc2[j] = (p.sc2 && cvalid) ? p.sc2[co] : 1.f;
+        sh2[j] = (p.sh2 && cvalid) ? p.sh2[co] : 0.f;
+    }
+
+    // =================================== conv1 on R0 (staged per channel chunk) ========================================
     // filter fragments: [n_tile][chunk][tap][kk][lane] x 16 bytes; k-step q = (chunk*9 + tap)*2 + kk
-    const int nq1 = p.nch1 * 18;
-    f32x16 acc1[NT];
+    const int nq1 = p.nch1 * 18, nq2 = p.nch2 * 18;
+    f32x16 acc1[MT1][NJ1];
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+    for (int i = 0; i < MT1; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc1[j][r] = 0.f;
+        for (int j = 0; j < NJ1; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[i][j][r] = 0.f;
     {
-        const unsigned char* wb = p.w1 + lane * 16;
-        const long long nstride = (long long)nq1 * 1024;
-        u32x4 ring[RK1][NT];
+        const unsigned char* wb[NJ1];
+#pragma unroll
+        for (int j = 0; j < NJ1; ++j) wb[j] = p.w1 + (long long)n1[j] * nq1 * 1024 + lane * 16;
+        u32x4 ring[RK1][NJ1];
         auto load_b = [&](int slot, int q) {
 #pragma unroll
-            for (int j = 0; j < NT; ++j) ring[slot][j] = ldg16(wb + j * nstride + (long long)q * 1024);
+            for (int j = 0; j < NJ1; ++j) ring[slot][j] = ldg16(wb[j] + (long long)q * 1024);
         };
-        const int frag_base = ((wave * 2 + (l31 >> 4)) * ZW0 + (l31 & 15)) * ZPITCH + (lane >> 5) * 16;
+        int frag[MT1];
+#pragma unroll
+        for (int i = 0; i < MT1; ++i) frag[i] = ((m1[i] * 2 + (l31 >> 4)) * ZW0 + (l31 & 15)) * ZPITCH + (lane >> 5) * 16;
+        ZT(0);
         load_in(0);
 #pragma unroll
-        for (int s = 0; s < RK1; ++s)
-            if (s < nq1) load_b(s, s);
+        for (int s = 0; s < RK1; ++s) load_b(s, s);               // nq >= 18 >= RK
+        __builtin_amdgcn_sched_barrier(0);                        // keep the whole prologue burst ahead of the first wait
         store_in(0);
         __syncthreads();
+        ZT(1);
         for (int c = 0; c < p.nch1; ++c) {
             const int buf = c & 1;
             const bool more = (c + 1) < p.nch1;
             if (more) load_in(c + 1);
-            const unsigned char* hal = smem + buf * Z_IN_BYTES + frag_base;
-#pragma unroll
-            for (int ks = 0; ks < 18; ++ks) {
+            const unsigned char* hal = smem + buf * Z_IN_BYTES;
+            u32x4 af[APF + 1][MT1];                               // A fragments APF k-steps ahead of their MFMAs (LDS latency)
+            auto load_a = [&](int ks) {
                 const int tap = ks >> 1, kk = ks & 1;
                 const int r = tap / 3, s = tap - r * 3;
-                const int slot = ks % RK1;
-                const u32x4 af = *reinterpret_cast<const u32x4*>(hal + (r * ZW0 + s) * ZPITCH + kk * 32);
 #pragma unroll
-                for (int j = 0; j < NT; ++j) MmaZ<T>::run(af, ring[slot][j], acc1[j]);
-                const int qn = c * 18 + ks + RK1;
-                if (qn < nq1) load_b(slot, qn);
+                for (int i = 0; i < MT1; ++i)
+                    af[ks % (APF + 1)][i] = *reinterpret_cast<const u32x4*>(hal + frag[i] + (r * ZW0 + s) * ZPITCH + kk * 32);
+            };
+#pragma unroll
+            for (int ks = 0; ks < APF; ++ks) load_a(ks);
+#pragma unroll
+            for (int ks = 0; ks < 18; ++ks) {
+                const int slot = ks % RK1;
+                if (ks + APF < 18) load_a(ks + APF);
+#pragma unroll
+                for (int i = 0; i < MT1; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ1; ++j) MmaZ<T>::run(af[ks % (APF + 1)][i], ring[slot][j], acc1[i][j]);
+                load_b(slot, min(c * 18 + ks + RK1, nq1 - 1));      // branch-free: past the end it re-reads the last k-step
             }
             if (more) store_in(buf ^ 1);
             __syncthreads();
         }
     }
+    ZT(2);
+    // conv2's first filter fragments are requested now: their latency hides behind the conv1 epilogue
+    const unsigned char* wb2[NJ2];
+#pragma unroll
+    for (int j = 0; j < NJ2; ++j) wb2[j] = p.w2 + (long long)n2[j] * nq2 * 1024 + lane * 16;
+    u32x4 ring2[RK2][NJ2];
+    auto load_b2 = [&](int slot, int q) {
+#pragma unroll
+        for (int j = 0; j < NJ2; ++j) ring2[slot][j] = ldg16(wb2[j] + (long long)q * 1024);
+    };
+#pragma unroll
+    for (int s = 0; s < RK2; ++s) load_b2(s, s);
+    __builtin_amdgcn_sched_barrier(0);
     // ---- conv1 epilogue: BN + ReLU, zero outside the image (conv2's zero padding), R1 -> LDS in T, all mid channels ----
     {
         unsigned char* mid = smem + MID_OFF;
+        const int hi = lane >> 5;
+        uint32_t colmask = 0;                 // bit x: R1 column x + 4 * hi lies inside the image
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int co = j * 32 + l31;
+        for (int x = 0; x < 12; ++x)
+            colmask |= ((unsigned)(ox0 - e - 1 + x + 4 * hi) < (unsigned)p.w) ? (1u << x) : 0u;
+#pragma unroll
+        for (int j = 0; j < NJ1; ++j) {
+            const int co = n1[j] * 32 + l31;
             const bool cvalid = co < p.Cmid;
-            const float sc = (p.sc1 && cvalid) ? p.sc1[co] : 1.f;
-            const float sh = (p.sh1 && cvalid) ? p.sh1[co] : 0.f;
-            unsigned char* dst = mid + (co / CK) * Z_MID_CHUNK + (co % CK) * ES;
+            if (n1[j] < NT) {                    // (NT == 3: wave 3 holds a padding tile that has no place in the mid map)
+                // accumulator register r of this lane is pixel (row (r >> 3), column (r & 3) + 8 * ((r >> 2) & 1) + 4 * hi) of the
+                // m-tile: the in-image test is one bit of a per-lane column mask and a per-row flag
+                unsigned char* dst = mid + (co / CK) * Z_MID_CHUNK + (co % CK) * ES + hi * 4 * ZPITCH;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int prow = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int r1y = wave * 2 + (prow >> 4), r1x = prow & 15;
-                const int ly = oy0 - e - 1 + r1y, lx = ox0 - e - 1 + r1x;
-                const bool in_img = ((unsigned)ly < (unsigned)p.h) && ((unsigned)lx < (unsigned)p.w);
-                const float o = (in_img && cvalid) ? fmaxf(acc1[j][r] * sc + sh, 0.f) : 0.f;
-                Elem<T>::store(reinterpret_cast<T*>(dst + (r1y * 16 + r1x) * ZPITCH), o);
+                for (int i = 0; i < MT1; ++i) {
+                    const int ly0 = oy0 - e - 1 + m1[i] * 2;
+                    const bool row_ok[2] = {cvalid && (unsigned)ly0 < (unsigned)p.h, cvalid && (unsigned)(ly0 + 1) < (unsigned)p.h};
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int col = (r & 3) + 8 * ((r >> 2) & 1);                 // + 4 * hi, folded into colmask / dst
+                        const bool in_img = row_ok[r >> 3] && ((colmask >> col) & 1u);
+                        const float o = in_img ? fmaxf(acc1[i][j][r] * sc1[j] + sh1[j], 0.f) : 0.f;
+                        Elem<T>::store(reinterpret_cast<T*>(dst + ((m1[i] * 2 + (r >> 3)) * 16 + col) * ZPITCH), o);
+                    }
+                }
             }
         }
     }
     __syncthreads();
+    ZT(3);
 
     // =================================== conv2 on R1 (resident), R2 = 3 m-tiles x NT n-tiles ===========================
-    int m_idx[MT2], n_idx[NJ2];
-    bool m_ok[MT2];
-    if (NT >= 3) {
-#pragma unroll
-        for (int i = 0; i < MT2; ++i) { m_idx[i] = i; m_ok[i] = true; }
-#pragma unroll
-        for (int j = 0; j < NJ2; ++j) n_idx[j] = wave + 4 * j;        // may run past NT: those banks are zero-filled, nothing stored
-    } else if (NT == 2) {                  // 6 (m, n) jobs: waves 0,1 take m-tiles {0, 2}, waves 2,3 take m-tile 1
-        m_idx[0] = wave >> 1; m_ok[0] = true;
-        m_ok[MT2 - 1] = MT2 > 1 ? (wave >> 1) == 0 : m_ok[0];
-        m_idx[MT2 - 1] = MT2 > 1 ? (m_ok[MT2 - 1] ? 2 : 0) : m_idx[0];
-        n_idx[0] = wave & 1;
-    } else {                               // 3 jobs: waves 0..2 take one m-tile each
-        m_ok[0] = wave < 3; m_idx[0] = m_ok[0] ? wave : 0;
-        n_idx[0] = 0;
-    }
     f32x16 acc2[MT2][NJ2];
 #pragma unroll
     for (int i = 0; i < MT2; ++i)
@@ -259,67 +342,58 @@ __global__ __launch_bounds__(256) void zoom_cell_kernel(ZoomArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.f;
     {
-        const int nq2 = p.nch2 * 18;
-        const long long nstride = (long long)nq2 * 1024;
-        const unsigned char* wb[NJ2];
+        int frag[MT2];
 #pragma unroll
-        for (int j = 0; j < NJ2; ++j) wb[j] = p.w2 + n_idx[j] * nstride + lane * 16;
-        u32x4 ring[RK2][NJ2];
-        auto load_b = [&](int slot, int q) {
-#pragma unroll
-            for (int j = 0; j < NJ2; ++j) ring[slot][j] = ldg16(wb[j] + (long long)q * 1024);
-        };
-        int frag_base[MT2];
-#pragma unroll
-        for (int i = 0; i < MT2; ++i) frag_base[i] = ((m_idx[i] * 2 + (l31 >> 4)) * 16 + (l31 & 15)) * ZPITCH + (lane >> 5) * 16;
-#pragma unroll
-        for (int s = 0; s < RK2; ++s)
-            if (s < nq2) load_b(s, s);
+        for (int i = 0; i < MT2; ++i) frag[i] = ((m2[i] * 2 + (l31 >> 4)) * 16 + (l31 & 15)) * ZPITCH + (lane >> 5) * 16;
         for (int c = 0; c < p.nch2; ++c) {
             const unsigned char* midc = smem + MID_OFF + c * Z_MID_CHUNK;
-#pragma unroll
-            for (int ks = 0; ks < 18; ++ks) {
+            u32x4 af[APF + 1][MT2];
+            auto load_a = [&](int ks) {
                 const int tap = ks >> 1, kk = ks & 1;
                 const int r = tap / 3, s = tap - r * 3;
+#pragma unroll
+                for (int i = 0; i < MT2; ++i)
+                    af[ks % (APF + 1)][i] = *reinterpret_cast<const u32x4*>(midc + frag[i] + (r * 16 + s) * ZPITCH + kk * 32);
+            };
+#pragma unroll
+            for (int ks = 0; ks < APF; ++ks) load_a(ks);
+#pragma unroll
+            for (int ks = 0; ks < 18; ++ks) {
                 const int slot = ks % RK2;
-                u32x4 af[MT2];
-#pragma unroll
-                for (int i = 0; i < MT2; ++i)
-                    af[i] = *reinterpret_cast<const u32x4*>(midc + frag_base[i] + (r * 16 + s) * ZPITCH + kk * 32);
+                if (ks + APF < 18) load_a(ks + APF);
 #pragma unroll
                 for (int i = 0; i < MT2; ++i)
 #pragma unroll
-                    for (int j = 0; j < NJ2; ++j) MmaZ<T>::run(af[i], ring[slot][j], acc2[i][j]);
-                const int qn = c * 18 + ks + RK2;
-                if (qn < nq2) load_b(slot, qn);
+                    for (int j = 0; j < NJ2; ++j) MmaZ<T>::run(af[ks % (APF + 1)][i], ring2[slot][j], acc2[i][j]);
+                load_b2(slot, min(c * 18 + ks + RK2, nq2 - 1));
             }
         }
     }
+    ZT(4);
     __syncthreads();                       // every wave is done reading R0/R1: the fp32 R2 tile may overlay them
     {
         const bool relu_now = !p.up;
 #pragma unroll
         for (int j = 0; j < NJ2; ++j) {
-            const int co = n_idx[j] * 32 + l31;
+            const int co = n2[j] * 32 + l31;
             const bool cvalid = co < p.Cout;
-            const float sc = (p.sc2 && cvalid) ? p.sc2[co] : 1.f;
-            const float sh = (p.sh2 && cvalid) ? p.sh2[co] : 0.f;
 #pragma unroll
             for (int i = 0; i < MT2; ++i) {
-                if (m_ok[i] && cvalid) {
+                if (m2_ok[i] && cvalid) {
+                    unsigned char* dst = smem + ((m2[i] * 2) * 16 + 4 * (lane >> 5)) * OUT_PITCH + co * 4;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int prow = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                        const int pix = (m_idx[i] * 2 + (prow >> 4)) * 16 + (prow & 15);
-                        float o = acc2[i][j][r] * sc + sh;
+                        const int pix = (r >> 3) * 16 + (r & 3) + 8 * ((r >> 2) & 1);   // within the m-tile, without the 4*hi term
+                        float o = acc2[i][j][r] * sc2[j] + sh2[j];
                         if (relu_now) o = fmaxf(o, 0.f);
-                        *reinterpret_cast<float*>(smem + pix * OUT_PITCH + co * 4) = o;
+                        *reinterpret_cast<float*>(dst + pix * OUT_PITCH) = o;
                     }
                 }
             }
         }
     }
     __syncthreads();
+    ZT(5);
 
     // =================================== output: x2 bilinear + ReLU (or R2 as it is), 16-byte stores ===================
     {
@@ -328,12 +402,11 @@ __global__ __launch_bounds__(256) void zoom_cell_kernel(ZoomArgs p) {
         if (p.up) {
             const int PW = 2 * TW, PH = 2 * TH;
             const int total = PH * PW * cv;
-            for (int idx = tid; idx < total; idx += 256) {
+            auto emit = [&](int idx) {
                 const int c = (idx % cv) * VEC;
                 const int pp = idx / cv;
                 const int py = pp / PW, px = pp - py * PW;
                 const int Y = 2 * oy0 + py, X = 2 * ox0 + px;
-                if (Y >= p.Ho || X >= p.Wo) continue;
                 const Tap th = make_tap(p.rh_up, Y, p.h), tw = make_tap(p.rw_up, X, p.w);
                 const int a0 = min(max(th.i0 - (oy0 - 1), 0), ZR2 - 1), a1 = min(max(th.i1 - (oy0 - 1), 0), ZR2 - 1);
                 const int b0 = min(max(tw.i0 - (ox0 - 1), 0), 13), b1 = min(max(tw.i1 - (ox0 - 1), 0), 13);
@@ -341,6 +414,7 @@ __global__ __launch_bounds__(256) void zoom_cell_kernel(ZoomArgs p) {
                 const float* q01 = reinterpret_cast<const float*>(smem + (a0 * 16 + b1) * OUT_PITCH) + c;
                 const float* q10 = reinterpret_cast<const float*>(smem + (a1 * 16 + b0) * OUT_PITCH) + c;
                 const float* q11 = reinterpret_cast<const float*>(smem + (a1 * 16 + b1) * OUT_PITCH) + c;
+                const float w00 = th.l0 * tw.l0, w01 = th.l0 * tw.l1, w10 = th.l1 * tw.l0, w11 = th.l1 * tw.l1;
                 float o[VEC];
 #pragma unroll
                 for (int k = 0; k < VEC; k += 4) {
@@ -348,10 +422,16 @@ __global__ __launch_bounds__(256) void zoom_cell_kernel(ZoomArgs p) {
                     const f32x4 v10 = *reinterpret_cast<const f32x4*>(q10 + k), v11 = *reinterpret_cast<const f32x4*>(q11 + k);
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
-                        o[k + u] = fmaxf(th.l0 * (tw.l0 * v00[u] + tw.l1 * v01[u]) + th.l1 * (tw.l0 * v10[u] + tw.l1 * v11[u]), 0.f);
+                        o[k + u] = fmaxf(fmaf(w11, v11[u], fmaf(w10, v10[u], fmaf(w01, v01[u], w00 * v00[u]))), 0.f);
                 }
-                stg16(y + (((long long)img * p.Ho + Y) * p.Wo + X) * p.y_cs + c, Elem<T>::pack(o));
+                if (Y < p.Ho && X < p.Wo) stg16(y + (((long long)img * p.Ho + Y) * p.Wo + X) * p.y_cs + c, Elem<T>::pack(o));
+            };
+            int idx = tid;
+            for (; idx + 256 < total; idx += 512) {        // two independent items per trip: their LDS reads overlap
+                emit(idx);
+                emit(idx + 256);
             }
+            if (idx < total) emit(idx);
         } else {
             const int total = TH * TW * cv;
             for (int idx = tid; idx < total; idx += 256) {
@@ -371,6 +451,7 @@ __global__ __launch_bounds__(256) void zoom_cell_kernel(ZoomArgs p) {
             }
         }
     }
+    ZT(6);
 }
 
 template <typename T, int NT> static void launch_zoom(hipStream_t st, const ZoomArgs& a) {
@@ -393,7 +474,7 @@ extern "C" int fs_zoom_cell_supported(const fs_zoom_desc* d) {
     const int nt = (d->Cmid + 31) / 32;
     const int nt_max = d->dtype == FS_BF16 ? 8 : 4;             // LDS: all mid channels of R1 stay resident
     if (nt > nt_max) return 0;
-    if (d->down ? (d->h != d->H / 2 || d->w != d->W / 2 || d->h < 2 || d->w < 2) : (d->h != d->H || d->w != d->W)) return 0;
+    if (d->down ? (d->H % 2 || d->W % 2 || d->h != d->H / 2 || d->w != d->W / 2 || d->h < 2 || d->w < 2) : (d->h != d->H || d->w != d->W)) return 0;
     if (d->up ? (d->Ho != 2 * d->h || d->Wo != 2 * d->w) : (d->Ho != d->h || d->Wo != d->w)) return 0;
     if ((long long)d->H * d->W * d->x_cs * elem_size(d->dtype) >= (1ll << 31)) return 0;
     return 1;

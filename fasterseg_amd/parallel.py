@@ -15,10 +15,14 @@ import torch.distributed as dist
 
 
 class FlatGradientSync:
-    def __init__(self, params, bucket_mb=256, group=None, average=True):
+    def __init__(self, params, bucket_mb=256, group=None, average=True, comm_dtype=None):
+        """comm_dtype=torch.bfloat16 sends every bucket as bf16 (half the bytes over xGMI: the supernet's 1 GB fp32 buffer is
+        ~11 ms on one ring link); the buffer itself, the clip and the optimizer stay fp32."""
         self.params = [p for p in params if p.requires_grad]
         self.group = group
         self.average = average
+        self.comm_dtype = comm_dtype if comm_dtype not in (None, torch.float32) else None
+        self.passes = 1
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         dev = self.params[0].device
         sizes = [p.numel() for p in self.params]
@@ -41,6 +45,7 @@ class FlatGradientSync:
         self.pending = [0] * len(self.buckets)
         self.count = [sum(1 for i in range(len(self.params)) if self.bucket_id[i] == b) for b in range(len(self.buckets))]
         self.handles = {}
+        self.stage = torch.empty_like(self.flat, dtype=self.comm_dtype) if (self.comm_dtype is not None and self.world > 1) else None
         self._touched = [False] * len(self.params)
         self._index = {id(p): i for i, p in enumerate(self.params)}
         self._hooks = []
@@ -63,14 +68,22 @@ class FlatGradientSync:
                 self._touched[i] = True
                 b = self.bucket_id[i]
                 self.pending[b] += 1
-                if self.pending[b] == self.count[b] and not (self.flat.is_cuda and torch.cuda.is_current_stream_capturing()):
+                # Early (overlapped) launch only when this step has ONE backward: with several accumulating backward passes
+                # (the supernet's `_loss` = 4 passes) a bucket completed by the first pass would be reduced before the later
+                # passes have added to it.  Those steps launch every bucket in sync().
+                if (self.passes == 1 and self.pending[b] == self.count[b]
+                        and not (self.flat.is_cuda and torch.cuda.is_current_stream_capturing())):
                     self._launch(b)
         return hook
 
     def _launch(self, b):
         if self.world > 1 and b not in self.handles:
             s, e = self.buckets[b]
-            self.handles[b] = dist.all_reduce(self.flat[s:e], group=self.group, async_op=True)
+            buf = self.flat[s:e]
+            if self.stage is not None:
+                buf = self.stage[s:e]
+                buf.copy_(self.flat[s:e])
+            self.handles[b] = dist.all_reduce(buf, group=self.group, async_op=True)
 
     # ---- fused gradient accumulation protocol (functional.conv_weight_grad) -------------------------------
     def accepts(self, param):
@@ -80,8 +93,11 @@ class FlatGradientSync:
     def touched(self, param):
         self._hooks[self._index[id(param)]](param)
 
-    def prepare(self):
-        """Call before each backward: zero the buffer and point every .grad at its slice."""
+    def prepare(self, passes=1):
+        """Call before the backward(s) of a step: zero the buffer and point every .grad at its slice.  `passes` = number of
+        backward passes that will accumulate into the buffer before sync() (1: buckets are all-reduced as soon as backward
+        has filled them; more: all buckets go out in sync())."""
+        self.passes = int(passes)
         from . import functional as FN
         from . import kernels as K
         if self.flat.is_cuda:
@@ -106,6 +122,8 @@ class FlatGradientSync:
             self._launch(b)
         for h in self.handles.values():
             h.wait()
+        if self.stage is not None and self.handles:
+            self.flat.copy_(self.stage)
         if self.world > 1 and self.average:
             self.flat.div_(self.world)
         if hasattr(self.params[0], "register_post_accumulate_grad_hook"):

@@ -31,7 +31,7 @@ class StudentDistillStep:
         broadcast_parameters(self.teacher)
         min_kept = int(batch * height * width // 16)                       # train/train.py:62 with gt_down_sampling = 1
         self.ohem = ProbOhemCrossEntropy2d(ignore_label=255, thresh=0.7, min_kept=min_kept, use_weight=False)
-        self.sync = FlatGradientSync(self.student.parameters(), bucket_mb=256)
+        self.sync = FlatGradientSync(self.student.parameters(), bucket_mb=4)      # 17.6 MB -> 5 buckets, overlapped with backward
         self.optimizer = FlatSGD(self.sync, lr, momentum, weight_decay, pack_dtype=compute_dtype)       # train/train.py:173-176
         self.lamb = 0.2
         self.teacher_engine = None
@@ -174,7 +174,7 @@ class SupernetStep:
 
         def fresh():
             if phase == "w":
-                self.sync.prepare()
+                self.sync.prepare(passes=len(self._specs()))
             else:
                 self._zero_arch_grads()
         fresh()
@@ -279,7 +279,7 @@ class SupernetStep:
             for optimizer in self.architect.optimizers:
                 optimizer.step()
         self._set_phase("w")
-        self.sync.prepare()
+        self.sync.prepare(passes=len(self._specs()))
         loss = self._phase_loss("w", imgs, target)
         self.sync.sync()
         self.optimizer.step()
@@ -298,7 +298,7 @@ class SupernetStep:
                 loss_arch = self.architect.step(imgs, target, imgs_search, target_search)
             finally:
                 self._set_phase("w")
-        self.sync.prepare()
+        self.sync.prepare(passes=1)           # `_loss` sums its four forwards: ONE backward over all of them
         loss = self.model._loss(imgs, target, self.pretrain)
         loss.backward()
         self.sync.sync()

@@ -64,7 +64,11 @@ typedef struct fs_resize_desc {
 } fs_resize_desc;
 
 const char* fs_last_error(void);
+/* ABI revision of this header; fs_version() returns the one the library was built from.  Bindings check both this and
+ * fs_struct_size() when they load the library (fasterseg_amd/_lib.py) - a stale .so must not be used silently. */
+#define FS_ABI_VERSION 200
 int fs_version(void);
+int fs_struct_size(int which);   /* 0 fs_conv_desc, 1 fs_resize_desc, 2 fs_zoom_desc, 3 fs_sgd_tensor; -1 otherwise */
 /* test hook: force the tile configuration of fs_conv2d_fwd (0..6; -1 = heuristic).  Not for production use. */
 void fs_debug_force_conv_cfg(int cfg);
 /* number of elements of a packed filter bank for (Cout,R,S,Cin) */
