@@ -183,6 +183,8 @@ def run_student_infer(args, world, rank):
                              "into 1x1 convs; candidate instantiations timed at build, ms/frame: %s)" % (
                                  len(eng.calls), getattr(eng, "graph_lanes", 1), eng.shared_resizes, eng.fused_resizes,
                                  getattr(eng, "capture_log", [])),
+                   "cells": "per zoomed/2x cell [label, choice, fused us, split us (isolated), frame ms when flipped]: %s" % (
+                       getattr(eng, "cell_log", []),),
                    "vs_baseline_note": "per-GPU fps / 163.9 FPS published on GTX 1080Ti+TensorRT fp32 (nearest-resample "
                                        "latency/ variant); this run is the bilinear train/ network"},
         "alg_gflop_per_frame": round(eng.total_flops / batch / 1e9, 3), "alg_mb_per_frame": round(eng.total_bytes / batch / 1e6, 1),

@@ -110,6 +110,17 @@ __global__ __launch_bounds__(256) void zoom_cell_kernel(ZoomArgs p) {
     const int TH = p.up ? ZR2 - 2 : ZR2, TW = p.up ? 12 : 14;
     const int oy0 = ty * TH, ox0 = tx * TW;                     // low-resolution origin of this block's output patch
 
+    // ---- warm L2 with both filter banks --------------------------------------------------------------------------------
+    // Inside a frame the banks were last read a whole frame ago and come from HBM / Infinity Cache; the fragment rings
+    // look only RK k-steps ahead, which covers an L2 hit but not a miss.  One 4-byte load per 128-byte line, issued before
+    // anything else, starts every line's fetch during the input staging; the values are never used (see the end).
+    uint32_t touch = 0;
+    {
+        const int lines1 = min(NT * p.nch1 * 18 * 8, 1024), lines2 = min(NT * p.nch2 * 18 * 8, 1024);      // <= 128 KB each
+        for (int l = tid; l < lines1; l += 256) touch ^= *reinterpret_cast<const volatile uint32_t*>(p.w1 + (long long)l * 128);
+        for (int l = tid; l < lines2; l += 256) touch ^= *reinterpret_cast<const volatile uint32_t*>(p.w2 + (long long)l * 128);
+    }
+
     // ---- R0 staging map: slot v -> (R0 pixel, 16-byte part of the chunk); 4 bilinear taps each when `down` ----------
     const unsigned char* xb = p.x + (long long)img * p.H * p.W * p.x_cs * ES;
     int a_off[Z_IN_ITEMS][4];
@@ -452,6 +463,7 @@ __global__ __launch_bounds__(256) void zoom_cell_kernel(ZoomArgs p) {
         }
     }
     ZT(6);
+    if (touch == 0x5a17c0deu && p.N < 0) p.y[0] = 0;          // keeps the warm-up loads alive; never true
 }
 
 template <typename T, int NT> static void launch_zoom(hipStream_t st, const ZoomArgs& a) {

@@ -95,6 +95,9 @@ class InferenceEngine:
         self._lower()
         self.graph = None
         if use_graph:
+            if self.fuse_cells == "auto":
+                self._warm()
+                self._tune_cells()
             self._capture()
 
     # ---- 1. trace ----------------------------------------------------------------------------------
@@ -419,8 +422,8 @@ class InferenceEngine:
                      label="cell[%s%s] %d->%d->%d conv@%dx%d" % ("dn " if down else "", "up" if up else "", cin, cmid, cout, d.h, d.w))
         if self.fuse_cells != "auto":
             self.calls.append(fused)
-            self.cell_log.append((fused["label"], "fused", None, None))
-            return
+            self.cell_log.append([fused["label"], "fused", None, None])
+            return None
         # the same cell as separate launches through temporaries, timed against the fused launch
         first = len(self.calls)
         cur = x
@@ -436,10 +439,13 @@ class InferenceEngine:
             self.calls.append(self._resize_call(t2, out, True))
         chain = self.calls[first:]
         del self.calls[first:]
+        # prior from isolated (cache-warm) timings; _tune_cells() then decides on whole-frame time, where the filter banks and
+        # the input are cold as they are in production
         t_fused, t_chain = self._time_calls([fused]), self._time_calls(chain)
         keep_fused = t_fused <= t_chain
-        self.cell_log.append((fused["label"], "fused" if keep_fused else "split", round(t_fused * 1e3, 2), round(t_chain * 1e3, 2)))
+        self.cell_log.append([fused["label"], "fused" if keep_fused else "split", round(t_fused * 1e3, 2), round(t_chain * 1e3, 2)])
         self.calls += [fused] if keep_fused else chain
+        return dict(variants=[[fused], chain], choice=0 if keep_fused else 1, log=self.cell_log[-1])
 
     def _time_call(self, fn, args, reps=20):
         """Device time (ms) of one launch, replayed back-to-back from a small hipGraph (same method as profile())."""
@@ -472,8 +478,9 @@ class InferenceEngine:
         return self._sym_ready.get(sym.id, [])
 
     def _lower(self):
+        """Ops -> call groups (a group = the launches of one op; a cell has two alternative groups), then _flatten()."""
         self.calls = []
-        self._sym_ready = {}
+        self.groups = []
         es = 2 if self.dtype == torch.bfloat16 else 4
         for idx, op in enumerate(self.ops):
             if op.get("dead"):
@@ -481,7 +488,7 @@ class InferenceEngine:
             kind, out = op["kind"], op["out"]
             first_call = len(self.calls)
             in_syms = op["inputs"] if kind == "cat" else [op["x"]]
-            deps = sorted({d for s_ in in_syms for d in self._ready(s_)})
+            alt = None
             if kind == "stem":
                 N, _, H, W = op["x"].shape
                 cout = out.shape[1]
@@ -500,7 +507,7 @@ class InferenceEngine:
                 self._add_conv(op["x"], out, op["weight"], scale, shift, op["k"], op["stride"], op["pad"], op["relu"], op["cout"],
                                op["cin"], vres=op.get("vres"))
             elif kind == "zoom":
-                self._add_zoom(op, out)
+                alt = self._add_zoom(op, out)
             elif kind == "fr":
                 half = op["half"]
                 for j, (w, pad) in enumerate(((op["w1"], 0), (op["w2"], -1))):
@@ -533,19 +540,58 @@ class InferenceEngine:
                                            label="copy C%d @%dx%d" % (C, H, W)))
             else:
                 raise RuntimeError("unknown op kind " + kind)
-            new_calls = list(range(first_call, len(self.calls)))
-            for ci in new_calls:
-                self.calls[ci]["deps"] = deps
-            if kind == "zoom" and len(new_calls) > 1:        # the un-fused form of a cell is a dependent chain of launches
-                for ci in new_calls[1:]:
-                    self.calls[ci]["deps"] = [ci - 1]
-                self._sym_ready[out.id] = [new_calls[-1]]
-                continue
-            # a cat output is ready when its aliased producers and its copy calls are; other outputs when their calls are
-            self._sym_ready[out.id] = (deps + new_calls) if kind == "cat" else new_calls
+            calls = self.calls[first_call:]
+            del self.calls[first_call:]
+            group = dict(kind=kind, in_syms=in_syms, out=out, variants=[calls], choice=0, log=None)
+            if alt is not None:
+                group.update(alt)
+            self.groups.append(group)
+        self._flatten()
+
+    def _flatten(self):
+        """The launch list of the current variant choices, with dependencies, stream lanes and totals."""
+        self.calls = []
+        self._sym_ready = {}
+        for g in self.groups:
+            deps = sorted({d for s_ in g["in_syms"] for d in self._ready(s_)})
+            first = len(self.calls)
+            chain = g["kind"] == "zoom" and len(g["variants"][g["choice"]]) > 1     # un-fused cell: a dependent chain of launches
+            for k, c in enumerate(g["variants"][g["choice"]]):
+                c = dict(c)
+                c["deps"] = [first + k - 1] if (chain and k > 0) else deps
+                self.calls.append(c)
+            new_calls = list(range(first, len(self.calls)))
+            if chain:
+                self._sym_ready[g["out"].id] = [new_calls[-1]]
+            else:   # a cat output is ready when its aliased producers and its copy calls are; other outputs when their calls are
+                self._sym_ready[g["out"].id] = (deps + new_calls) if g["kind"] == "cat" else new_calls
         self._assign_lanes()
         self.total_flops = sum(c["flops"] for c in self.calls)
         self.total_bytes = sum(c["bytes"] for c in self.calls)
+
+    def _tune_cells(self):
+        """Fused or separate launches, per cell, decided on the time of the WHOLE frame (single-stream hipGraph): timed alone,
+        back to back, a launch finds its filter bank and input in L2, which flatters the fused kernel (it waits on memory in
+        several dependent phases).  Greedy: flip one cell at a time, keep the flip if the frame gets faster."""
+        cells = [g for g in self.groups if len(g["variants"]) > 1]
+        if not cells:
+            return
+
+        def frame_ms():
+            self._flatten()
+            return self._time_graph(self._capture_once(1), reps=30)
+        best = frame_ms()
+        for g in cells:
+            g["choice"] ^= 1
+            t = frame_ms()
+            if t < best * 0.997:
+                best = t
+            else:
+                g["choice"] ^= 1
+            g["log"][1] = "fused" if g["choice"] == 0 else "split"
+            g["log"].append(round(t, 4))
+        self._flatten()
+
 
     # ---- 3b. independent chains (the two branches of the derived network) go to separate HIP streams ----
     def _assign_lanes(self):
@@ -576,7 +622,8 @@ class InferenceEngine:
         # one split-K scratch buffer per lane (calls of a lane are ordered, lanes run concurrently): the implicit-GEMM conv
         # splits long contractions of launch-latency-sized layers across blocks when it gets a workspace
         if bool(int(os.environ.get("FS_ENGINE_SPLITK", "1"))):
-            self._workspaces = [torch.empty(K.WORKSPACE_BYTES, dtype=torch.uint8, device=self.device) for _ in range(n_lanes)]
+            if getattr(self, "_workspaces", None) is None:
+                self._workspaces = [torch.empty(K.WORKSPACE_BYTES, dtype=torch.uint8, device=self.device) for _ in range(n_lanes)]
             for c in self.calls:
                 if c["fn"] == "fs_conv2d_fwd":
                     c["fn"] = "fs_conv2d_fwd_ws"
@@ -704,11 +751,7 @@ class InferenceEngine:
         e1.synchronize()
         return e0.elapsed_time(e1) / reps
 
-    def _capture(self):
-        """Capture the plan and keep the fastest of a few instantiations.  How the runtime maps the forked lanes of a
-        captured graph onto hardware queues is not under our control and is bimodal on MI355X (the same 3-lane graph replays
-        in 0.49 ms or in 0.63 ms per frame, kernels identical): so the multi-lane capture is tried a few times on fresh
-        streams, the single-stream graph (0.53 ms) is the fallback, and every candidate is timed on the device."""
+    def _warm(self):
         torch.cuda.synchronize()
         warm = torch.cuda.Stream()
         warm.wait_stream(torch.cuda.current_stream())
@@ -716,6 +759,13 @@ class InferenceEngine:
             self._launch_all()                     # warm-up outside capture
         torch.cuda.current_stream().wait_stream(warm)
         torch.cuda.synchronize()
+
+    def _capture(self):
+        """Capture the plan and keep the fastest of a few instantiations.  How the runtime maps the forked lanes of a
+        captured graph onto hardware queues is not under our control and is bimodal on MI355X (the same 3-lane graph replays
+        in 0.49 ms or in 0.63 ms per frame, kernels identical): so the multi-lane capture is tried a few times on fresh
+        streams, the single-stream graph (0.53 ms) is the fallback, and every candidate is timed on the device."""
+        self._warm()
         tries = ([self.n_lanes] * 3 if self.n_lanes > 1 else []) + [1]
         self.capture_log = []
         best = None
