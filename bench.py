@@ -1,28 +1,32 @@
 """bench.py — headline benchmark of the FasterSeg hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|fp32]
-                    [--workload student_infer|student_train|supernet_pretrain|supernet_search]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|fp32] [--workloads c2,c3,c4,c5]
 
-Default workload = BASELINE.json configs[1]: searched student (arch_1) inference at 1x3x1024x2048, bf16 storage /
-fp32 accumulate, one frame per step, input already resident in HBM, the whole forward replayed from one hipGraph
-(fasterseg_amd.engine; the engine times a few instantiations of the plan at build and keeps the fastest, the candidates
-are listed in config.engine).  N>1 (launched by torch.distributed.run, one rank per GPU) runs one replica per GPU —
-inference does not shard, so there is no data-path collective; value = frames of all ranks / max-over-ranks time ("weak").
+ONE JSON line on rank 0.  Top level = BASELINE.json configs[1] (C2): searched student (arch_1) inference at 1x3x1024x2048,
+frames/s, input resident in HBM, the whole forward replayed from one hipGraph (fasterseg_amd.engine).  Before anything is
+timed the engine's logits are checked against the CPU oracle on the same weights and input (bf16: relative error <= 5e-2
+and arg-max agreement >= 97 %; fp32: <= 1e-3) — a frame rate of a wrong answer is never printed.
 
-The other workloads are the train steps of BASELINE configs[2..4] restated in fasterseg_amd/train_step.py (images/s):
-  student_train      teacher eval forward (engine) + student train forward/backward (3 heads, fused OHEM-CE + KL) + RCCL
-                     all-reduce of the flat gradient buffer + one-launch SGD, 12 x 3x512x1024 per GPU
-  supernet_pretrain  `_loss(pretrain=True)`: max / min / random / random width passes + clip + SGD, 3 x 3x256x512
-  supernet_search    Architect.step on a search batch + the weight step, 2 x 3x224x448 per GPU
---dtype selects the activation / MFMA operand type of all of them (bf16: fp32 accumulate, fp32 BN statistics, fp32 master
-weights and parameter gradients; fp32: exact-fp32 MFMA).
+`workloads` carries every BASELINE configuration with its own ms_per_step, images/s, `roofline` and `cpu_baseline`:
+  C2_student_infer      the top-level numbers again
+  C3_supernet_pretrain  `_loss(pretrain=True)`: max / min / random / random width passes, backward, clip, SGD; 3 x 3x256x512
+  C4_student_train      teacher eval forward + student train forward/backward (3 heads, OHEM-CE + KL), SGD; 12 x 3x512x1024
+  C5_supernet_search    Architect.step (arch0, arch1 Gumbel, max, min + latency loss, Adam) + weight step; 2 x 3x224x448,
+                        latency table = the shipped MI355X table rebuilt from HIP-kernel timings
+The train steps are restated in fasterseg_amd/train_step.py from search/train_search.py:215-251 and train/train.py:219-271.
+With N > 1 (one rank per GPU, RCCL) inference runs as independent replicas (it does not shard: no data-path collective,
+"weak") and the three train steps run data-parallel with the flat-gradient all-reduce, so every --gpus N run exercises the
+collective path; launched without torchrun, `--gpus N` re-executes itself under torch.distributed.run.
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel family of the step, from per-launch HIP-event
-timings taken live on the launch stream (engine.profile()); `cpu_baseline` is the CPU oracle (oracle/ref_ops.py, a
-port of the reference's module code on torch-CPU kernels) timed on this host on a bounded number of frames.
+roofline: C2 from per-launch HIP-event timings of the plan (engine.profile()); train steps from a launch census of one step
+x per-shape HIP-event timings (fasterseg_amd/census.py).  cpu_baseline: the CPU oracle (oracle/, fixture-pinned port of the
+reference modules on torch-CPU kernels) on a bounded sample of the same workload, on this host's cores.
+A step count whose timed region would be shorter than --min-seconds is raised (reported as `steps`; `steps_requested` keeps
+the flag).
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -36,35 +40,53 @@ if ROOT not in sys.path:
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}      # dense MFMA peaks, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 PUBLISHED_STUDENT_FPS = 163.9                        # BASELINE.md §1 (GTX 1080Ti + TensorRT fp32, latency/ variant)
+METRIC = "supernet train-step images/sec @1024x2048 (1/2/4/8 GPU) + student fps"
+PRECISION = {"bf16": "bf16 activations + bf16 MFMA, fp32 accumulate / BN statistics / master weights / parameter gradients",
+             "fp32": "fp32 storage, exact-fp32 MFMA"}
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 1000 inference frames / 10 train steps)")
-    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default: 100 inference / 3 train)")
+    ap.add_argument("--steps", type=int, default=None, help="timed C2 frames (default 2000); train workloads time 10 steps")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 100 frames / 3 train steps)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--workload", default="student_infer", choices=["student_infer", "student_train", "supernet_pretrain", "supernet_search"])
-    ap.add_argument("--height", type=int, default=1024)
-    ap.add_argument("--width", type=int, default=2048)
-    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 1 for inference, 12 for training)")
+    ap.add_argument("--workloads", default="c2,c3,c4,c5", help="comma list of c2,c3,c4,c5 (c2 is always the headline)")
+    ap.add_argument("--train-steps", type=int, default=10)
+    ap.add_argument("--train-warmup", type=int, default=3)
+    ap.add_argument("--min-seconds", type=float, default=0.5, help="minimum length of every timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU budget of the cpu_baseline sample")
-    ap.add_argument("--dump-plan", default=None, help="write the per-launch table (json) here")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU budget of each cpu_baseline sample")
+    ap.add_argument("--dump-plan", default=None, help="write the per-launch table of the C2 plan (json) here")
     args = ap.parse_args()
-    infer = args.workload == "student_infer"
+    args.steps_requested = args.steps
     if args.steps is None:
-        args.steps = 1000 if infer else 10
+        args.steps = 2000
     if args.warmup is None:
-        args.warmup = 100 if infer else 3
+        args.warmup = 100
+    args.workloads = [w.strip().lower() for w in args.workloads.split(",") if w.strip()]
     return args
 
 
+# ---- distributed plumbing ----------------------------------------------------------------------------------------------
 def dist_setup(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 and args.gpus > 1:
+        # not under torchrun: start one rank per GPU ourselves (the driver's own launch line, contract in the task statement)
+        have = torch.cuda.device_count()
+        if have < args.gpus and os.environ.get("FS_DIST_BACKEND", "nccl") == "nccl":
+            raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (RCCL needs one device per rank)" % (args.gpus, have))
+        import socket
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr",
+               "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        os.execvp(cmd[0], cmd)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    backend = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -73,10 +95,10 @@ def dist_setup(args):
         # backend "nccl" is RCCL on ROCm; FS_DIST_BACKEND=gloo exists only to exercise this path with several ranks on
         # a single-GPU box (RCCL refuses two ranks on one device)
         dist.init_process_group(os.environ.get("FS_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
+        backend = dist.get_backend()
     else:
         torch.cuda.set_device(0)
-    assert world == args.gpus or world == 1, "WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
-    return world, rank, local
+    return world, rank, backend
 
 
 def barrier(world):
@@ -96,6 +118,31 @@ def max_over_ranks(value, world):
     return float(t.item())
 
 
+def timed_region(run, steps, warmup, world, min_seconds):
+    """warm-up, then EXACTLY `steps` calls of run() between barrier+synchronize pairs; max over ranks.  `steps` is raised
+    first (from the warm-up's own rate) if the region would be shorter than min_seconds."""
+    barrier(world)
+    t0 = time.perf_counter()
+    for _ in range(max(warmup, 1)):
+        run()
+    barrier(world)
+    per = max_over_ranks((time.perf_counter() - t0) / max(warmup, 1), world)
+    steps = max(steps, int(math.ceil(min_seconds / max(per, 1e-7))))
+    barrier(world)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run()
+    barrier(world)
+    return max_over_ranks(time.perf_counter() - t0, world), steps
+
+
+def parallelism(world, backend, what):
+    if world == 1:
+        return "single GPU"
+    return "dp%d, %s, torch.distributed backend '%s'%s" % (world, what, backend, " (= RCCL)" if backend == "nccl" else " (functional test only)")
+
+
+# ---- C2: student inference ---------------------------------------------------------------------------------------------
 def roofline_from_profile(rows, dtype):
     fam = {}
     for r in rows:
@@ -106,7 +153,7 @@ def roofline_from_profile(rows, dtype):
     avg_ms = dom["ms"] / dom["n"]
     out = {"kernel": name, "launches_per_step": dom["n"], "avg_launch_us": round(avg_ms * 1e3, 3),
            "share_of_kernel_time": round(dom["ms"] / total_ms, 4), "traffic": None}
-    if name.startswith("conv"):
+    if dom["flops"] > 0:
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         out.update(bound="mfma", achieved=round(ach, 2), peak=PEAK_TFLOPS[dtype], unit="TFLOP/s", frac=round(ach / PEAK_TFLOPS[dtype], 4),
                    alg_flops_per_launch=dom["flops"] / dom["n"], alg_bytes_per_launch=dom["bytes"] / dom["n"],
@@ -119,8 +166,7 @@ def roofline_from_profile(rows, dtype):
     if os.path.exists(traffic_file):
         try:
             with open(traffic_file) as f:
-                t = json.load(f)
-            out["traffic"] = t.get(dtype, {}).get(name)
+                out["traffic"] = json.load(f).get(dtype, {}).get(name)
         except Exception:
             pass
     families = {k: {"ms": round(v["ms"], 4), "launches": v["n"], "TFLOPs": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else 0.0,
@@ -128,66 +174,55 @@ def roofline_from_profile(rows, dtype):
     return out, families, total_ms
 
 
-def cpu_baseline_infer(shape, budget_s):
-    """The CPU oracle (port of the reference modules on torch-CPU kernels) on the same workload, bounded sample."""
-    from oracle import ref_ops
-    from oracle.seeded import resolve_aliases, seeded_state
-    with open(os.path.join(ROOT, "tests", "golden", "arch_1.json")) as f:
-        meta = json.load(f)["eval_21"]
-    params = resolve_aliases(seeded_state({k: torch.empty(v) for k, v in meta["state_shapes"].items()}, 12345), meta)
-    x = torch.randn(*shape)
-    cores = torch.get_num_threads()
-    with torch.no_grad():
-        ref_ops.derived_forward(params, meta, x)           # warm-up
-        n, t0 = 0, time.perf_counter()
-        while True:
-            ref_ops.derived_forward(params, meta, x)
-            n += 1
-            el = time.perf_counter() - t0
-            if el >= budget_s or n >= 50:
-                break
-    return {"value": round(n / el, 3), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "%d frames of %dx3x%dx%d fp32, oracle/ref_ops.derived_forward (arch_1 eval build), %.1f s" % (
-                n, shape[0], shape[2], shape[3], el)}
-
-
-def run_student_infer(args, world, rank):
+def run_student_infer(args, world, rank, backend):
     from fasterseg_amd import archs, engine
+    from oracle import ref_ops
+    from oracle.seeded import resolve_aliases
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    batch = args.batch or 1
-    shape = (batch, 3, args.height, args.width)
+    shape = (1, 3, 1024, 2048)
+    with open(os.path.join(ROOT, "tests", "golden", "arch_1.json")) as f:
+        meta = json.load(f)["eval_21"]                    # decoded structure of arch_1 (test fixture): only the oracle reads it
     net = archs.build_derived(1, training=False)          # eval build, branches chosen by objective_acc_lat -> [2, 1]
     archs.init_weight(net, seed=12345)
+    params = resolve_aliases({k: v.detach().clone() for k, v in net.state_dict().items()}, meta)
     net = net.cuda().eval()
     eng = engine.InferenceEngine(net, shape, dtype=dtype, logits_dtype=torch.float32)
-    eng.input.copy_(torch.randn(shape, generator=torch.Generator().manual_seed(rank)).cuda())
-    for _ in range(args.warmup):
-        eng.run()
-    barrier(world)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.run()
-    barrier(world)
-    elapsed = max_over_ranks(time.perf_counter() - t0, world)
-    fps = world * batch * args.steps / elapsed
+    x = torch.randn(shape, generator=torch.Generator().manual_seed(rank))
+    # ---- parity gate: the engine that is about to be timed vs the CPU oracle, same weights, same frame
+    cores = torch.get_num_threads()
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        want = ref_ops.derived_forward(params, meta, x)
+        oracle_s = time.perf_counter() - t0
+        got = eng(x.cuda()).float().cpu()
+    err = float((got - want).abs().max())
+    rel = err / float(want.abs().max())
+    agree = float((got.argmax(1) == want.argmax(1)).float().mean())
+    ok = (err <= 1e-3) if args.dtype == "fp32" else (rel <= 5e-2 and agree >= 0.97)
+    parity = {"vs": "oracle.ref_ops.derived_forward (CPU fp32), same weights and frame", "max_abs_err": err, "rel_to_max_logit": rel,
+              "argmax_agreement": agree, "bar": "fp32: max_abs_err <= 1e-3; bf16: rel <= 5e-2 and argmax >= 0.97", "pass": bool(ok)}
+    if not ok:
+        raise SystemExit("bench.py: engine logits do not match the CPU oracle: %s" % json.dumps(parity))
+    elapsed, steps = timed_region(eng.run, args.steps, args.warmup, world, args.min_seconds)
+    fps = world * steps / elapsed
     line = {
-        "metric": "supernet train-step images/sec @1024x2048 (1/2/4/8 GPU) + student fps",
-        "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": round(fps / world / PUBLISHED_STUDENT_FPS, 3) if (args.height, args.width, batch) == (1024, 2048, 1) else None,
-        "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "student fps: searched arch_1 (eval build, branches 1/32+1/16) inference %dx3x%dx%d, 19 classes, "
-                               "fp32 logits at input resolution" % (shape[0], shape[2], shape[3]),
-                   "weights": "random kaiming init, seed 12345", "parallelism": "replicas x%d (no collective)" % world,
-                   "engine": "static plan of %d launches in one hipGraph (%d stream lanes; %d duplicate resamples shared, %d folded "
-                             "into 1x1 convs; candidate instantiations timed at build, ms/frame: %s)" % (
-                                 len(eng.calls), getattr(eng, "graph_lanes", 1), eng.shared_resizes, eng.fused_resizes,
-                                 getattr(eng, "capture_log", [])),
-                   "cells": "per zoomed/2x cell [label, choice, fused us, split us (isolated), frame ms when flipped]: %s" % (
-                       getattr(eng, "cell_log", []),),
-                   "vs_baseline_note": "per-GPU fps / 163.9 FPS published on GTX 1080Ti+TensorRT fp32 (nearest-resample "
-                                       "latency/ variant); this run is the bilinear train/ network"},
-        "alg_gflop_per_frame": round(eng.total_flops / batch / 1e9, 3), "alg_mb_per_frame": round(eng.total_bytes / batch / 1e6, 1),
+        "value": round(fps, 2), "unit": "frames/s", "steps": steps, "warmup": args.warmup, "ms_per_step": round(elapsed / steps * 1e3, 4),
+        "dtype": args.dtype, "precision": PRECISION[args.dtype] + "; fp32 logits",
+        "config": {"workload": "C2 student fps (BASELINE configs[1]): searched arch_1 (eval build, branches 1/32+1/16) inference 1x3x1024x2048, "
+                               "19 classes, fp32 logits at input resolution",
+                   "weights": "random kaiming init, seed 12345",
+                   "parallelism": "replicas x%d (inference does not shard: no collective)" % world,
+                   "engine": "static plan of %d launches in one hipGraph (%d stream lanes; %d zoomed / 2x cells as one fused launch each of "
+                             "%d candidates; %d duplicate resamples shared, %d folded into 1x1 convs; instantiations timed at build, "
+                             "ms/frame: %s)" % (len(eng.calls), getattr(eng, "graph_lanes", 1),
+                                                sum(1 for c in eng.calls if c["fn"] == "fs_zoom_cell_fwd"), eng.fused_cells,
+                                                eng.shared_resizes, eng.fused_resizes, getattr(eng, "capture_log", [])),
+                   "cells": "[label, choice, fused us, split us (alone, cache-warm), frame ms with the choice flipped]: %s" % (eng.cell_log,)},
+        "parity": parity,
+        "alg_gflop_per_frame": round(eng.total_flops / 1e9, 3), "alg_mb_per_frame": round(eng.total_bytes / 1e6, 1),
+        "vs_baseline": round(fps / world / PUBLISHED_STUDENT_FPS, 3),
+        "vs_baseline_note": "per-GPU fps / 163.9 FPS published on GTX 1080Ti + TensorRT fp32 (nearest-resample latency/ variant of "
+                            "the network); this run is the bilinear train/ network",
     }
     if rank == 0 and not args.no_roofline:
         rows = eng.profile()
@@ -195,31 +230,204 @@ def run_student_infer(args, world, rank):
         line["roofline"] = roof
         line["kernel_families"] = families
         line["sum_kernel_ms"] = round(total_ms, 4)
+        flops_roof = eng.total_flops / (PEAK_TFLOPS[args.dtype] * 1e12)
+        bytes_roof = eng.total_bytes / (PEAK_HBM_GBS * 1e9)
+        line["frame_roofline"] = {"ideal_ms": round(max(flops_roof, bytes_roof) * 1e3, 4), "frac": round(max(flops_roof, bytes_roof) / (elapsed / steps), 4),
+                                  "note": "max(alg FLOPs / MFMA peak, alg bytes / 8 TB/s) / measured frame time"}
         if args.dump_plan:
             with open(args.dump_plan, "w") as f:
                 json.dump(rows, f, indent=1)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline_infer(shape, args.cpu_seconds)
+        with torch.no_grad():
+            n, t0 = 0, time.perf_counter()
+            while True:
+                ref_ops.derived_forward(params, meta, x)
+                n += 1
+                el = time.perf_counter() - t0
+                if el >= args.cpu_seconds or n >= 50:
+                    break
+        line["cpu_baseline"] = {"value": round(n / el, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+                                "sample": "%d frames of 1x3x1024x2048 fp32 through oracle/ref_ops.derived_forward (port of train/model_seg.py "
+                                          "on torch-CPU kernels, pinned to fixtures generated from the unmodified reference), %.1f s; first "
+                                          "(cold) frame %.2f s" % (n, el, oracle_s)}
     return line
 
 
-def run_student_train(args, world, rank):
-    from fasterseg_amd import train_step
-    return train_step.bench_student_train(args, world, rank, barrier, max_over_ranks)
+# ---- train workloads ---------------------------------------------------------------------------------------------------
+def _census_roofline(args, entries):
+    from fasterseg_amd import census
+    return census.roofline(entries, args.dtype, PEAK_TFLOPS[args.dtype], PEAK_HBM_GBS)
+
+
+def _train_line(args, world, backend, name, batch, elapsed, steps, warmup, extra):
+    ips = world * batch * steps / elapsed
+    line = {"value": round(ips, 4), "unit": "images/s", "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3),
+            "dtype": args.dtype, "precision": PRECISION[args.dtype], "per_gpu_batch": batch, "global_batch": world * batch,
+            "config": {"workload": name, "parallelism": parallelism(world, backend, "flat fp32 gradient buckets all-reduced before clip / SGD")}}
+    line.update(extra)
+    return line
+
+
+def run_student_train(args, world, rank, backend):
+    from fasterseg_amd import census, train_step
+    from oracle import ref_ops
+    from oracle.seeded import resolve_aliases
+    batch, H, W = 12, 512, 1024
+    dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    stepper = train_step.StudentDistillStep(batch, H, W, teacher_engine_dtype=dt, compute_dtype=dt)
+    imgs, target = train_step.synthetic_batch(batch, H, W, rank, "cuda")
+    loss = [None]
+
+    def run():
+        loss[0] = stepper.step(imgs, target)
+    elapsed, steps = timed_region(run, args.train_steps, args.train_warmup, world, args.min_seconds)
+    name = ("C4 student KL-distillation train step (BASELINE configs[3]): %d x 3x%dx%d per GPU, teacher arch_0 eval (engine) + student arch_1 "
+            "train (3 heads), OHEM-CE + KLDiv, SGD" % (batch, H, W))
+    line = _train_line(args, world, backend, name, batch, elapsed, steps, args.train_warmup, {"final_loss": float(loss[0])})
+    if rank == 0 and not args.no_roofline:
+        with census.recording() as rec:
+            stepper.step(imgs, target)
+        torch.cuda.synchronize()
+        entries = rec.entries + (stepper.teacher_engine.census_entries() if stepper.teacher_engine is not None else [])
+        line["roofline"], line["kernel_families"] = _census_roofline(args, entries)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # the same step on the CPU oracle, on a 2-image sample (teacher eval forward + student train forward/backward)
+        nb = 2
+        with open(os.path.join(ROOT, "tests", "golden", "arch_1.json")) as f:
+            meta_s = json.load(f)["train_21"]
+        with open(os.path.join(ROOT, "tests", "golden", "arch_0.json")) as f:
+            meta_t = json.load(f)["train_21"]
+        ps = resolve_aliases({k: v.detach().cpu().clone() for k, v in stepper.student.state_dict().items()}, meta_s)
+        pt = resolve_aliases({k: v.detach().cpu().clone() for k, v in stepper.teacher.state_dict().items()}, meta_t)
+        for k, v in ps.items():
+            if v.is_floating_point() and not k.endswith(("running_mean", "running_var")):
+                v.requires_grad_(True)
+        xi, ti = imgs[:nb].cpu(), target[:nb].cpu()
+        crit = torch.nn.CrossEntropyLoss(ignore_index=255)
+
+        def cpu_step():
+            with torch.no_grad():
+                t_logits = ref_ops.derived_forward(pt, meta_t, xi, training=False)
+            p8, p16, p32 = ref_ops.derived_forward(ps, meta_s, xi, training=True)
+            l_ = crit(p8, ti) + 0.2 * crit(p16, ti) + 0.2 * crit(p32, ti)
+            l_ = l_ + torch.nn.functional.kl_div(torch.log_softmax(p8, 1), torch.softmax(t_logits, 1), reduction="mean")
+            l_.backward()
+        line["cpu_baseline"] = _time_cpu(cpu_step, nb, args.cpu_seconds,
+                                         "%d images of 3x%dx%d: teacher eval forward + student train forward/backward through oracle/ref_ops "
+                                         "(plain CE in place of OHEM selection)" % (nb, H, W))
+    return line
+
+
+def _time_cpu(fn, images, budget_s, what, threads=None):
+    """`threads`: the supernet's maps are tiny (a few thousand pixels): with one thread per core of a 128-core host the torch-CPU
+    kernels spend their time in fork/join, so that baseline runs on a bounded pool (stated in `cores`)."""
+    all_threads = torch.get_num_threads()
+    if threads:
+        torch.set_num_threads(min(threads, all_threads))
+    cores = torch.get_num_threads()
+    try:
+        return _time_cpu_inner(fn, images, budget_s, what, cores)
+    finally:
+        torch.set_num_threads(all_threads)
+
+
+def _time_cpu_inner(fn, images, budget_s, what, cores):
+    t0 = time.perf_counter()
+    fn()                                                   # warm-up (also the only run if it already exceeds the budget)
+    first = time.perf_counter() - t0
+    n, el = 1, first
+    if first < budget_s:
+        n, t0 = 0, time.perf_counter()
+        while True:
+            fn()
+            n += 1
+            el = time.perf_counter() - t0
+            if el >= budget_s or n >= 20:
+                break
+    return {"value": round(images * n / el, 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "%s; %d timed pass(es) after one warm-up (%.1f s), %.1f s" % (what, n, first, el)}
+
+
+def run_supernet(args, world, rank, backend, pretrain):
+    from fasterseg_amd import census, latency_lookup_table, train_step
+    from oracle import ref_supernet
+    batch = 3 if pretrain else 2
+    H, W = (256, 512) if pretrain else (224, 448)
+    dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    lut = None if pretrain else latency_lookup_table.load_shipped("bf16")
+    stepper = train_step.SupernetStep(pretrain=pretrain, lut=lut, compute_dtype=dt)
+    g = torch.Generator().manual_seed(2000 + rank)
+
+    def make():
+        imgs = torch.randn(batch, 3, H, W, generator=g).cuda()
+        tgt = torch.randint(0, 19, (batch, H // 8, W // 8), generator=g)
+        tgt[torch.rand(batch, H // 8, W // 8, generator=g) < 0.05] = 255
+        return imgs, tgt.cuda()
+    imgs, target = make()
+    imgs_s, target_s = make()
+    out = [None, None]
+
+    def run():
+        out[0], out[1] = stepper.step(imgs, target, imgs_s, target_s)
+    elapsed, steps = timed_region(run, args.train_steps, args.train_warmup, world, args.min_seconds)
+    if pretrain:
+        name = "C3 supernet pretrain step (BASELINE configs[2]): %d x 3x%dx%d per GPU, F12.L16, widths {4,6,8,10,12}/12, all 5 primitives per MixedOp, " \
+               "4 width passes fwd+bwd, clip 5, SGD" % (batch, H, W)
+    else:
+        name = "C5 architecture-search step (BASELINE configs[4]): arch update (Architect.step, Adam) + weight update, %d x 3x%dx%d per GPU for " \
+               "each, F12.L16; latency table = shipped MI355X table (667 hipEvent-timed entries, fasterseg_amd/latency_lookup_table.py)" % (batch, H, W)
+    line = _train_line(args, world, backend, name, batch, elapsed, steps, args.train_warmup,
+                       {"final_loss": float(out[0]), "arch_loss": None if out[1] is None else float(out[1]),
+                        "eager_passes_per_phase": sum(1 for s_ in stepper._specs() if not stepper._is_static(s_))})
+    if rank == 0 and not args.no_roofline:
+        with census.recording() as rec:
+            stepper.step(imgs, target, imgs_s, target_s, force_eager=True)
+        torch.cuda.synchronize()
+        line["roofline"], line["kernel_families"] = _census_roofline(args, rec.entries)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cfg = dict(layers=train_step.SearchConfig.layers, width_mult_list=train_step.SearchConfig.width_mult_list,
+                   prun_modes=train_step.SearchConfig.prun_modes, stem_head_width=train_step.SearchConfig.stem_head_width)
+        params = {k: v.detach().cpu().clone() for k, v in stepper.model.state_dict().items()}
+        for k, v in params.items():
+            if v.is_floating_point() and not k.endswith(("running_mean", "running_var")):
+                v.requires_grad_(True)
+        xi, ti = imgs[:1].cpu(), target[:1].cpu()
+
+        def cpu_step():
+            if not pretrain:                               # the architecture step's `_loss` on the search batch, then the weight step's
+                ref_supernet.loss(params, cfg, xi, ti, False).backward()
+            ref_supernet.loss(params, cfg, xi, ti, pretrain).backward()
+        line["cpu_baseline"] = _time_cpu(cpu_step, 1, args.cpu_seconds,
+                                         "1 image of 3x%dx%d: %s through oracle/ref_supernet (port of search/model_search.py on torch-CPU "
+                                         "kernels, fixture-pinned)" % (H, W, "`_loss(pretrain)` forward+backward" if pretrain else
+                                                                       "`_loss` forward+backward of the arch step and of the weight step"),
+                                         threads=16)
+    return line
 
 
 def main():
     args = parse()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
-    world, rank, _ = dist_setup(args)
-    if args.workload == "student_infer":
-        line = run_student_infer(args, world, rank)
-    elif args.workload == "student_train":
-        line = run_student_train(args, world, rank)
-    else:
-        from fasterseg_amd import train_step
-        line = train_step.bench_supernet(args, world, rank, barrier, max_over_ranks, args.workload == "supernet_pretrain")
+    world, rank, backend = dist_setup(args)
+    c2 = run_student_infer(args, world, rank, backend)
+    workloads = {"C2_student_infer": {k: c2[k] for k in ("value", "unit", "ms_per_step", "steps", "dtype", "roofline", "cpu_baseline") if k in c2}}
+    runners = {"c3": ("C3_supernet_pretrain", lambda: run_supernet(args, world, rank, backend, True)),
+               "c4": ("C4_student_train", lambda: run_student_train(args, world, rank, backend)),
+               "c5": ("C5_supernet_search", lambda: run_supernet(args, world, rank, backend, False))}
+    for key in ("c4", "c3", "c5"):
+        if key in args.workloads:
+            name, fn = runners[key]
+            torch.cuda.empty_cache()
+            workloads[name] = fn()
+    line = {"metric": METRIC, "value": c2["value"], "unit": c2["unit"], "n_gpus": world, "steps": c2["steps"],
+            "steps_requested": args.steps_requested, "warmup": c2["warmup"], "ms_per_step": c2["ms_per_step"], "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": c2["vs_baseline"] if world >= 1 else None, "dtype": args.dtype, "data": "synthetic"}
+    for k in ("precision", "config", "parity", "alg_gflop_per_frame", "alg_mb_per_frame", "vs_baseline_note", "roofline", "kernel_families",
+              "sum_kernel_ms", "frame_roofline", "cpu_baseline"):
+        if k in c2:
+            line[k] = c2[k]
+    line["workloads"] = workloads
     if rank == 0:
         print(json.dumps(line))
     if world > 1:

@@ -30,6 +30,10 @@ class ResizeDesc(ctypes.Structure):
     _fields_ = [(n, c_int) for n in ("N", "Hi", "Wi", "Ho", "Wo", "C", "x_cs", "y_cs", "dtype", "relu", "out_nchw")]
 
 
+class CensusEntry(ctypes.Structure):
+    _fields_ = [("family", c_int), ("desc", ConvDesc), ("count", c_ll)]
+
+
 class SgdTensor(ctypes.Structure):
     _fields_ = [("p", c_vp), ("g_off", c_ll), ("numel", c_ll), ("I", c_int), ("taps", c_int), ("pack_fwd", c_vp), ("pack_flip", c_vp)]
 
@@ -86,6 +90,8 @@ _SPECIAL = {
     "fs_packed_weight_frag_elems": ([c_int, c_int, c_int], c_ll),
     "fs_sgd_chunk_elems": ([], c_int),
     "fs_zoom_cell_supported": ([ctypes.POINTER(ZoomDesc)], c_int),
+    "fs_census_enable": ([c_int], None),
+    "fs_census_read": ([c_vp, c_int], c_int),
     "fs_event_create": ([], c_vp),
     "fs_event_destroy": ([c_vp], None),
 }

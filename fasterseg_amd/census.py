@@ -1,0 +1,144 @@
+"""Launch census + per-shape timing: what a train step's dominant kernel achieves against its roofline.
+
+The train steps replay most of their launches from hipGraphs, where individual kernels cannot be bracketed by events.  So
+the measurement is split: (1) the C library counts every convolution launch by geometry while one step is issued (launches
+recorded during a capture are counted once = per replay); (2) each counted geometry is then run alone on the device,
+`reps` times back to back from a small hipGraph bracketed by HIP events on the launch stream (same method as
+InferenceEngine.profile()); (3) achieved = sum(count x algorithmic FLOPs) / sum(count x measured duration).
+profiles/*_kernel_stats.csv (rocprofv3 --kernel-trace --stats of the same bench command) hold the in-step average durations
+of the same kernels for cross-checking.
+"""
+import contextlib
+import ctypes
+
+import torch
+
+from . import _lib
+from . import kernels as K
+from ._lib import FS_CONV_TRANSPOSED, CensusEntry, ConvDesc, call
+
+IGEMM, HALO, WGRAD, STATS = 0, 1, 2, 0x100
+FAMILY_NAMES = {IGEMM: "conv_igemm (fwd + dgrad)", HALO: "conv3x3_halo", WGRAD: "conv_wgrad"}
+
+
+@contextlib.contextmanager
+def recording():
+    """with recording() as rec: <issue one step>  ->  rec.entries = [(family, ConvDesc, count)]"""
+    lib = _lib.lib()
+
+    class _Rec:
+        entries = []
+    rec = _Rec()
+    lib.fs_census_enable(1)
+    try:
+        yield rec
+    finally:
+        lib.fs_census_enable(0)
+        n = lib.fs_census_read(None, 0)
+        buf = (CensusEntry * max(n, 1))()
+        n = min(n, lib.fs_census_read(ctypes.cast(buf, ctypes.c_void_p), n))
+        out = []
+        for i in range(n):
+            d = ConvDesc()
+            ctypes.memmove(ctypes.byref(d), ctypes.byref(buf[i].desc), ctypes.sizeof(ConvDesc))
+            out.append((int(buf[i].family), d, int(buf[i].count)))
+        rec.entries = out
+
+
+def conv_flops(d):
+    return 2.0 * d.N * d.Ho * d.Wo * d.Cout * d.Cin * d.R * d.S
+
+
+def conv_bytes(d):
+    es = 2 if d.dtype == _lib.FS_BF16 else 4
+    in_px = d.N * (d.vr_H * d.vr_W if d.vr_H > 0 else d.H * d.W)
+    return es * (in_px * d.Cin + d.Cout * d.R * d.S * d.Cin + d.N * d.Ho * d.Wo * d.Cout)
+
+
+def _graph_time_ms(fn, reps=20, rounds=3):
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn(ctypes.c_void_p(side.cuda_stream))
+        side.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            for _ in range(reps):
+                fn(st)
+        g.replay()
+        best = None
+        for _ in range(rounds):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            g.replay()
+            e1.record()
+            e1.synchronize()
+            t = e0.elapsed_time(e1) / reps
+            best = t if best is None or t < best else best
+    torch.cuda.current_stream().wait_stream(side)
+    return best
+
+
+def time_entry(family, d, device="cuda"):
+    """Device time (ms) of one launch of this geometry on random operands."""
+    dt = torch.bfloat16 if d.dtype == _lib.FS_BF16 else torch.float32
+    fam = family & 0xff
+    in_h, in_w = (d.vr_H, d.vr_W) if d.vr_H > 0 else (d.H, d.W)
+    x = torch.randn(d.N * in_h * in_w * d.x_cs, device=device).to(dt)
+    y = torch.empty(d.N * d.Ho * d.Wo * max(d.y_cs, d.Cout), dtype=dt, device=device)
+    stats = torch.zeros(2 * d.Cout, dtype=torch.float32, device=device) if family & STATS else None
+    dd = ConvDesc()
+    ctypes.memmove(ctypes.byref(dd), ctypes.byref(d), ctypes.sizeof(ConvDesc))
+    if fam == WGRAD:
+        dy = torch.randn(d.N * d.Ho * d.Wo * d.y_cs, device=device).to(dt)
+        dw = torch.zeros(d.Cout * d.R * d.S * d.Cin, dtype=torch.float32, device=device)        # [O][R][S][I]
+        o_s, i_s, t_s = d.R * d.S * d.Cin, 1, d.Cin
+        return _graph_time_ms(lambda st: call("fs_conv2d_wgrad_strided", st, ctypes.byref(dd), K._p(x), K._p(dy), K._p(dw), o_s, i_s, t_s))
+    if fam == HALO:
+        n = _lib.lib().fs_packed_weight_frag_elems(d.Cout, d.Cin, d.dtype)
+        w = (torch.randn(n, device=device) * 0.05).to(dt)
+        return _graph_time_ms(lambda st: call("fs_conv3x3_s1_fwd", st, ctypes.byref(dd), K._p(x), K._p(w), None, None, K._p(y), K._p(stats)))
+    rows = max(d.w_os, d.R * d.S * max(d.w_ts, d.Cin)) if d.w_os else d.R * d.S * d.Cin
+    w = (torch.randn(d.Cout * rows, device=device) * 0.05).to(dt)
+    ws = torch.empty(K.WORKSPACE_BYTES, dtype=torch.uint8, device=device)
+    return _graph_time_ms(lambda st: call("fs_conv2d_fwd_ws", st, ctypes.byref(dd), K._p(x), K._p(w), None, None, K._p(y), K._p(stats),
+                                          K._p(ws), K.WORKSPACE_BYTES))
+
+
+def roofline(entries, dtype_name, peak_tflops, peak_hbm_gbs=8000.0, max_shapes=160, coverage=0.95):
+    """Per family: launches/step, algorithmic FLOPs and bytes, measured time; returns (dominant-family roofline dict, families).
+    Shapes are timed in descending order of their share of the step's FLOPs until `coverage` of all FLOPs (or max_shapes) is
+    reached; the remainder is reported as un-timed (`flops_coverage`), never extrapolated."""
+    fams = {}
+    order = sorted(entries, key=lambda e: -conv_flops(e[1]) * e[2])
+    total_flops = sum(conv_flops(d) * c for _, d, c in order) or 1.0
+    kept, acc = [], 0.0
+    for e in order:
+        if len(kept) >= max_shapes or acc >= coverage * total_flops:
+            break
+        kept.append(e)
+        acc += conv_flops(e[1]) * e[2]
+    skipped_launches = sum(c for _, _, c in order[len(kept):])
+    for family, d, count in kept:
+        ms = time_entry(family, d)
+        f = fams.setdefault(family & 0xff, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0, shapes=0))
+        f["ms"] += ms * count
+        f["flops"] += conv_flops(d) * count
+        f["bytes"] += conv_bytes(d) * count
+        f["launches"] += count
+        f["shapes"] += 1
+    if not fams:
+        return None, {}
+    dom_id, dom = max(fams.items(), key=lambda kv: kv[1]["ms"])
+    ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+    roof = {"kernel": FAMILY_NAMES[dom_id], "bound": "mfma", "achieved": round(ach, 2), "peak": peak_tflops, "unit": "TFLOP/s",
+            "frac": round(ach / peak_tflops, 4), "launches_per_step": dom["launches"], "distinct_shapes": dom["shapes"],
+            "avg_launch_us": round(dom["ms"] / dom["launches"] * 1e3, 3),
+            "alg_flops_per_launch": dom["flops"] / dom["launches"], "alg_bytes_per_launch": dom["bytes"] / dom["launches"],
+            "achieved_GBps": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9, 1), "traffic": None,
+            "flops_coverage": round(acc / total_flops, 4), "untimed_small_launches": skipped_launches,
+            "method": "launch census of one step x per-shape HIP-event timing (fasterseg_amd/census.py)"}
+    families = {FAMILY_NAMES[k]: {"ms_per_step": round(v["ms"], 3), "launches": v["launches"], "shapes": v["shapes"],
+                                  "TFLOPs": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in fams.items()}
+    return roof, families

@@ -33,6 +33,14 @@ inline fs_status check_launch(const char* what) {
     return FS_OK;
 }
 
+// launch census (api.cpp): one branch per conv launch when disabled
+extern int g_census_on;
+void census_conv(int family, const fs_conv_desc* d);
+#define FS_CENSUS(family, d)                                  \
+    do {                                                      \
+        if (fs::g_census_on) fs::census_conv((family), (d));  \
+    } while (0)
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 inline int elem_size(int dtype) { return dtype == FS_BF16 ? 2 : 4; }
 inline int vec_elems(int dtype) { return 16 / elem_size(dtype); }

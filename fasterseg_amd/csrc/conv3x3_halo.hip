@@ -340,6 +340,7 @@ extern "C" fs_status fs_conv3x3_s1_fwd(void* stream, const fs_conv_desc* d, cons
     a.nchunks = (d->Cin + 4 * vec - 1) / (4 * vec);
     a.flags = d->flags;
     if (!(aligned16(y) && (d->y_cs % vec == 0))) a.flags |= 0x100;
+    FS_CENSUS(FS_CENSUS_CONV_HALO | (stats ? FS_CENSUS_STATS : 0), d);
     if (d->dtype == FS_F32) dispatch_halo<float>((hipStream_t)stream, a);
     else dispatch_halo<bf16_t>((hipStream_t)stream, a);
     return check_launch("fs_conv3x3_s1_fwd");

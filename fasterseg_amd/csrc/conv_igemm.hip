@@ -626,6 +626,7 @@ extern "C" fs_status fs_conv2d_fwd_ws(void* stream, const fs_conv_desc* d, const
     }
     // 16-byte epilogue stores need an aligned slice; otherwise every tile takes the element-wise path
     if (!(aligned16(y) && (d->y_cs % vec == 0))) a.flags |= CONV_SCALAR_STORE;
+    FS_CENSUS(FS_CENSUS_CONV_IGEMM | (stats ? FS_CENSUS_STATS : 0), d);
     if (d->dtype == FS_F32) dispatch<float>((hipStream_t)stream, a, g_force_cfg, (float*)workspace, workspace_bytes);
     else dispatch<bf16_t>((hipStream_t)stream, a, g_force_cfg, (float*)workspace, workspace_bytes);
     return check_launch("fs_conv2d_fwd");

@@ -807,6 +807,11 @@ class InferenceEngine:
         self.input.copy_(x)
         return self.run()
 
+    def census_entries(self):
+        """The plan's convolution launches as (family, descriptor, count) tuples in fasterseg_amd.census form."""
+        fam = {"fs_conv2d_fwd_ws": 0, "fs_conv2d_fwd": 0, "fs_conv3x3_s1_fwd": 1}
+        return [(fam[c["fn"]], c["desc"], 1) for c in self.calls if c["fn"] in fam]
+
     def profile(self, repeats=20, rounds=3):
         """Device time of every launch of the plan, measured with HIP events on the launch stream.
 

@@ -70,6 +70,16 @@ def entries(Fch_cells=(12,), Fch_heads=(8, 12), Fch_max=12):
                    lambda F=Fch, b=branch: Head._latency(H // 8, W // 8, 8 * F * b, 19))
 
 
+SHIPPED = {"bf16": os.path.join(os.path.dirname(os.path.abspath(__file__)), "fasterseg", "latency_lookup_table_mi355x_bf16.json")}
+
+
+def load_shipped(dtype="bf16"):
+    """The table this module generated on an MI355X (hipEvent timings of the HIP kernels, 667 keys = the reference's key set):
+    what `operations.latency_lookup_table` should hold for a search on this hardware (search/operations.py:33-36)."""
+    with open(SHIPPED[dtype]) as f:
+        return json.load(f)
+
+
 def generate(out="latency_lookup_table.npy", quick=False, dtype=torch.bfloat16, verbose=True):
     from . import latency
     FN.set_compute_dtype(dtype)

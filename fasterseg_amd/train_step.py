@@ -8,9 +8,6 @@ synthetic batches (the drivers themselves need Cityscapes + cv2 + tensorboardX a
 Every conv / BN / resize in both networks runs on the HIP kernels (operations.py -> functional.py); losses and the
 optimizer are PyTorch ops.
 """
-import json
-import time
-
 import torch
 
 from . import archs
@@ -244,11 +241,13 @@ class SupernetStep:
     def _graphed_pretrain_loss(self, imgs, target):
         return self._phase_loss("w", imgs, target)
 
-    def step(self, imgs, target, imgs_search=None, target_search=None):
+    def step(self, imgs, target, imgs_search=None, target_search=None, force_eager=False):
+        """One iteration.  force_eager=True issues every launch from the host (no hipGraph replay): same kernels, used by
+        bench.py to take the launch census of a step."""
         from . import functional as FN
         FN.set_compute_dtype(self.compute_dtype)
         try:
-            if self.use_graphs:
+            if self.use_graphs and not force_eager:
                 return self._step_graphed(imgs, target, imgs_search, target_search)
             return self._step_eager(imgs, target, imgs_search, target_search)
         finally:
@@ -327,77 +326,3 @@ def synthetic_batch(batch, height, width, rank, device, num_classes=19):
     target = torch.randint(0, num_classes, (batch, height, width), generator=g)
     target[torch.rand(batch, height, width, generator=g) < 0.05] = 255
     return imgs.to(device), target.to(device)
-
-
-def bench_student_train(args, world, rank, barrier, max_over_ranks):
-    batch = args.batch or 12
-    H, W = (args.height, args.width) if (args.height, args.width) != (1024, 2048) else (512, 1024)   # config C4 crop
-    eng_dtype = {"bf16": torch.bfloat16, "fp32": torch.float32}[args.dtype]
-    stepper = StudentDistillStep(batch, H, W, teacher_engine_dtype=eng_dtype, compute_dtype=eng_dtype)
-    imgs, target = synthetic_batch(batch, H, W, rank, "cuda")
-    for _ in range(args.warmup):
-        stepper.step(imgs, target)
-    barrier(world)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = stepper.step(imgs, target)
-    barrier(world)
-    elapsed = max_over_ranks(time.perf_counter() - t0, world)
-    ips = world * batch * args.steps / elapsed
-    return {
-        "metric": "supernet train-step images/sec @1024x2048 (1/2/4/8 GPU) + student fps",
-        "value": round(ips, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.dtype, "data": "synthetic",
-        "precision": ("bf16 activations + bf16 MFMA, fp32 accumulate / BN statistics / master weights / parameter gradients"
-                      if args.dtype == "bf16" else "fp32 storage, exact-fp32 MFMA") + "; teacher engine %s" % args.dtype,
-        "config": {"workload": "student KL-distillation train step (BASELINE configs[3]): %d x 3x%dx%d per GPU, teacher arch_0 eval "
-                               "+ student arch_1 train (3 heads), OHEM-CE + KLDiv, SGD" % (batch, H, W),
-                   "global_batch": world * batch, "parallelism": "dp%d, flat fp32 gradient bucket all-reduce (RCCL)" % world},
-        "final_loss": float(loss),
-    }
-
-
-def bench_supernet(args, world, rank, barrier, max_over_ranks, pretrain):
-    """BASELINE configs[2] (pretrain, 3 x 3x256x512) / configs[4] (search, 2 x 3x224x448 per GPU); labels at 1/8 resolution."""
-    import os
-    batch = args.batch or (3 if pretrain else 2)
-    default_hw = (256, 512) if pretrain else (224, 448)
-    H, W = (args.height, args.width) if (args.height, args.width) != (1024, 2048) else default_hw
-    lut = None
-    if not pretrain:
-        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "latency_lut_1080ti.json")
-        with open(path) as f:
-            lut = json.load(f)      # the reference's shipped table until fasterseg_amd.latency_lookup_table regenerates it
-    stepper = SupernetStep(pretrain=pretrain, lut=lut, compute_dtype={"bf16": torch.bfloat16, "fp32": torch.float32}[args.dtype])
-    g = torch.Generator().manual_seed(2000 + rank)
-
-    def make():
-        imgs = torch.randn(batch, 3, H, W, generator=g).cuda()
-        tgt = torch.randint(0, 19, (batch, H // 8, W // 8), generator=g)
-        tgt[torch.rand(batch, H // 8, W // 8, generator=g) < 0.05] = 255
-        return imgs, tgt.cuda()
-    imgs, target = make()
-    imgs_s, target_s = make()
-    for _ in range(args.warmup):
-        stepper.step(imgs, target, imgs_s, target_s)
-    barrier(world)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, loss_arch = stepper.step(imgs, target, imgs_s, target_s)
-    barrier(world)
-    elapsed = max_over_ranks(time.perf_counter() - t0, world)
-    ips = world * batch * args.steps / elapsed
-    name = "supernet pretrain step (BASELINE configs[2])" if pretrain else "architecture-search step: arch update + weight update (BASELINE configs[4])"
-    return {
-        "metric": "supernet train-step images/sec @1024x2048 (1/2/4/8 GPU) + student fps",
-        "value": round(ips, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.dtype, "data": "synthetic",
-        "precision": ("bf16 activations + bf16 MFMA, fp32 accumulate / BN statistics / master weights / parameter gradients"
-                      if args.dtype == "bf16" else "fp32 storage, exact-fp32 MFMA"),
-        "config": {"workload": "%s: %d x 3x%dx%d per GPU, F12.L16, widths {4,6,8,10,12}/12, all 5 primitives per MixedOp, "
-                               "fwd+bwd, clip 5, SGD" % (name, batch, H, W),
-                   "global_batch": world * batch, "parallelism": "dp%d, flat fp32 gradient buckets all-reduced over RCCL" % world},
-        "final_loss": float(loss), "arch_loss": None if loss_arch is None else float(loss_arch),
-    }

@@ -290,6 +290,22 @@ fs_status fs_kl_distill_fwd(void* stream, const float* student, const float* tea
 fs_status fs_kl_distill_bwd(void* stream, const float* student, const float* teacher, const float* lse_s, const float* lse_t,
                             const float* scale, long long B, int C, long long HW, float* d_student);
 
+/* --- launch census (measurement support) ------------------------------------------------------------ */
+/* While enabled, every convolution launched through this ABI is counted by geometry (family + descriptor); launches
+ * issued during hipGraph capture are counted once, i.e. per replay.  bench.py times each counted shape alone with HIP
+ * events and reports the step's dominant kernel against its roofline (DESIGN.md "What the numbers are computed from"). */
+#define FS_CENSUS_CONV_IGEMM 0      /* fs_conv2d_fwd[_ws]: forward and data-gradient convolutions; +FS_CENSUS_STATS with BN partials */
+#define FS_CENSUS_CONV_HALO  1      /* fs_conv3x3_s1_fwd */
+#define FS_CENSUS_WGRAD      2      /* fs_conv2d_wgrad[_strided] */
+#define FS_CENSUS_STATS      0x100
+typedef struct fs_census_entry {
+    int family;
+    fs_conv_desc desc;
+    long long count;
+} fs_census_entry;
+void fs_census_enable(int on);                                   /* 1: clear and start counting, 0: stop */
+int fs_census_read(fs_census_entry* out, int max_entries);      /* fills up to max_entries, returns the number of distinct shapes */
+
 /* --- command-list executor ------------------------------------------------------------------------ */
 /* Replays a pre-built sequence of the launches above from one host call (csrc/program.hip describes the word encoding).
  * A supernet MixedOp (model_search.py:46-99) with given widths is a fixed sequence of ~60 launches forward and ~90

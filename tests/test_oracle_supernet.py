@@ -1,0 +1,56 @@
+"""Pins oracle/ref_supernet.py (the CPU restatement of search/model_search.py used by bench.py's cpu_baseline and by the
+full-size supernet checks) to the fixtures oracle/make_golden.py generated from the unmodified reference."""
+import numpy as np
+import torch
+
+from oracle import ref_supernet
+from oracle.seeded import seeded_input, seeded_state
+from tests._util import assert_close_golden, golden_get, load_json, load_npz
+
+WML = [4. / 12, 6. / 12, 8. / 12, 10. / 12, 1.]
+CFG = dict(layers=6, Fch=12, width_mult_list=WML, prun_modes=['max', 'arch_ratio'], stem_head_width=[(1, 1), (8. / 12, 8. / 12)])
+
+
+def _params(requires_grad=False):
+    meta = load_json("supernet_meta.json")
+    sd = seeded_state({k: torch.empty(v) for k, v in meta["state_shapes"].items()}, 777)
+    for k in list(sd):
+        if k.split("_")[0] in ("alpha", "beta", "ratio"):
+            sd[k] = sd[k] * 5.0
+    if requires_grad:
+        for k, v in sd.items():
+            if v.is_floating_point() and not k.endswith(("running_mean", "running_var")):
+                v.requires_grad_(True)
+    return sd
+
+
+def test_oracle_supernet_eval_logits_match_reference():
+    store = load_npz("supernet.npz")
+    params = _params()
+    x = seeded_input((2, 3, 128, 256), 31)
+    for idx in (0, 1):
+        with torch.no_grad():
+            preds = ref_supernet.forward(params, CFG, x, idx, "max", training=False)
+        for i, p in enumerate(preds):
+            assert_close_golden(p[:, :, ::4, ::4], store, "eval_arch%d/pred%d_sub" % (idx, i), 2e-5, 1e-5, "arch%d pred%d" % (idx, i))
+
+
+def test_oracle_supernet_losses_and_gradients_match_reference():
+    store = load_npz("supernet.npz")
+    x = seeded_input((2, 3, 128, 256), 31)
+    target = torch.tensor(store["target"])
+    for mode in ("pretrain", "search"):
+        params = _params(requires_grad=True)
+        np.random.seed(5)
+        torch.manual_seed(6)
+        loss = ref_supernet.loss(params, CFG, x, target, mode == "pretrain")
+        loss.backward()
+        want = float(store["%s_f32/loss" % mode][0])
+        assert abs(float(loss.detach()) - want) <= 2e-5 * abs(want), (mode, float(loss.detach()), want)
+        for key in store:
+            if key.startswith("%s_f32/g/" % mode):
+                pname = key[len("%s_f32/g/" % mode):].split("@")[0]
+                want_g, step = golden_get(store, "%s_f32/g/%s" % (mode, pname))
+                got = params[pname].grad.reshape(-1)[::step].numpy()
+                denom = float(np.abs(want_g).max()) + 1e-12
+                assert float(np.abs(got - want_g.reshape(-1)).max()) <= 2e-3 * denom, (mode, pname)
