@@ -32,20 +32,23 @@ def compute_latency_ms_hip(model, input_size, iterations=None, device=None, grap
             model(x)
         run = lambda: model(x)
         if graph:
+            # A table must not mix device-time entries with entries that include Python dispatch: if the forward cannot be
+            # captured the measurement FAILS (ask for graph=False explicitly to get the eager number).
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
             try:
-                torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                side = torch.cuda.Stream()
-                side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
                     model(x)
                     with torch.cuda.graph(g, stream=side):
                         model(x)
-                torch.cuda.current_stream().wait_stream(side)
-                run = g.replay
-            except Exception:      # capture is an optimisation of the timer, never of the result
+            except Exception as e:
                 torch.cuda.synchronize()
-                run = lambda: model(x)
+                raise RuntimeError("compute_latency_ms_hip: forward of %s is not hipGraph-capturable (%s); pass graph=False for an "
+                                   "eager, dispatch-inclusive timing" % (type(model).__name__, e)) from e
+            torch.cuda.current_stream().wait_stream(side)
+            run = g.replay
         for _ in range(10):        # warm-up, darts_utils.py:141-142,194-195
             run()
         torch.cuda.synchronize()

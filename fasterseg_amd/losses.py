@@ -27,11 +27,10 @@ class _OhemCE(torch.autograd.Function):
         valid = tgt.ne(ignore)
         num_valid = valid.sum()
         kept = valid
-        if min_kept > 0 or thresh < 1.0:
+        if min_kept > 0:        # the reference builds kept_mask only inside `if self.min_kept > 0` (loss_opr.py:80-86)
             threshold = torch.full((), float(thresh), dtype=torch.float32, device=pred.device)
-            if min_kept > 0:
-                kth = torch.sort(true_prob).values[min(P, min_kept) - 1]
-                threshold = torch.maximum(threshold, kth)
+            kth = torch.sort(true_prob).values[min(P, min_kept) - 1]
+            threshold = torch.maximum(threshold, kth)
             # OHEM only applies when enough valid pixels exist (loss_opr.py:74-76); decided on the device, no host sync
             apply = (num_valid >= min_kept) & (num_valid > 0)
             kept = valid & (true_prob.le(threshold) | ~apply)
@@ -80,15 +79,15 @@ class ProbOhemCrossEntropy2d(nn.Module):
                 prob = F.softmax(pred, dim=1).transpose(0, 1).reshape(c, -1)
                 true_prob = prob.gather(0, flat.unsqueeze(0)).squeeze(0).masked_fill(~valid, 1)
                 threshold = self.thresh
-                if self.min_kept > 0:
+                if self.min_kept > 0:       # no mask at all when min_kept == 0 (loss_opr.py:80-86)
                     # k-th smallest probability = sorted[min_kept-1] (the reference argsorts, loss_opr.py:82-83); a device
                     # radix sort is ~30x faster than torch.kthvalue at 6.3 M pixels on ROCm
                     kth = torch.sort(true_prob).values[min(true_prob.numel(), self.min_kept) - 1]
                     if float(kth) > self.thresh:
                         threshold = kth
-                kept = true_prob.le(threshold)
-                flat = flat * kept.long()
-                valid = valid & kept
+                    kept = true_prob.le(threshold)
+                    flat = flat * kept.long()
+                    valid = valid & kept
         flat = flat.masked_fill(~valid, self.ignore_label)
         return self.criterion(pred, flat.view(b, h, w))
 

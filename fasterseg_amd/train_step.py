@@ -175,11 +175,19 @@ class SupernetStep:
             else:
                 self._zero_arch_grads()
         fresh()
+        # the warm-up pass is plumbing (allocator, pack caches), not a training step: BatchNorm running statistics and
+        # num_batches_tracked are put back afterwards so that capture costs no extra momentum update (the reference runs
+        # every pass exactly once per step)
+        buffers = [b_ for b_ in self.model.buffers()]
+        saved = [b_.clone() for b_ in buffers]
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):                      # warm-up on the capture stream (allocator, pack caches)
+        with torch.cuda.stream(side):                      # warm-up on the capture stream
             self._run_pass(spec, imgs, target).backward()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        with torch.no_grad():
+            for b_, s_ in zip(buffers, saved):
+                b_.copy_(s_)
         fresh()
         g = torch.cuda.CUDAGraph()
         from . import kernels as K

@@ -77,3 +77,46 @@ def test_missing_library_fails_loudly(tmp_path):
             "try:\n    L.lib()\nexcept ImportError as e:\n    print('LOUD', e)\n")
     out = subprocess.run(["python", "-c", code], capture_output=True, text=True, cwd=ROOT)
     assert "LOUD" in out.stdout and "no CPU/eager fallback" in out.stdout
+
+
+def test_integration_doc_binds_the_same_conv_descriptor():
+    """INTEGRATION.md section 2 shows a maintainer how to bind fs_conv_desc by hand: its field list must be the header's
+    (a short struct makes the kernel read stack garbage as filter strides)."""
+    import re
+    from fasterseg_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    block = re.search(r"class fs_conv_desc\(ctypes.Structure\):.*?_fields_ = \[\(n, ctypes.c_int\) for n in \((.*?)\)\]", doc, re.S)
+    assert block, "INTEGRATION.md no longer shows the fs_conv_desc binding"
+    fields = re.findall(r'"(\w+)"', block.group(1))
+    assert fields == [n for n, _ in _lib.ConvDesc._fields_]
+    header = open(os.path.join(root, "include", "fasterseg_hip.h")).read()
+    struct = re.search(r"typedef struct fs_conv_desc \{(.*?)\} fs_conv_desc;", header, re.S).group(1)
+    struct = re.sub(r"/\*.*?\*/", "", struct, flags=re.S)
+    names = [n.strip() for decl in re.findall(r"int ([^;]+);", struct) for n in decl.split(",")]
+    assert names == fields
+    sections = [int(m) for m in re.findall(r"^## (\d+)\.", doc, re.M)]
+    assert sections == list(range(1, len(sections) + 1)), "section numbering of INTEGRATION.md"
+
+
+def test_product_does_not_reach_into_tests_or_fixtures():
+    """Nothing under fasterseg_amd/ may open files of tests/ (golden fixtures are reference-held data for the checker)."""
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fasterseg_amd")
+    bad = []
+    for dirpath, _, files in os.walk(root):
+        for fn in files:
+            if fn.endswith(".py"):
+                src = open(os.path.join(dirpath, fn)).read()
+                for m in re.finditer(r"""["'](tests|golden)["']|tests[/\\]golden|latency_lut_1080ti""", src):
+                    bad.append((fn, m.group(0)))
+    assert not bad, bad
+
+
+def test_library_reports_the_abi_the_bindings_expect():
+    from fasterseg_amd import _lib
+    h = _lib.lib()
+    assert h.fs_version() == _lib.EXPECTED_ABI
+    for which, struct in enumerate((_lib.ConvDesc, _lib.ResizeDesc, _lib.ZoomDesc, _lib.SgdTensor)):
+        assert h.fs_struct_size(which) == __import__("ctypes").sizeof(struct)
+    assert h.fs_struct_size(99) == -1

@@ -24,3 +24,17 @@ def test_distill_kl_is_torch_kldivloss():
     s, t = torch.randn(2, 19, 6, 8, generator=g), torch.randn(2, 19, 6, 8, generator=g)
     want = torch.nn.KLDivLoss()(torch.softmax(s, 1).log(), torch.softmax(t, 1))
     assert torch.allclose(distill_kl(s, t), want, atol=1e-6)
+
+
+def test_ohem_with_min_kept_zero_is_plain_cross_entropy():
+    """The reference only builds its keep-mask inside `if self.min_kept > 0` (tools/seg_opr/loss_opr.py:80-86): with
+    min_kept == 0 every valid pixel contributes, whatever `thresh` is."""
+    import torch
+    from fasterseg_amd.losses import ProbOhemCrossEntropy2d
+    g = torch.Generator().manual_seed(3)
+    pred = torch.randn(2, 19, 8, 12, generator=g) * 3
+    target = torch.randint(0, 19, (2, 8, 12), generator=g)
+    target[0, :2] = 255
+    got = ProbOhemCrossEntropy2d(ignore_label=255, thresh=0.3, min_kept=0)(pred, target)
+    want = torch.nn.functional.cross_entropy(pred, target, ignore_index=255)
+    assert abs(float(got) - float(want)) < 1e-6
