@@ -90,6 +90,48 @@ def branch_lanes(stream):
     return lanes
 
 
+# One level up, all MixedOps of a layer (up to 3 scales x {from-down, from-keep} x {_op, downsample} = 12) only depend on the
+# previous layer: under capture the primitives of ALL of them fork from the capturing stream at once (one flat fork / join
+# per layer over a pool of 20 streams - 60 measured slower; nested forks - a lane forking its own lanes - crash hipStreamEndCapture on ROCm 7.2),
+# so a layer's critical path is one primitive chain instead of twelve MixedOps in a row.  FS_LAYER_LANES=1 disables it.
+_LAYER_LANES = int(os.environ.get("FS_LAYER_LANES", "20"))
+_task_pool = {}
+
+
+def layer_lanes(stream):
+    """Side streams for the primitives of one layer (create BEFORE capturing on `stream`)."""
+    key = (stream.device, stream.cuda_stream)
+    pool = _task_pool.get(key)
+    if pool is None:
+        pool = _task_pool[key] = [torch.cuda.Stream(device=stream.device) for _ in range(max(0, _LAYER_LANES - 1))]
+    return pool
+
+
+def _run_tasks(tasks):
+    """tasks: [(mixed_op, x, alpha, ratios)] -> outputs.  While capturing, every primitive of every task runs on its own
+    stream; the alpha-weighted sums follow on the capturing stream after the join."""
+    if not (_LAYER_LANES > 1 and len(tasks) > 1 and tasks[0][1].is_cuda and torch.cuda.is_current_stream_capturing()):
+        return [op(x, alpha, ratios) for op, x, alpha, ratios in tasks]
+    main = torch.cuda.current_stream()
+    pool = layer_lanes(main)
+    used, slot, pending = [], 0, []
+    for op, x, alpha, ratios in tasks:
+        coef = op._coefficients(x, alpha, ratios)          # also selects the widths of the five primitives
+        outs = []
+        for prim in op._ops:
+            lane = pool[slot % len(pool)]
+            slot += 1
+            if lane not in used:
+                lane.wait_stream(main)                     # fork: the previous layer's outputs are complete on `main`
+                used.append(lane)
+            with torch.cuda.stream(lane):
+                outs.append(prim(x))
+        pending.append((outs, coef))
+    for lane in used:
+        main.wait_stream(lane)                             # one join per layer
+    return [FN.weighted_sum(outs, coef) for outs, coef in pending]
+
+
 def _run_branches(ops, x):
     main = torch.cuda.current_stream()
     lanes = branch_lanes(main)
@@ -126,10 +168,13 @@ class MixedOp(nn.Module):
         for op in self._ops:
             op.set_ratio(ratio)
 
-    def forward(self, x, weights, ratios):
+    def _coefficients(self, x, weights, ratios, widths=None):
+        """Selects the widths (set_prun_ratio) and returns the five coefficients w_k * r_score0 * r_score1 (reference :64-78)."""
         ratio0, r_score0 = _width_and_score(ratios[0], self._width_mult_list)
         ratio1, r_score1 = _width_and_score(ratios[1], self._width_mult_list)
         self.set_prun_ratio((ratio0, ratio1))
+        if widths is not None:
+            widths[:] = [ratio0, ratio1]
         coef = weights                                 # sum_k w_k * r_score0 * r_score1 * op_k(x), reference :76-78
         if not torch.is_tensor(coef):
             coef = torch.stack([torch.as_tensor(w, dtype=torch.float32, device=x.device).reshape(()) for w in coef])
@@ -137,6 +182,12 @@ class MixedOp(nn.Module):
             coef = coef * r_score0
         if torch.is_tensor(r_score1):
             coef = coef * r_score1
+        return coef
+
+    def forward(self, x, weights, ratios):
+        widths = [None, None]
+        coef = self._coefficients(x, weights, ratios, widths)
+        ratio0, ratio1 = widths
         if x.is_cuda and torch.cuda.is_current_stream_capturing():
             if _BRANCH_LANES > 1:
                 return FN.weighted_sum(_run_branches(self._ops, x), coef)
@@ -363,23 +414,39 @@ class Network_Multi_Path(nn.Module):
         out_prev = [[stem(input), None]]  # stem: one cell
         # i: layer | j: scale
         for i, cells in enumerate(self.cells):
-            out = []
+            # every MixedOp evaluation of this layer (reference :303-333: cell(out_prev[..], alpha, ratio) = its `_op` and,
+            # if the cell can down-sample, its `downsample`), listed first and run together (see _run_tasks)
+            tasks, slots = [], []
             for j, cell in enumerate(cells):
                 alpha = alphas[j][i - j]
                 ratio = self._cell_ratio(i, j, ratios)
-                # out,down -- 0: from down; 1: from keep
+                assert (cell._down and (ratio[2] is not None)) or ((not cell._down) and (ratio[2] is None))
+                # sources -- 0: from down; 1: from keep
                 if j == 0:
-                    out.append(cell(out_prev[0][0], alpha, ratio))
+                    srcs = [(1, out_prev[0][0])]
                 elif i == j:
-                    out.append(cell(out_prev[j - 1][1], alpha, ratio))
+                    srcs = [(0, out_prev[j - 1][1])]
                 else:
-                    out0 = down0 = out1 = down1 = None
-                    if beta_pos[j][i - j - 1][0]:
-                        out0, down0 = cell(out_prev[j - 1][1], alpha, ratio)
+                    srcs = [(0, out_prev[j - 1][1])] if beta_pos[j][i - j - 1][0] else []
                     if beta_pos[j][i - j - 1][1]:
-                        out1, down1 = cell(out_prev[j][0], alpha, ratio)
+                        srcs.append((1, out_prev[j][0]))
+                for tag, x in srcs:
+                    tasks.append((cell._op, x, alpha, (ratio[0], ratio[1])))
+                    slots.append((j, tag, 0))
+                    if cell._down:
+                        tasks.append((cell.downsample, x, alpha, (ratio[0], ratio[2])))
+                        slots.append((j, tag, 1))
+            res = dict(zip(slots, _run_tasks(tasks)))
+            out = []
+            for j, cell in enumerate(cells):
+                if j == 0:
+                    out.append((res[(0, 1, 0)], res.get((0, 1, 1))))
+                elif i == j:
+                    out.append((res[(j, 0, 0)], res.get((j, 0, 1))))
+                else:
                     b = betas[j][i - j - 1]
-                    out.append((_weighted_sum(b, [out0, out1]), _weighted_sum(b, [down0, down1])))
+                    out.append((_weighted_sum(b, [res.get((j, 0, 0)), res.get((j, 1, 0))]),
+                                _weighted_sum(b, [res.get((j, 0, 1)), res.get((j, 1, 1))])))
             out_prev = out
         ###################################
         up2 = lambda t: FN.interpolate(t, scale_factor=2)

@@ -216,6 +216,7 @@ class SupernetStep:
         from . import model_search
         side = torch.cuda.Stream()
         model_search.branch_lanes(side)           # MixedOp forks its five primitives onto these inside the capture
+        model_search.layer_lanes(side)            # ... and the MixedOps of a layer fork onto these
         state = (self.model.arch_idx, self.model.prun_mode)
         for phase in self.static:
             self._set_phase(phase)

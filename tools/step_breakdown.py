@@ -4,7 +4,10 @@ import json, os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from fasterseg_amd.train_step import SupernetStep
 from fasterseg_amd import kernels as K
-lut = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden', 'latency_lut_1080ti.json')))
+from fasterseg_amd import latency_lookup_table
+lut = latency_lookup_table.load_shipped('bf16')
+DT = torch.bfloat16 if os.environ.get('FS_BREAKDOWN_DTYPE', 'bf16') == 'bf16' else torch.float32
+ONLY = os.environ.get('FS_BREAKDOWN_ONLY', '')
 
 def sync():
     torch.cuda.synchronize(); return time.perf_counter()
@@ -14,11 +17,16 @@ def make(b, h, w, seed):
     return torch.randn(b, 3, h, w, generator=g).cuda(), torch.randint(0, 19, (b, h // 8, w // 8), generator=g).cuda()
 
 for pretrain in (True, False):
-    st = SupernetStep(pretrain=pretrain, lut=None if pretrain else lut)
+    if ONLY and ONLY != ('pretrain' if pretrain else 'search'):
+        continue
+    st = SupernetStep(pretrain=pretrain, lut=None if pretrain else lut, compute_dtype=DT)
     b, h, w = (3, 256, 512) if pretrain else (2, 224, 448)
     imgs, tgt = make(b, h, w, 1); imgs_s, tgt_s = make(b, h, w, 2)
+    from fasterseg_amd import functional as FN
+    FN.set_compute_dtype(DT)
     for _ in range(2):
         st.step(imgs, tgt, imgs_s, tgt_s)
+    FN.set_compute_dtype(DT)
     T = {}
     def timed(name, fn):
         t0 = sync(); r = fn(); T[name] = T.get(name, 0) + (sync() - t0) * 1e3; return r
@@ -31,12 +39,7 @@ for pretrain in (True, False):
                 timed("%s graph %s" % (ph, spec), g.replay)
                 if touched is not None: st.sync.mark_touched(touched)
             else:
-                if ph == "w" and not pretrain:
-                    import cProfile, pstats
-                    pr = cProfile.Profile(); pr.enable()
                 loss = timed("%s eager fwd %s" % (ph, spec), lambda: st._run_pass(spec, im, tg))
-                if ph == "w" and not pretrain:
-                    pr.disable(); pstats.Stats(pr).sort_stats('tottime').print_stats(30)
                 timed("%s eager bwd %s" % (ph, spec), loss.backward)
     t_all = sync()
     if not pretrain:
