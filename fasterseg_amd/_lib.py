@@ -51,6 +51,8 @@ SIGNATURES = {
     "fs_zoom_cell_fwd": [c_vp, ctypes.POINTER(ZoomDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "fs_conv_stem_fwd": [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int],
     "fs_bilinear_fwd": [c_vp, ctypes.POINTER(ResizeDesc), c_vp, c_vp],
+    "fs_bilinear_argmax": [c_vp, ctypes.POINTER(ResizeDesc), c_vp, c_vp],
+    "fs_hist_info": [c_vp, c_vp, c_vp, c_int, c_ll, c_int, c_vp, c_vp],
     "fs_bilinear_bwd": [c_vp, ctypes.POINTER(ResizeDesc), c_vp, c_vp, c_vp],
     "fs_bilinear_bwd_nchw": [c_vp, ctypes.POINTER(ResizeDesc), c_vp, c_vp, c_vp],
     "fs_bn_finalize": [c_vp, c_int, c_ll, c_vp, c_vp, c_vp, c_float, c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],

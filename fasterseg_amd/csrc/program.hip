@@ -200,6 +200,10 @@ extern "C" fs_status fs_exec_program_streams(void* const* streams, int n_streams
                 NEED(7);
                 st = fs_conv3x3_s1_fwd(stream, (const fs_conv_desc*)P(0), P(1), P(2), PF(3), PF(4), P(5), PF(6));
                 break;
+            case FS_OP_BILINEAR_ARGMAX:
+                NEED(3);
+                st = fs_bilinear_argmax(stream, (const fs_resize_desc*)P(0), P(1), (unsigned char*)P(2));
+                break;
             case FS_OP_ZOOM_CELL:
                 NEED(9);
                 st = fs_zoom_cell_fwd(stream, (const fs_zoom_desc*)P(0), P(1), P(2), PF(3), PF(4), P(5), PF(6), PF(7), P(8));

@@ -68,12 +68,17 @@ class _Tracer:
 
 class InferenceEngine:
     def __init__(self, net, input_shape, dtype=torch.bfloat16, logits_dtype=torch.float32, device="cuda", use_graph=True,
-                 halo_min_pixels=16384, lanes=3, fuse_cells=None):
+                 halo_min_pixels=16384, lanes=3, fuse_cells=None, output="logits"):
         assert not net.training, "call net.eval() first"
         self.dtype = dtype
         self.device = torch.device(device)
         self.input_shape = tuple(input_shape)
         self.logits_dtype = logits_dtype
+        # "logits": contiguous NCHW logits at input resolution (what Network_Multi_Path_Infer.forward returns, model_seg.py:365);
+        # "classes": uint8 (N, H, W) class map - the final up-sample and the evaluator's arg-max (evaluator.py:223) in one
+        # launch, so a validation frame writes 2 MB instead of 159 MB
+        assert output in ("logits", "classes")
+        self.output_mode = output
         self.vec = K.vec_of(dtype)
         # 3x3/s1 layers with at least this many output pixels run on the LDS-halo kernel (conv3x3_halo.hip)
         self.halo_min_pixels = int(os.environ.get("FS_HALO_MIN_PIXELS", halo_min_pixels))
@@ -279,6 +284,12 @@ class InferenceEngine:
             if out.storage is not None or op.get("dead"):
                 continue
             N, C, H, W = out.shape
+            if out.nchw and self.output_mode == "classes":
+                t = torch.empty((N, H, W), dtype=torch.uint8, device=self.device)
+                self._keep.append(t)
+                self.buffers["out%d" % idx] = t
+                out.storage = ("out%d" % idx, 0)
+                continue
             if out.nchw:
                 t = torch.empty((N, C, H, W), dtype=self.logits_dtype, device=self.device)
                 self._keep.append(t)
@@ -527,9 +538,14 @@ class InferenceEngine:
                 d = ResizeDesc(N, Hi, Wi, Ho, Wo, C, x_cs, y_cs, K.dtype_code(self.dtype), int(op["relu"]), onchw)
                 self._keep.append(d)
                 args = (ctypes.byref(d), ctypes.c_void_p(xp), ctypes.c_void_p(yp))
-                self.calls.append(dict(fn="fs_bilinear_fwd", args=args, desc=d, family="resize_nchw" if onchw else "resize", flops=0.0,
-                                       bytes=es * N * Hi * Wi * C + out_es * N * Ho * Wo * C,
-                                       label="resize %dx%d->%dx%d C%d%s" % (Hi, Wi, Ho, Wo, C, " nchw" if onchw else "")))
+                if op["out_nchw"] and self.output_mode == "classes":
+                    self.calls.append(dict(fn="fs_bilinear_argmax", args=args, desc=d, family="resize_argmax", flops=0.0,
+                                           bytes=es * N * Hi * Wi * C + N * Ho * Wo,
+                                           label="resize %dx%d->%dx%d C%d + argmax -> uint8" % (Hi, Wi, Ho, Wo, C)))
+                else:
+                    self.calls.append(dict(fn="fs_bilinear_fwd", args=args, desc=d, family="resize_nchw" if onchw else "resize",
+                                           flops=0.0, bytes=es * N * Hi * Wi * C + out_es * N * Ho * Wo * C,
+                                           label="resize %dx%d->%dx%d C%d%s" % (Hi, Wi, Ho, Wo, C, " nchw" if onchw else "")))
             elif kind == "cat":
                 for s, off in self.copies.get(idx, []):
                     N, C, H, W = s.shape
@@ -658,7 +674,7 @@ class InferenceEngine:
             main.wait_event(ev)
 
     # ---- 4b. the plan as one multi-stream launch program (fs_exec_program_streams) ---------------------------------
-    _OPS = {"fs_zoom_cell_fwd": "OP_ZOOM_CELL", "fs_conv2d_fwd_ws": "OP_CONV_FWD", "fs_conv2d_fwd": "OP_CONV_FWD", "fs_conv3x3_s1_fwd": "OP_CONV3X3_S1",
+    _OPS = {"fs_bilinear_argmax": "OP_BILINEAR_ARGMAX", "fs_zoom_cell_fwd": "OP_ZOOM_CELL", "fs_conv2d_fwd_ws": "OP_CONV_FWD", "fs_conv2d_fwd": "OP_CONV_FWD", "fs_conv3x3_s1_fwd": "OP_CONV3X3_S1",
             "fs_conv_stem_fwd": "OP_STEM", "fs_bilinear_fwd": "OP_BILINEAR_FWD", "fs_copy_channels": "OP_COPY_CHANNELS"}
 
     def _build_program(self):

@@ -33,7 +33,7 @@ _ALIGN = 256
 
 (OP_MEMSET, OP_PACK_WEIGHT, OP_CONV_FWD, OP_UNIT_FWD, OP_UNIT_BWD, OP_WGRAD_STRIDED, OP_CHANNEL_STATS, OP_BN_FINALIZE,
  OP_AFFINE_ACT, OP_BN_BWD_REDUCE, OP_BN_BWD_APPLY, OP_BILINEAR_FWD, OP_BILINEAR_BWD, OP_WSUM, OP_WSUM_BWD, OP_WSUM_DOTS,
- OP_AXPY, OP_CONV3X3_S1, OP_STEM, OP_COPY_CHANNELS, OP_EVENT_RECORD, OP_EVENT_WAIT, OP_ZOOM_CELL) = range(23)      # enum in include/fasterseg_hip.h
+ OP_AXPY, OP_CONV3X3_S1, OP_STEM, OP_COPY_CHANNELS, OP_EVENT_RECORD, OP_EVENT_WAIT, OP_ZOOM_CELL, OP_BILINEAR_ARGMAX) = range(24)      # enum in include/fasterseg_hip.h
 
 
 class Ref:

@@ -290,6 +290,20 @@ fs_status fs_kl_distill_fwd(void* stream, const float* student, const float* tea
 fs_status fs_kl_distill_bwd(void* stream, const float* student, const float* teacher, const float* lse_s, const float* lse_t,
                             const float* scale, long long B, int C, long long HW, float* d_student);
 
+/* --- evaluation on the device ------------------------------------------ */
+/* Class map straight from the 1/8-resolution logits: bilinear (align_corners=True) up-sample to (Ho, Wo) evaluated on the
+ * fly + arg-max over the C classes -> uint8 (N, Ho, Wo).  Replaces exp() + device-to-host copy of the (19, 1024, 2048) fp32
+ * score map + np.argmax in the reference evaluator (tools/engine/evaluator.py:205-225,297-318; exp is monotone).
+ * x: NHWC logits with channel stride d->x_cs (a multiple of 4, >= C; pad lanes readable), d->Wo % 4 == 0; d->y_cs, d->relu
+ * and d->out_nchw are ignored.  Ties: the lowest class index wins, as np.argmax. */
+fs_status fs_bilinear_argmax(void* stream, const fs_resize_desc* d, const void* x, unsigned char* classes);
+/* hist_info of tools/seg_opr/metric.py:7-17 on the device: over the n pixels with 0 <= gt < n_cl,
+ * hist[n_cl * gt + pred] += 1, counts[0] += 1 (labeled), counts[1] += (pred == gt) (correct).  gt is uint8 / int32 / int64
+ * (gt_bytes = 1 / 4 / 8; 255 or -1 = ignore); hist (n_cl * n_cl) and counts (2) are uint64 accumulators the caller zeroes
+ * once per evaluation run.  Integer atomics: bit-exact with np.bincount. */
+fs_status fs_hist_info(void* stream, const unsigned char* pred, const void* gt, int gt_bytes, long long n, int n_cl,
+                       unsigned long long* hist, unsigned long long* counts);
+
 /* --- launch census (measurement support) ------------------------------------------------------------ */
 /* While enabled, every convolution launched through this ABI is counted by geometry (family + descriptor); launches
  * issued during hipGraph capture are counted once, i.e. per replay.  bench.py times each counted shape alone with HIP
@@ -337,6 +351,7 @@ enum {
     FS_OP_EVENT_RECORD,      /* (event)  record on the command's stream   (fs_exec_program_streams)      */
     FS_OP_EVENT_WAIT,        /* (event)  make the command's stream wait for the event                     */
     FS_OP_ZOOM_CELL,         /* fs_zoom_cell_fwd */
+    FS_OP_BILINEAR_ARGMAX,   /* fs_bilinear_argmax */
     FS_OP_COUNT
 };
 fs_status fs_exec_program(void* stream, const long long* words, long long n_words, const unsigned char* blob,

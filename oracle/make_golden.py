@@ -421,12 +421,33 @@ def gen_supernet():
         json.dump(meta, f)
 
 
+# 8. evaluation metrics (tools/seg_opr/metric.py is pure numpy and imports unmodified)
+def gen_eval():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_metric", os.path.join(ref_loader.REFERENCE_ROOT, "tools", "seg_opr", "metric.py"))
+    metric = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(metric)
+    rng = np.random.RandomState(11)
+    store = {}
+    for name, shape in (("a", (64, 96)), ("b", (128, 256))):
+        gt = rng.randint(0, 19, size=shape).astype(np.int64)
+        gt[rng.rand(*shape) < 0.07] = 255                       # Cityscapes ignore label
+        pred = np.where(rng.rand(*shape) < 0.6, gt.clip(0, 18), rng.randint(0, 19, size=shape)).astype(np.uint8)
+        hist, labeled, correct = metric.hist_info(19, pred, gt)
+        iu, miou, miou_nb, acc = metric.compute_score(hist, correct, labeled)
+        store[name + "/gt"], store[name + "/pred"] = gt.astype(np.uint8), pred
+        store[name + "/hist"], store[name + "/counts"] = hist.astype(np.int64), np.array([labeled, correct], dtype=np.int64)
+        store[name + "/iu"], store[name + "/scores"] = iu, np.array([miou, miou_nb, acc])
+    np.savez_compressed(os.path.join(GOLD, "eval.npz"), **store)
+    print("eval fixtures:", sorted(store))
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(max(1, os.cpu_count() or 1))
-    which = sys.argv[1:] or ["arch", "decode", "ops", "nets", "lut", "loss", "supernet"]
+    which = sys.argv[1:] or ["arch", "decode", "ops", "nets", "lut", "loss", "supernet", "eval"]
     for w in which:
-        {"arch": gen_arch, "decode": gen_decode_cases, "ops": gen_ops, "nets": gen_nets, "lut": gen_lut, "loss": gen_loss, "supernet": gen_supernet}[w]()
+        {"arch": gen_arch, "decode": gen_decode_cases, "ops": gen_ops, "nets": gen_nets, "lut": gen_lut, "loss": gen_loss, "supernet": gen_supernet, "eval": gen_eval}[w]()
 
 
 if __name__ == "__main__":

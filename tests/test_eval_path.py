@@ -1,0 +1,141 @@
+"""Evaluation path: device-side class map + confusion histogram.
+
+CPU: oracle/ref_eval.py against fixtures produced by the reference's own tools/seg_opr/metric.py (tests/golden/eval.npz).
+GPU: fs_hist_info bit-exact against those fixtures; fs_bilinear_argmax equal to the arg-max of the logits tensor the same
+engine writes, and (where the top two classes are not within rounding of each other) to the arg-max of the CPU oracle's
+logits; the whole SegEvaluator loop on synthetic frames against the oracle's metrics."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_eval
+from tests._util import load_npz
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_oracle_metrics_match_reference_metric_py():
+    store = load_npz("eval.npz")
+    for name in ("a", "b"):
+        gt = store[name + "/gt"].astype(np.int64)
+        hist, labeled, correct = ref_eval.hist_info(19, store[name + "/pred"], gt)
+        assert (hist == store[name + "/hist"]).all()
+        assert [int(labeled), int(correct)] == store[name + "/counts"].tolist()
+        iu, miou, miou_nb, acc = ref_eval.compute_score(hist, correct, labeled)
+        np.testing.assert_array_equal(iu, store[name + "/iu"])
+        np.testing.assert_array_equal(np.array([miou, miou_nb, acc]), store[name + "/scores"])
+
+
+def test_product_compute_score_matches_reference():
+    from fasterseg_amd import metric
+    store = load_npz("eval.npz")
+    for name in ("a", "b"):
+        c = store[name + "/counts"]
+        iu, miou, miou_nb, acc = metric.compute_score(store[name + "/hist"], int(c[1]), int(c[0]))
+        np.testing.assert_allclose(iu, store[name + "/iu"], rtol=0, atol=0)
+        np.testing.assert_allclose(np.array([miou, miou_nb, acc]), store[name + "/scores"], rtol=0, atol=0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("label_dtype", [torch.uint8, torch.int32, torch.int64])
+def test_hist_info_bit_exact(label_dtype):
+    from fasterseg_amd import metric
+    store = load_npz("eval.npz")
+    for name in ("a", "b"):
+        gt = torch.tensor(store[name + "/gt"].astype(np.int64))
+        if label_dtype != torch.uint8:
+            gt = torch.where(gt == 255, torch.full_like(gt, -1), gt)       # both ignore conventions: 255 and -1
+        hist, labeled, correct = metric.hist_info(19, torch.tensor(store[name + "/pred"]).cuda(), gt.to(label_dtype).cuda())
+        assert (hist == store[name + "/hist"]).all()
+        assert [labeled, correct] == store[name + "/counts"].tolist()
+    # accumulation over several images, empty input, a large map (many blocks)
+    acc = metric.HistAccumulator(19)
+    g = torch.Generator().manual_seed(1)
+    P = torch.randint(0, 19, (3, 512, 1024), generator=g, dtype=torch.uint8)
+    G = torch.randint(0, 20, (3, 512, 1024), generator=g).to(torch.uint8)
+    G[G == 19] = 255
+    for i in range(3):
+        acc.add(P[i].cuda(), G[i].cuda())
+    acc.add(P[0, :0].cuda().contiguous(), G[0, :0].cuda().contiguous())
+    hist, labeled, correct = acc.result()
+    want = ref_eval.hist_info(19, P.numpy(), G.numpy().astype(np.int64))
+    assert (hist == want[0]).all() and labeled == int(want[1]) and correct == int(want[2])
+
+
+def _student(shape):
+    from fasterseg_amd import archs
+    from oracle import ref_ops
+    from oracle.seeded import resolve_aliases, seeded_input, seeded_state
+    with open(os.path.join(ROOT, "tests", "golden", "arch_1.json")) as f:
+        meta = json.load(f)["eval_21"]
+    net = archs.build_derived(1, training=False, lasts=[2, 1])
+    state = seeded_state(net.state_dict(), 12345)
+    net.load_state_dict(state)
+    x = seeded_input(shape, 3)
+    with torch.no_grad():
+        want = ref_ops.derived_forward(resolve_aliases({k: v.clone() for k, v in state.items()}, meta), meta, x, training=False)
+    return net.cuda().eval(), x, want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("shape", [(1, 3, 1024, 2048), (2, 3, 128, 256)], ids=["1024x2048", "2x128x256"])
+def test_engine_class_map(shape, dtype):
+    from fasterseg_amd import engine
+    net, x, want = _student(shape)
+    with torch.no_grad():
+        # same (deterministic) plan for both engines: with timing-based cell selection they could differ in rounding
+        logits = engine.InferenceEngine(net, shape, dtype=dtype, fuse_cells="1")(x.cuda()).clone()
+        eng = engine.InferenceEngine(net, shape, dtype=dtype, output="classes", fuse_cells="1")
+        classes = eng(x.cuda()).clone()
+    torch.cuda.synchronize()
+    assert classes.dtype == torch.uint8 and tuple(classes.shape) == (shape[0], shape[2], shape[3])
+    assert any(c["fn"] == "fs_bilinear_argmax" for c in eng.calls) and not any(c["family"] == "resize_nchw" for c in eng.calls)
+    own = logits.argmax(1).to(torch.uint8)
+    assert torch.equal(classes, own), "class map differs from the arg-max of the engine's own logits in %d pixels" % int((classes != own).sum())
+    ref = ref_eval.class_map(want[0].numpy())
+    agree = (classes[0].cpu().numpy() == ref)
+    if dtype == torch.float32:
+        top2 = want[0].topk(2, dim=0).values
+        clear = ((top2[0] - top2[1]) > 2e-3).numpy()          # winner not within the 1e-3 logits tolerance of the runner-up
+        assert agree[clear].all(), "%d clear-cut pixels disagree with the oracle" % int((~agree[clear]).sum())
+        assert agree.mean() >= 0.9995
+    else:
+        assert agree.mean() >= 0.97                            # the engine's bf16 bar (tests/test_engine_gpu.py)
+
+
+@pytest.mark.gpu
+def test_seg_evaluator_loop_matches_oracle_metrics():
+    from fasterseg_amd.evaluator import SegEvaluator
+    from oracle import ref_ops
+    from oracle.seeded import resolve_aliases
+    shape = (1, 3, 256, 512)
+    net, _, _ = _student(shape)
+    mean, std = np.array([0.485, 0.456, 0.406]), np.array([0.229, 0.224, 0.225])           # config_train.py:44-45
+    ev = SegEvaluator(net, 19, mean, std, image_shape=(256, 512), dtype=torch.float32)
+    with open(os.path.join(ROOT, "tests", "golden", "arch_1.json")) as f:
+        meta = json.load(f)["eval_21"]
+    params = resolve_aliases({k: v.detach().cpu().clone() for k, v in net.state_dict().items()}, meta)
+    rng = np.random.RandomState(5)
+    hist = np.zeros((19, 19), dtype=np.int64)
+    labeled = correct = 0
+    for _ in range(3):
+        img = rng.randint(0, 256, size=(256, 512, 3)).astype(np.uint8)
+        label = rng.randint(0, 19, size=(256, 512)).astype(np.uint8)
+        label[rng.rand(256, 512) < 0.05] = 255
+        pred = ev.func_per_iteration({"data": img, "label": label})
+        xin = torch.tensor(((img.astype(np.float32) / 255.0 - mean) / std).transpose(2, 0, 1)[None].astype(np.float32))   # img_utils.py:178-184
+        with torch.no_grad():
+            want = ref_ops.derived_forward(params, meta, xin)[0].numpy()
+        ref_pred = ref_eval.class_map(want)
+        assert (pred.cpu().numpy() == ref_pred).mean() >= 0.999
+        h, l, c = ref_eval.hist_info(19, pred.cpu().numpy(), label.astype(np.int64))       # metrics on the SAME class map: exact
+        hist += h; labeled += int(l); correct += int(c)
+    got = ev.compute_metric()
+    assert (got["hist"] == hist).all() and got["labeled"] == labeled and got["correct"] == correct
+    iu, miou, _, acc = ref_eval.compute_score(hist, correct, labeled)
+    np.testing.assert_allclose(got["iu"], iu) and np.testing.assert_allclose(got["mean_IU"], miou)
+    assert abs(got["mean_pixel_acc"] - acc) < 1e-12
