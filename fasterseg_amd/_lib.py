@@ -26,6 +26,10 @@ class ZoomDesc(ctypes.Structure):
     _fields_ = [(n, c_int) for n in ("N", "H", "W", "Cin", "Cmid", "Cout", "h", "w", "Ho", "Wo", "x_cs", "y_cs", "dtype", "down", "up")]
 
 
+class LogitsDesc(ctypes.Structure):
+    _fields_ = [(n, c_int) for n in ("N", "h", "w", "C", "cs", "H", "W", "dtype")]
+
+
 class ResizeDesc(ctypes.Structure):
     _fields_ = [(n, c_int) for n in ("N", "Hi", "Wi", "Ho", "Wo", "C", "x_cs", "y_cs", "dtype", "relu", "out_nchw")]
 
@@ -78,6 +82,10 @@ SIGNATURES = {
     "fs_ohem_ce_fwd": [c_vp, c_vp, c_vp, c_ll, c_int, c_ll, c_int, c_vp, c_vp, c_vp],
     "fs_ohem_ce_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_int, c_ll, c_vp],
     "fs_kl_distill_fwd": [c_vp, c_vp, c_vp, c_ll, c_int, c_ll, c_vp, c_vp, c_vp],
+    "fs_ohem_ce_up_fwd": [c_vp, ctypes.POINTER(LogitsDesc), c_vp, c_vp, c_int, c_vp, c_vp, c_vp],
+    "fs_ohem_ce_up_bwd": [c_vp, ctypes.POINTER(LogitsDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "fs_kl_distill_up_fwd": [c_vp, ctypes.POINTER(LogitsDesc), c_vp, ctypes.POINTER(LogitsDesc), c_vp, c_vp, c_vp, c_vp],
+    "fs_kl_distill_up_bwd": [c_vp, ctypes.POINTER(LogitsDesc), c_vp, ctypes.POINTER(LogitsDesc), c_vp, c_vp, c_vp, c_vp, c_vp],
     "fs_kl_distill_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_int, c_ll, c_vp],
     "fs_exec_program": [c_vp, c_vp, c_ll, c_vp, c_vp, c_int],
     "fs_exec_program_streams": [c_vp, c_int, c_vp, c_ll, c_vp, c_vp, c_int],
@@ -126,7 +134,7 @@ def lib():
         if got != EXPECTED_ABI:
             raise ImportError("libfasterseg_hip.so has ABI %d, these bindings expect %d: rebuild with `python -m fasterseg_amd.build "
                               "--force`" % (got, EXPECTED_ABI))
-        for which, struct in enumerate((ConvDesc, ResizeDesc, ZoomDesc, SgdTensor)):
+        for which, struct in enumerate((ConvDesc, ResizeDesc, ZoomDesc, SgdTensor, LogitsDesc)):
             if handle.fs_struct_size(which) != ctypes.sizeof(struct):
                 raise ImportError("libfasterseg_hip.so: sizeof(%s) is %d in the library, %d in the bindings - stale build" % (
                     struct.__name__, handle.fs_struct_size(which), ctypes.sizeof(struct)))

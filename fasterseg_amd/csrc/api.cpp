@@ -27,6 +27,7 @@ extern "C" int fs_struct_size(int which) {
         case 1: return (int)sizeof(fs_resize_desc);
         case 2: return (int)sizeof(fs_zoom_desc);
         case 3: return (int)sizeof(fs_sgd_tensor);
+        case 4: return (int)sizeof(fs_logits_desc);
         default: return -1;
     }
 }

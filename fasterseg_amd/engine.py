@@ -77,7 +77,9 @@ class InferenceEngine:
         # "logits": contiguous NCHW logits at input resolution (what Network_Multi_Path_Infer.forward returns, model_seg.py:365);
         # "classes": uint8 (N, H, W) class map - the final up-sample and the evaluator's arg-max (evaluator.py:223) in one
         # launch, so a validation frame writes 2 MB instead of 159 MB
-        assert output in ("logits", "classes")
+        # "lowres": the head's logits before the final up-sample, as an NHWC view (N, C, h, w) - for consumers that evaluate
+        # the bilinear up-sample themselves (losses.distill_kl_lowres reads the teacher this way)
+        assert output in ("logits", "classes", "lowres")
         self.output_mode = output
         self.vec = K.vec_of(dtype)
         # 3x3/s1 layers with at least this many output pixels run on the LDS-halo kernel (conv3x3_halo.hip)
@@ -119,6 +121,11 @@ class InferenceEngine:
         assert isinstance(out, FN.SymTensor) and out.nchw, "network must end in the NCHW logits up-sample"
         self.ops = tracer.ops
         self.out_sym = out
+        if self.output_mode == "lowres":
+            last = self.ops[out.producer]
+            assert last["kind"] == "resize" and last["out_nchw"]
+            last["dead"] = True
+            self.out_sym = last["x"]
 
     # ---- 1a. whole zoomed-conv cells -> one fused launch ---------------------------------------------------------------
     def _consumers(self):
@@ -301,6 +308,8 @@ class InferenceEngine:
             self.buffers[bid] = self._new_buffer(N, H, W, K.round_up(C, pad_to), zero=(C % self.vec != 0))
             out.storage = (bid, 0)
         self.output = self.buffers[self.out_sym.storage[0]]
+        if self.output_mode == "lowres":
+            self.output = self.output.permute(0, 3, 1, 2)[:, :self.out_sym.shape[1]]
 
     def _ptr(self, sym):
         bid, off = sym.storage

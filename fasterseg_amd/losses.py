@@ -92,6 +92,102 @@ class ProbOhemCrossEntropy2d(nn.Module):
         return self.criterion(pred, flat.view(b, h, w))
 
 
+def _logits_desc(x, size):
+    """fs_logits_desc of a low-resolution NHWC logits view (N, C, h, w) that is to be read at resolution `size`."""
+    from . import kernels as K
+    from ._lib import LogitsDesc
+    N, C, h, w = x.shape
+    cs = K.channel_stride(x)
+    assert cs is not None and cs % 4 == 0 and cs >= ((C + 3) // 4) * 4, "logits must be an NHWC view with a channel stride padded to 4"
+    return LogitsDesc(N, h, w, C, cs, int(size[0]), int(size[1]), K.dtype_code(x.dtype))
+
+
+class _OhemCEUp(torch.autograd.Function):
+    """_OhemCE on the bilinear up-sample of low-resolution logits, without the up-sampled tensor (fs_ohem_ce_up_fwd/_bwd):
+    ProbOhemCrossEntropy2d(F.interpolate(pred_lo, size, 'bilinear', align_corners=True), target)
+    (train/model_seg.py:357-362 + tools/seg_opr/loss_opr.py:63-93)."""
+
+    @staticmethod
+    def forward(ctx, pred_lo, target, thresh, min_kept, ignore):
+        import ctypes
+        from . import kernels as K
+        B, H, W = target.shape
+        d = _logits_desc(pred_lo, (H, W))
+        P = B * H * W
+        tgt = target.reshape(-1).contiguous()
+        buf = torch.empty((3, P), dtype=torch.float32, device=pred_lo.device)
+        true_prob, nll, lse = buf[0], buf[1], buf[2]
+        x = pred_lo.detach()
+        K.call("fs_ohem_ce_up_fwd", K._stream(), ctypes.byref(d), K._p(x), K._p(tgt), int(ignore), K._p(true_prob), K._p(nll), K._p(lse))
+        valid = tgt.ne(ignore)
+        num_valid = valid.sum()
+        kept = valid
+        if min_kept > 0:
+            threshold = torch.full((), float(thresh), dtype=torch.float32, device=x.device)
+            kth = torch.sort(true_prob).values[min(P, min_kept) - 1]
+            threshold = torch.maximum(threshold, kth)
+            apply = (num_valid >= min_kept) & (num_valid > 0)
+            kept = valid & (true_prob.le(threshold) | ~apply)
+        count = kept.sum()
+        loss = (nll * kept).sum() / count
+        ctx.save_for_backward(x, tgt, lse, kept.to(torch.uint8), count)
+        ctx.desc = d
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        import ctypes
+        from . import kernels as K
+        x, tgt, lse, kept, count = ctx.saved_tensors
+        d = ctx.desc
+        scale = (g.float() / count).reshape(1).contiguous()
+        dx = K.empty_nhwc(d.N, d.C, d.h, d.w, x.dtype, x.device, cs=d.cs)
+        K.call("fs_ohem_ce_up_bwd", K._stream(), ctypes.byref(d), K._p(x), K._p(tgt), K._p(lse), K._p(kept), K._p(scale), K._p(dx))
+        return dx, None, None, None, None
+
+
+class _DistillKLUp(torch.autograd.Function):
+    """distill_kl on the up-samples of two low-resolution logit maps (student / teacher may differ in resolution and dtype)."""
+
+    @staticmethod
+    def forward(ctx, student_lo, teacher_lo, size):
+        import ctypes
+        from . import kernels as K
+        ds, dt = _logits_desc(student_lo, size), _logits_desc(teacher_lo, size)
+        P = ds.N * ds.H * ds.W
+        s, t = student_lo.detach(), teacher_lo.detach()
+        buf = torch.empty((3, P), dtype=torch.float32, device=s.device)
+        K.call("fs_kl_distill_up_fwd", K._stream(), ctypes.byref(ds), K._p(s), ctypes.byref(dt), K._p(t), K._p(buf[0]), K._p(buf[1]), K._p(buf[2]))
+        ctx.save_for_backward(s, t, buf)
+        ctx.descs = (ds, dt)
+        return buf[0].sum() / (P * ds.C)
+
+    @staticmethod
+    def backward(ctx, g):
+        import ctypes
+        from . import kernels as K
+        s, t, buf = ctx.saved_tensors
+        ds, dt = ctx.descs
+        scale = (g.float() / (ds.N * ds.H * ds.W * ds.C)).reshape(1).contiguous()
+        dx = K.empty_nhwc(ds.N, ds.C, ds.h, ds.w, s.dtype, s.device, cs=ds.cs)
+        K.call("fs_kl_distill_up_bwd", K._stream(), ctypes.byref(ds), K._p(s), ctypes.byref(dt), K._p(t), K._p(buf[1]), K._p(buf[2]),
+               K._p(scale), K._p(dx))
+        return dx, None, None
+
+
+def ohem_ce_lowres(criterion, pred_lo, target):
+    """`criterion(F.interpolate(pred_lo, target.shape[-2:], mode='bilinear', align_corners=True), target)` for a
+    ProbOhemCrossEntropy2d `criterion`, computed from the low-resolution NHWC logits (CUDA only)."""
+    assert pred_lo.is_cuda and target.dtype == torch.long and criterion.criterion.reduction == "mean"
+    return _OhemCEUp.apply(pred_lo, target, criterion.thresh, criterion.min_kept, criterion.ignore_label)
+
+
+def distill_kl_lowres(student_lo, teacher_lo, size):
+    """distill_kl(up(student_lo), up(teacher_lo)) with both bilinear up-samples to `size` evaluated inside the kernels."""
+    assert student_lo.is_cuda and not teacher_lo.requires_grad
+    return _DistillKLUp.apply(student_lo, teacher_lo, (int(size[0]), int(size[1])))
+
+
 class _DistillKL(torch.autograd.Function):
     @staticmethod
     def forward(ctx, student, teacher):

@@ -347,7 +347,13 @@ class Network_Multi_Path_Infer(nn.Module):
             return pred8, pred16, pred32
         return pred8
 
-    def forward(self, input):
+    def forward_lowres(self, input):
+        """forward() without its last line (model_seg.py:357-365): the heads' logits at 1/8, 1/16, 1/32 resolution as NHWC
+        views (channel stride 32).  For losses that evaluate the bilinear up-sample themselves (losses.ohem_ce_lowres,
+        distill_kl_lowres) instead of reading (B, 19, H, W) fp32 tensors."""
+        return self.forward(input, lowres=True)
+
+    def forward(self, input, lowres=False):
         _, _, H, W = input.size()
         stem = self.stem(input)
 
@@ -370,9 +376,11 @@ class Network_Multi_Path_Infer(nn.Module):
         up = lambda t, f: None if t is None else FN.interpolate(t, size=(int(t.size(2)) * f, int(t.size(3)) * f), out_nchw=1)
         if self.training:
             pred8, pred16, pred32 = self.agg_ffm(outputs8, outputs16, outputs32)
+            if lowres:
+                return pred8, pred16, pred32
             return up(pred8, 8), up(pred16, 16), up(pred32, 32)     # contiguous NCHW fp32 logits
         pred8 = self.agg_ffm(outputs8, outputs16, outputs32)
-        return up(pred8, 8)
+        return pred8 if lowres else up(pred8, 8)
 
     def forward_latency(self, size):
         _, H, W = size

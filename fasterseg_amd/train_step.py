@@ -18,7 +18,7 @@ from .parallel import FlatGradientSync, broadcast_parameters
 
 class StudentDistillStep:
     def __init__(self, batch, height, width, lr=0.01, momentum=0.9, weight_decay=5e-4, teacher_engine_dtype=None, seed=12345,
-                 device="cuda", compute_dtype=torch.float32):
+                 device="cuda", compute_dtype=torch.float32, fused_loss=None):
         self.device = torch.device(device)
         self.compute_dtype = compute_dtype      # activation storage / MFMA operand type; master weights, BN statistics,
         # accumulators and gradients of parameters stay fp32
@@ -31,28 +31,42 @@ class StudentDistillStep:
         self.sync = FlatGradientSync(self.student.parameters(), bucket_mb=4)      # 17.6 MB -> 5 buckets, overlapped with backward
         self.optimizer = FlatSGD(self.sync, lr, momentum, weight_decay, pack_dtype=compute_dtype)       # train/train.py:173-176
         self.lamb = 0.2
+        # loss heads straight from the 1/8 - 1/32 resolution logits (loss_up.hip): the up-sampled (B, 19, H, W) tensors of
+        # student and teacher are never materialised.  FS_FUSED_LOSS=0 keeps the up-sample + full-resolution criteria.
+        import os
+        self.fused_loss = bool(int(os.environ.get("FS_FUSED_LOSS", "1"))) if fused_loss is None else bool(fused_loss)
+        self.size = (height, width)
         self.teacher_engine = None
         if teacher_engine_dtype is not None:        # frozen teacher through the static-plan engine (hipGraph)
             from .engine import InferenceEngine
-            self.teacher_engine = InferenceEngine(self.teacher, (batch, 3, height, width), dtype=teacher_engine_dtype)
+            self.teacher_engine = InferenceEngine(self.teacher, (batch, 3, height, width), dtype=teacher_engine_dtype,
+                                                  output="lowres" if self.fused_loss else "logits")
 
     def teacher_logits(self, imgs):
         with torch.no_grad():
             if self.teacher_engine is not None:
                 return self.teacher_engine(imgs)
+            if self.fused_loss:
+                return self.teacher.forward_lowres(imgs)
             return self.teacher(imgs)
 
     def step(self, imgs, target):
         from . import functional as FN
+        from .losses import distill_kl_lowres, ohem_ce_lowres
         self.sync.prepare()
         t_logits = self.teacher_logits(imgs)
         FN.set_compute_dtype(self.compute_dtype)
         try:
-            p8, p16, p32 = self.student(imgs)
+            p8, p16, p32 = self.student.forward_lowres(imgs) if self.fused_loss else self.student(imgs)
         finally:
             FN.set_compute_dtype(torch.float32)
-        loss = self.ohem(p8, target) + self.lamb * self.ohem(p16, target) + self.lamb * self.ohem(p32, target)
-        loss = loss + distill_kl(p8, t_logits)
+        if self.fused_loss:      # train/train.py:254-260 with the x8 / x16 / x32 up-samples evaluated inside the criteria
+            loss = (ohem_ce_lowres(self.ohem, p8, target) + self.lamb * ohem_ce_lowres(self.ohem, p16, target)
+                    + self.lamb * ohem_ce_lowres(self.ohem, p32, target))
+            loss = loss + distill_kl_lowres(p8, t_logits, self.size)
+        else:
+            loss = self.ohem(p8, target) + self.lamb * self.ohem(p16, target) + self.lamb * self.ohem(p32, target)
+            loss = loss + distill_kl(p8, t_logits)
         loss.backward()
         self.sync.sync()
         self.optimizer.step()
