@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfasterseg_hip.so")
 
-EXPECTED_ABI = 200          # FS_ABI_VERSION of include/fasterseg_hip.h these bindings were written against
+EXPECTED_ABI = 201          # FS_ABI_VERSION of include/fasterseg_hip.h these bindings were written against
 FS_F32, FS_BF16 = 0, 1
 FS_CONV_RELU, FS_CONV_TRANSPOSED, FS_CONV_ACCUM = 1, 2, 4
 
@@ -19,7 +19,7 @@ c_int, c_ll, c_float, c_vp = ctypes.c_int, ctypes.c_longlong, ctypes.c_float, ct
 
 class ConvDesc(ctypes.Structure):
     _fields_ = [(n, c_int) for n in ("N", "H", "W", "Cin", "Cout", "R", "S", "stride", "pad", "Ho", "Wo",
-                                     "x_cs", "y_cs", "dtype", "flags", "w_os", "w_ts", "vr_H", "vr_W", "vr_relu")]
+                                     "x_cs", "y_cs", "dtype", "flags", "w_os", "w_ts", "vr_H", "vr_W", "vr_relu", "bn_groups")]
 
 
 class ZoomDesc(ctypes.Structure):
@@ -64,6 +64,10 @@ SIGNATURES = {
                           c_int, c_int],
     "fs_affine_act": [c_vp, c_ll, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int],
     "fs_channel_stats": [c_vp, c_ll, c_int, c_vp, c_int, c_int, c_vp],
+    "fs_bn_group_fwd": [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_float, c_float, c_vp, c_vp, c_vp, c_vp, c_vp,
+                        c_int, c_int, c_int],
+    "fs_bn_group_bwd": [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_vp,
+                        c_vp, c_vp],
     "fs_bn_bwd_reduce": [c_vp, c_ll, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_vp],
     "fs_bn_bwd_apply": [c_vp, c_ll, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_ll, c_int,
                         c_int, c_vp, c_int, c_vp, c_vp],

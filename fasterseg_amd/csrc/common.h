@@ -41,6 +41,11 @@ void census_conv(int family, const fs_conv_desc* d);
         if (fs::g_census_on) fs::census_conv((family), (d));  \
     } while (0)
 
+// fs_conv2d_fwd_ws without its split-K reduction launch: when the kernel splits K across blocks the partial slabs stay in
+// `workspace` ([*slices][M][Cout] fp32, y untouched) and the caller sums them (fs_bn_group_fwd does); *slices == 1: y is written.
+fs_status conv_fwd_deferred(void* stream, const fs_conv_desc* d, const void* x, const void* w_packed, void* y, void* workspace,
+                            long long workspace_bytes, int* slices);
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 inline int elem_size(int dtype) { return dtype == FS_BF16 ? 2 : 4; }
 inline int vec_elems(int dtype) { return 16 / elem_size(dtype); }

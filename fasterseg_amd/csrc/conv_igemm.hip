@@ -463,6 +463,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 
 constexpr long long SPLITK_TARGET_BLOCKS = 1024;
+static thread_local bool t_defer_reduce = false;     // conv_fwd_deferred(): leave the split-K slabs to the caller
+static thread_local int t_slices = 1;
 
 // Number of K slices for a 32x32-tile config with `bkt` K elements per iteration (1 = do not split).  Measured on MI355X
 // (tools/conv_sweep.py): the second launch and the partial-tile traffic only pay off when the tiles cover well under
@@ -502,6 +504,10 @@ static void launch_cfg(hipStream_t st, ConvArgs& a, float* ws = nullptr, long lo
         a.ws = ws;
         hipLaunchKernelGGL((conv_igemm_kernel<T, WAVES_M, WAVES_N, WAVES_K, WM_T, WN_T, KSUB, VRES>),
                            dim3((unsigned)(tiles_m * a.tiles_n), 1, (unsigned)slices), dim3(256), 0, st, a);
+        if (t_defer_reduce) {
+            t_slices = slices;
+            return;
+        }
         const int cv = a.Cout / Elem<T>::VEC;
         const int rpb = 256 / cv;
         int rows = ((a.M + 511) / 512 + rpb - 1) / rpb * rpb;        // ~512 blocks, whole row groups per block
@@ -557,6 +563,16 @@ template <typename T> static void dispatch(hipStream_t st, ConvArgs& a, int forc
 }  // namespace fs
 
 using namespace fs;
+
+fs_status fs::conv_fwd_deferred(void* stream, const fs_conv_desc* d, const void* x, const void* w_packed, void* y, void* workspace,
+                                long long workspace_bytes, int* slices) {
+    t_defer_reduce = true;
+    t_slices = 1;
+    const fs_status s = fs_conv2d_fwd_ws(stream, d, x, w_packed, nullptr, nullptr, y, nullptr, workspace, workspace_bytes);
+    t_defer_reduce = false;
+    *slices = t_slices;
+    return s;
+}
 
 static int g_force_cfg = -1;
 /* test hook: force a tile configuration (0..6), -1 = heuristic */

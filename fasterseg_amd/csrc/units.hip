@@ -8,6 +8,10 @@
 // accumulation all happen here or inside the kernels.
 #include "common.h"
 
+// maps up to this many pixels take the one-launch column-owner BatchNorm (bn_col.hip); larger ones (the student's 12 x 64 x 128
+// and up) keep the grid-wide passes, where one block per channel vector would leave the chip idle
+static const long long BN_COL_MAX_PIXELS = 16384;
+
 extern "C" fs_status fs_conv_bn_act_train_fwd(void* stream, const fs_conv_desc* d, const void* x, const void* w_packed,
                                               const float* gamma, const float* beta, float* running_mean,
                                               float* running_var, long long* num_batches_tracked, float eps,
@@ -15,11 +19,21 @@ extern "C" fs_status fs_conv_bn_act_train_fwd(void* stream, const fs_conv_desc* 
                                               long long workspace_bytes) {
     FS_REQUIRE(d && x && w_packed && stats && saved && z && y, FS_ERR_INVALID, "fs_conv_bn_act_train_fwd: null argument");
     fs_conv_desc c = *d;
-    c.flags &= ~FS_CONV_RELU;          // the conv writes the raw pre-normalisation map z (+ per-channel sum / sumsq)
-    fs_status s = fs_conv2d_fwd_ws(stream, &c, x, w_packed, nullptr, nullptr, z, stats, workspace, workspace_bytes);
-    if (s != FS_OK) return s;
+    c.flags &= ~FS_CONV_RELU;          // the conv writes the raw pre-normalisation map z
     const int C = d->Cout;
     const long long count = (long long)d->N * d->Ho * d->Wo;
+    const int groups = d->bn_groups > 1 ? d->bn_groups : 1;
+    FS_REQUIRE(d->N % groups == 0, FS_ERR_INVALID, "fs_conv_bn_act_train_fwd: batch %d is not %d equal groups", d->N, groups);
+    if (count <= BN_COL_MAX_PIXELS || groups > 1) {      // small map: statistics + normalisation (+ split-K sum) in ONE launch
+        int slices = 1;
+        fs_status s = fs::conv_fwd_deferred(stream, &c, x, w_packed, z, workspace, workspace_bytes, &slices);
+        if (s != FS_OK) return s;
+        return fs_bn_group_fwd(stream, count, C, groups, z, d->y_cs, slices > 1 ? (const float*)workspace : nullptr, slices, gamma, beta,
+                               eps, momentum, running_mean, running_var, num_batches_tracked, saved, y, d->y_cs, d->dtype,
+                               (d->flags & FS_CONV_RELU) ? 1 : 0);
+    }
+    fs_status s = fs_conv2d_fwd_ws(stream, &c, x, w_packed, nullptr, nullptr, z, stats, workspace, workspace_bytes);   // (+ sum / sumsq)
+    if (s != FS_OK) return s;
     return fs_bn_train_apply(stream, count, C, z, d->y_cs, stats, gamma, beta, eps, momentum, running_mean, running_var,
                              num_batches_tracked, saved, y, d->y_cs, d->dtype, (d->flags & FS_CONV_RELU) ? 1 : 0);
 }
@@ -37,11 +51,19 @@ extern "C" fs_status fs_conv_bn_act_train_bwd(void* stream, const fs_conv_desc* 
     const long long pixels = (long long)d->N * d->Ho * d->Wo;
     const float* mean = saved;
     const float* invstd = saved + C;
-    fs_status s = fs_bn_bwd_reduce(stream, pixels, C, z, d->y_cs, dy, dy_cs, y, d->y_cs, mean, invstd, d->dtype, relu, red);
-    if (s != FS_OK) return s;
-    s = fs_bn_bwd_apply(stream, pixels, C, z, d->y_cs, dy, dy_cs, y, d->y_cs, mean, invstd, gamma, red, pixels, d->dtype, relu,
-                        dz, C, dgamma_acc, dbeta_acc);          // dz is dense: channel stride == Cout
-    if (s != FS_OK) return s;
+    const int groups = d->bn_groups > 1 ? d->bn_groups : 1;
+    fs_status s;
+    if (pixels <= BN_COL_MAX_PIXELS || groups > 1) {
+        s = fs_bn_group_bwd(stream, pixels, C, groups, z, d->y_cs, dy, dy_cs, y, d->y_cs, saved, gamma, d->dtype, relu, dz, C, red,
+                            dgamma_acc, dbeta_acc);                  // both reductions + the input gradient: one launch
+        if (s != FS_OK) return s;
+    } else {
+        s = fs_bn_bwd_reduce(stream, pixels, C, z, d->y_cs, dy, dy_cs, y, d->y_cs, mean, invstd, d->dtype, relu, red);
+        if (s != FS_OK) return s;
+        s = fs_bn_bwd_apply(stream, pixels, C, z, d->y_cs, dy, dy_cs, y, d->y_cs, mean, invstd, gamma, red, pixels, d->dtype, relu,
+                            dz, C, dgamma_acc, dbeta_acc);          // dz is dense: channel stride == Cout
+        if (s != FS_OK) return s;
+    }
     if (dw) {
         FS_REQUIRE(x, FS_ERR_INVALID, "fs_conv_bn_act_train_bwd: weight gradient needs x");
         fs_conv_desc w = *d;

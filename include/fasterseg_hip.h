@@ -53,6 +53,11 @@ typedef struct fs_conv_desc {
                                interpolation if vr_relu - the F.interpolate of the zoomed convs (operations.py:271,275,437,444)
                                folded into the gather instead of materialised by fs_bilinear_fwd                 */
     int vr_relu;
+    int bn_groups;          /* train-mode fused units only (fs_conv_bn_act_train_fwd/bwd): > 1 = the batch is that many equal groups
+                               of images that BatchNorm normalises independently (same affine parameters, running statistics
+                               updated group after group): ONE batched evaluation of a module on several inputs with the
+                               arithmetic of separate evaluations (the from-down / from-keep pair of a supernet cell,
+                               model_search.py:322-329).  0 or 1 = ordinary BatchNorm over the whole batch. */
 } fs_conv_desc;
 
 typedef struct fs_resize_desc {
@@ -66,7 +71,7 @@ typedef struct fs_resize_desc {
 const char* fs_last_error(void);
 /* ABI revision of this header; fs_version() returns the one the library was built from.  Bindings check both this and
  * fs_struct_size() when they load the library (fasterseg_amd/_lib.py) - a stale .so must not be used silently. */
-#define FS_ABI_VERSION 200
+#define FS_ABI_VERSION 201
 int fs_version(void);
 int fs_struct_size(int which);   /* 0 fs_conv_desc, 1 fs_resize_desc, 2 fs_zoom_desc, 3 fs_sgd_tensor, 4 fs_logits_desc; -1 otherwise */
 /* test hook: force the tile configuration of fs_conv2d_fwd (0..6; -1 = heuristic).  Not for production use. */
@@ -181,6 +186,19 @@ fs_status fs_affine_act(void* stream, long long pixels, int C, const void* x, in
 /* per-channel sum / sumsq of an NHWC tensor (for BN after an op that is not a conv, e.g. the channel
  * concat of FactorizedReduce, operations.py:523-524). stats is accumulated (caller zeroes). */
 fs_status fs_channel_stats(void* stream, long long pixels, int C, const void* x, int x_cs, int dtype, float* stats);
+/* Train-mode BatchNorm (+ReLU) of a SMALL map in one launch, forward and backward (bn_col.hip): a block owns one 16-byte
+ * channel vector and all pixels of it - no atomics, fixed summation order (bit-reproducible), no statistics buffer to zero.
+ * `groups` equal consecutive pixel ranges are normalised independently with the same gamma/beta, their running-statistics
+ * updates applied in order (see fs_conv_desc.bn_groups).  saved: groups x 4 x C floats (mean, invstd, scale, shift per group).
+ * fs_bn_group_fwd with splits > 1 first sums the producing convolution's split-K partial slabs partials[splits][pixels][C]
+ * (fp32) into z (which it then writes); otherwise z is read.  fs_bn_group_bwd: red[0..C) = dbeta, red[C..2C) = dgamma (sums
+ * over the groups), optionally accumulated into dgamma_acc / dbeta_acc. */
+fs_status fs_bn_group_fwd(void* stream, long long pixels, int C, int groups, void* z, int z_cs, const float* partials, int splits,
+                          const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                          float* running_var, long long* num_batches_tracked, float* saved, void* y, int y_cs, int dtype, int relu);
+fs_status fs_bn_group_bwd(void* stream, long long pixels, int C, int groups, const void* z, int z_cs, const void* dy, int dy_cs,
+                          const void* y_out, int y_cs, const float* saved, const float* gamma, int dtype, int relu, void* dz,
+                          int dz_cs, float* red, float* dgamma_acc, float* dbeta_acc);
 /* BN(+ReLU) backward, two passes.
  * pass 1: red[0..C)=sum(dz), red[C..2C)=sum(dz*xhat) where dz = dy * (y>0 if relu) and xhat=(x-mean)*invstd.
  * pass 2: dx = gamma*invstd*(dz - red0/count - xhat*red1/count); when dgamma_acc/dbeta_acc are given (both or neither)
