@@ -17,12 +17,14 @@
 
 namespace fs {
 
-constexpr int BNC_THREADS = 256;
-constexpr int BNC_CACHE = 4;              // pixel vectors per lane kept in registers between the two passes
+constexpr int BNC_THREADS = 1024;           // launch bound; small groups run 256 lanes (see bnc_threads)
+constexpr int BNC_MAX_WAVES = BNC_THREADS / 64;
+constexpr int BNC_UNROLL = 4;             // independent 16-byte loads in flight per lane (forward: one tensor)
+constexpr int BNC_UNROLL_BWD = 2;         // backward reads three tensors per pixel: 6 loads in flight, and no spills at 1024 lanes
 
 template <int VEC>
-__device__ __forceinline__ void block_sum2(float (&a)[VEC], float (&b)[VEC], float* red /* [2][4][VEC] */) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__device__ __forceinline__ void block_sum2(float (&a)[VEC], float (&b)[VEC], float* red /* [2][BNC_MAX_WAVES][VEC] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
         a[i] = wave_sum(a[i]);
@@ -32,15 +34,20 @@ __device__ __forceinline__ void block_sum2(float (&a)[VEC], float (&b)[VEC], flo
     if (lane == 0) {
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
-            red[(0 * 4 + wave) * VEC + i] = a[i];
-            red[(1 * 4 + wave) * VEC + i] = b[i];
+            red[(0 * BNC_MAX_WAVES + wave) * VEC + i] = a[i];
+            red[(1 * BNC_MAX_WAVES + wave) * VEC + i] = b[i];
         }
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) {       // fixed order: waves 0..3
-        a[i] = red[(0 * 4 + 0) * VEC + i] + red[(0 * 4 + 1) * VEC + i] + red[(0 * 4 + 2) * VEC + i] + red[(0 * 4 + 3) * VEC + i];
-        b[i] = red[(1 * 4 + 0) * VEC + i] + red[(1 * 4 + 1) * VEC + i] + red[(1 * 4 + 2) * VEC + i] + red[(1 * 4 + 3) * VEC + i];
+    for (int i = 0; i < VEC; ++i) {       // fixed order: waves 0, 1, 2, ...
+        float sa = 0.f, sb = 0.f;
+        for (int w = 0; w < nw; ++w) {
+            sa += red[(0 * BNC_MAX_WAVES + w) * VEC + i];
+            sb += red[(1 * BNC_MAX_WAVES + w) * VEC + i];
+        }
+        a[i] = sa;
+        b[i] = sb;
     }
 }
 
@@ -52,52 +59,72 @@ __global__ __launch_bounds__(BNC_THREADS) void bn_group_fwd_kernel(long long pix
                                                                     long long* num_batches_tracked, float* __restrict__ saved,
                                                                     T* __restrict__ y, int y_cs, int relu) {
     constexpr int VEC = Elem<T>::VEC;
-    __shared__ float red[2 * 4 * VEC];
+    __shared__ float red[2 * BNC_MAX_WAVES * VEC];
     __shared__ float affine[2 * VEC];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, nthr = blockDim.x;
     const int c0 = blockIdx.x * VEC;
     const long long mg = pixels / groups;
     if (blockIdx.x == 0 && tid == 0 && num_batches_tracked) *num_batches_tracked += groups;
     for (int g = 0; g < groups; ++g) {
         const long long base = (long long)g * mg;
-        float s1[VEC], s2[VEC], cache[BNC_CACHE][VEC];
+        float s1[VEC], s2[VEC];
 #pragma unroll
         for (int i = 0; i < VEC; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
-        int it = 0;
-        for (long long m = tid; m < mg; m += BNC_THREADS, ++it) {
-            float v[VEC];
+        // pass 1: statistics.  BNC_UNROLL independent 16-byte loads are in flight per lane before the first is consumed (a lane
+        // owns up to pixels/256 vectors of this column; one dependent L2 round trip per vector would dominate the kernel)
+        for (long long m0 = tid; m0 < mg; m0 += BNC_UNROLL * nthr) {
+            float v[BNC_UNROLL][VEC];
             if (splits > 1) {             // sum the split-K slabs of the producing conv; keep z for the backward
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) v[i] = 0.f;
-                for (int s = 0; s < splits; ++s) {
-                    const float* src = partials + ((long long)s * pixels + base + m) * C + c0;
+                for (int u = 0; u < BNC_UNROLL; ++u) {
+                    const long long m = m0 + (long long)u * nthr;
 #pragma unroll
-                    for (int q = 0; q < VEC; q += 4) {
-                        const f32x4 t = *reinterpret_cast<const f32x4*>(src + q);
-                        v[q] += t[0]; v[q + 1] += t[1]; v[q + 2] += t[2]; v[q + 3] += t[3];
+                    for (int i = 0; i < VEC; ++i) v[u][i] = 0.f;
+                    if (m < mg) {
+                        for (int s = 0; s < splits; ++s) {
+                            const float* src = partials + ((long long)s * pixels + base + m) * C + c0;
+#pragma unroll
+                            for (int q = 0; q < VEC; q += 4) {
+                                const f32x4 t = *reinterpret_cast<const f32x4*>(src + q);
+                                v[u][q] += t[0]; v[u][q + 1] += t[1]; v[u][q + 2] += t[2]; v[u][q + 3] += t[3];
+                            }
+                        }
+                        const u32x4 packed = Elem<T>::pack(v[u]);
+                        stg16(z + (base + m) * z_cs + c0, packed);
+                        Elem<T>::unpack(packed, v[u]);            // statistics of the STORED (rounded) map, as without split-K
                     }
                 }
-                const u32x4 packed = Elem<T>::pack(v);
-                stg16(z + (base + m) * z_cs + c0, packed);
-                Elem<T>::unpack(packed, v);                       // statistics of the STORED (rounded) map, as without split-K
             } else {
-                Elem<T>::unpack(ldg16(z + (base + m) * z_cs + c0), v);
+                u32x4 raw[BNC_UNROLL];
+#pragma unroll
+                for (int u = 0; u < BNC_UNROLL; ++u) {
+                    const long long m = m0 + (long long)u * nthr;
+                    raw[u] = ldg16(z + (base + (m < mg ? m : m0)) * z_cs + c0);
+                }
+#pragma unroll
+                for (int u = 0; u < BNC_UNROLL; ++u) {
+                    Elem<T>::unpack(raw[u], v[u]);
+                    if (m0 + (long long)u * nthr >= mg) {
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) v[u][i] = 0.f;
+                    }
+                }
             }
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) { s1[i] += v[i]; s2[i] += v[i] * v[i]; }
+            for (int u = 0; u < BNC_UNROLL; ++u)
 #pragma unroll
-            for (int k = 0; k < BNC_CACHE; ++k)
-                if (it == k) {
-#pragma unroll
-                    for (int i = 0; i < VEC; ++i) cache[k][i] = v[i];
-                }
+                for (int i = 0; i < VEC; ++i) { s1[i] += v[u][i]; s2[i] += v[u][i] * v[u][i]; }
         }
         block_sum2<VEC>(s1, s2, red);
         if (tid < VEC) {
             const int c = c0 + tid;
             const float count = (float)mg;
-            const float m_ = s1[tid] / count;
-            const float var = fmaxf(s2[tid] / count - m_ * m_, 0.f);
+            float sum1 = 0.f, sum2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i)
+                if (i == tid) { sum1 = s1[i]; sum2 = s2[i]; }
+            const float m_ = sum1 / count;
+            const float var = fmaxf(sum2 / count - m_ * m_, 0.f);
             const float is = 1.0f / sqrtf(var + eps);
             const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
             float* sv = saved + (long long)g * 4 * C;
@@ -117,25 +144,28 @@ __global__ __launch_bounds__(BNC_THREADS) void bn_group_fwd_kernel(long long pix
         float sc[VEC], sh[VEC];
 #pragma unroll
         for (int i = 0; i < VEC; ++i) { sc[i] = affine[i]; sh[i] = affine[VEC + i]; }
-        it = 0;
-        for (long long m = tid; m < mg; m += BNC_THREADS, ++it) {
-            float v[VEC];
-            if (it < BNC_CACHE) {
+        // pass 2: normalise (+ReLU); the column is L2-resident from pass 1
+        for (long long m0 = tid; m0 < mg; m0 += BNC_UNROLL * nthr) {
+            u32x4 raw[BNC_UNROLL];
 #pragma unroll
-                for (int k = 0; k < BNC_CACHE; ++k)
-                    if (it == k) {
+            for (int u = 0; u < BNC_UNROLL; ++u) {
+                const long long m = m0 + (long long)u * nthr;
+                raw[u] = ldg16(z + (base + (m < mg ? m : m0)) * z_cs + c0);
+            }
 #pragma unroll
-                        for (int i = 0; i < VEC; ++i) v[i] = cache[k][i];
+            for (int u = 0; u < BNC_UNROLL; ++u) {
+                const long long m = m0 + (long long)u * nthr;
+                if (m < mg) {
+                    float v[VEC];
+                    Elem<T>::unpack(raw[u], v);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) {
+                        const float o = v[i] * sc[i] + sh[i];
+                        v[i] = relu ? fmaxf(o, 0.f) : o;
                     }
-            } else {
-                Elem<T>::unpack(ldg16(z + (base + m) * z_cs + c0), v);
+                    stg16(y + (base + m) * y_cs + c0, Elem<T>::pack(v));
+                }
             }
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) {
-                const float o = v[i] * sc[i] + sh[i];
-                v[i] = relu ? fmaxf(o, 0.f) : o;
-            }
-            stg16(y + (base + m) * y_cs + c0, Elem<T>::pack(v));
         }
         __syncthreads();                  // `affine` is rewritten by the next group
     }
@@ -149,8 +179,8 @@ __global__ __launch_bounds__(BNC_THREADS) void bn_group_bwd_kernel(long long pix
                                                                     int dz_cs, float* __restrict__ red_out, float* dgamma_acc,
                                                                     float* dbeta_acc) {
     constexpr int VEC = Elem<T>::VEC;
-    __shared__ float red[2 * 4 * VEC];
-    const int tid = threadIdx.x;
+    __shared__ float red[2 * BNC_MAX_WAVES * VEC];
+    const int tid = threadIdx.x, nthr = blockDim.x;
     const int c0 = blockIdx.x * VEC;
     const long long mg = pixels / groups;
     float tot_b[VEC], tot_g[VEC], ga[VEC];
@@ -162,60 +192,61 @@ __global__ __launch_bounds__(BNC_THREADS) void bn_group_bwd_kernel(long long pix
         float mu[VEC], is[VEC], a0[VEC], a1[VEC];
 #pragma unroll
         for (int i = 0; i < VEC; ++i) { mu[i] = sv[c0 + i]; is[i] = sv[C + c0 + i]; a0[i] = 0.f; a1[i] = 0.f; }
-        float cg[BNC_CACHE][VEC], cx[BNC_CACHE][VEC];           // masked upstream gradient and xhat of the first pixels
-        int it = 0;
-        for (long long m = tid; m < mg; m += BNC_THREADS, ++it) {
-            float f[VEC], gr[VEC];
-            Elem<T>::unpack(ldg16(z + (base + m) * z_cs + c0), f);
-            Elem<T>::unpack(ldg16(dy + (base + m) * dy_cs + c0), gr);
+        // the raw 16-byte vectors of BNC_UNROLL_BWD pixels are requested together; each is unpacked only when it is consumed
+        // (holding all of them as fp32 would spill at 1024 lanes per block)
+        u32x4 rz[BNC_UNROLL_BWD], rg[BNC_UNROLL_BWD], ro[BNC_UNROLL_BWD];
+        auto issue = [&](long long m0) {
+#pragma unroll
+            for (int u = 0; u < BNC_UNROLL_BWD; ++u) {
+                const long long m = m0 + (long long)u * nthr;
+                const long long mm = base + (m < mg ? m : m0);
+                rz[u] = ldg16(z + mm * z_cs + c0);
+                rg[u] = ldg16(dy + mm * dy_cs + c0);
+                if (relu) ro[u] = ldg16(yo + mm * y_cs + c0);
+            }
+        };
+        auto decode = [&](int u, bool live, float (&gr)[VEC], float (&xh)[VEC]) {
+            Elem<T>::unpack(rz[u], xh);
+            Elem<T>::unpack(rg[u], gr);
             if (relu) {
                 float o[VEC];
-                Elem<T>::unpack(ldg16(yo + (base + m) * y_cs + c0), o);
+                Elem<T>::unpack(ro[u], o);
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) gr[i] = o[i] > 0.f ? gr[i] : 0.f;
             }
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
-                f[i] = (f[i] - mu[i]) * is[i];
-                a0[i] += gr[i];
-                a1[i] += gr[i] * f[i];
+                xh[i] = (xh[i] - mu[i]) * is[i];
+                if (!live) gr[i] = 0.f;
             }
+        };
+        for (long long m0 = tid; m0 < mg; m0 += BNC_UNROLL_BWD * nthr) {
+            issue(m0);
 #pragma unroll
-            for (int k = 0; k < BNC_CACHE; ++k)
-                if (it == k) {
+            for (int u = 0; u < BNC_UNROLL_BWD; ++u) {
+                float gr[VEC], xh[VEC];
+                decode(u, m0 + (long long)u * nthr < mg, gr, xh);
 #pragma unroll
-                    for (int i = 0; i < VEC; ++i) { cg[k][i] = gr[i]; cx[k][i] = f[i]; }
-                }
+                for (int i = 0; i < VEC; ++i) { a0[i] += gr[i]; a1[i] += gr[i] * xh[i]; }
+            }
         }
         block_sum2<VEC>(a0, a1, red);
         const float inv = 1.0f / (float)mg;
 #pragma unroll
         for (int i = 0; i < VEC; ++i) { tot_b[i] += a0[i]; tot_g[i] += a1[i]; }
-        it = 0;
-        for (long long m = tid; m < mg; m += BNC_THREADS, ++it) {
-            float f[VEC], gr[VEC];
-            if (it < BNC_CACHE) {
+        for (long long m0 = tid; m0 < mg; m0 += BNC_UNROLL_BWD * nthr) {
+            issue(m0);
 #pragma unroll
-                for (int k = 0; k < BNC_CACHE; ++k)
-                    if (it == k) {
+            for (int u = 0; u < BNC_UNROLL_BWD; ++u) {
+                const long long m = m0 + (long long)u * nthr;
+                if (m < mg) {
+                    float gr[VEC], xh[VEC];
+                    decode(u, true, gr, xh);
 #pragma unroll
-                        for (int i = 0; i < VEC; ++i) { gr[i] = cg[k][i]; f[i] = cx[k][i]; }
-                    }
-            } else {
-                Elem<T>::unpack(ldg16(z + (base + m) * z_cs + c0), f);
-                Elem<T>::unpack(ldg16(dy + (base + m) * dy_cs + c0), gr);
-                if (relu) {
-                    float o[VEC];
-                    Elem<T>::unpack(ldg16(yo + (base + m) * y_cs + c0), o);
-#pragma unroll
-                    for (int i = 0; i < VEC; ++i) gr[i] = o[i] > 0.f ? gr[i] : 0.f;
+                    for (int i = 0; i < VEC; ++i) gr[i] = ga[i] * is[i] * (gr[i] - a0[i] * inv - xh[i] * a1[i] * inv);
+                    stg16(dz + (base + m) * dz_cs + c0, Elem<T>::pack(gr));
                 }
-#pragma unroll
-                for (int i = 0; i < VEC; ++i) f[i] = (f[i] - mu[i]) * is[i];
             }
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) f[i] = ga[i] * is[i] * (gr[i] - a0[i] * inv - f[i] * a1[i] * inv);
-            stg16(dz + (base + m) * dz_cs + c0, Elem<T>::pack(f));
         }
     }
     if (tid < VEC) {                      // parameter gradients of this channel vector: summed over the groups, one writer
@@ -236,6 +267,11 @@ __global__ __launch_bounds__(BNC_THREADS) void bn_group_bwd_kernel(long long pix
 }  // namespace fs
 
 using namespace fs;
+
+// lanes per block: enough that a lane owns at most a few pixels of its column (one block serves the whole column)
+static inline int bnc_threads(long long pixels_per_group) {
+    return pixels_per_group > 2048 ? 1024 : pixels_per_group > 512 ? 512 : 256;
+}
 
 static fs_status check_map(const char* fn, const void* p, int cs, int C, int dtype) {
     const int vec = vec_elems(dtype);
@@ -260,10 +296,10 @@ extern "C" fs_status fs_bn_group_fwd(void* stream, long long pixels, int C, int 
     const int cv = C / vec_elems(dtype);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == FS_F32)
-        hipLaunchKernelGGL((bn_group_fwd_kernel<float>), dim3(cv), dim3(BNC_THREADS), 0, st, pixels, C, groups, (float*)z, z_cs, partials, splits,
+        hipLaunchKernelGGL((bn_group_fwd_kernel<float>), dim3(cv), dim3(bnc_threads(pixels / groups)), 0, st, pixels, C, groups, (float*)z, z_cs, partials, splits,
                            gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, saved, (float*)y, y_cs, relu);
     else
-        hipLaunchKernelGGL((bn_group_fwd_kernel<bf16_t>), dim3(cv), dim3(BNC_THREADS), 0, st, pixels, C, groups, (bf16_t*)z, z_cs, partials, splits,
+        hipLaunchKernelGGL((bn_group_fwd_kernel<bf16_t>), dim3(cv), dim3(bnc_threads(pixels / groups)), 0, st, pixels, C, groups, (bf16_t*)z, z_cs, partials, splits,
                            gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, saved, (bf16_t*)y, y_cs, relu);
     return check_launch("fs_bn_group_fwd");
 }
@@ -282,10 +318,10 @@ extern "C" fs_status fs_bn_group_bwd(void* stream, long long pixels, int C, int 
     const int cv = C / vec_elems(dtype);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == FS_F32)
-        hipLaunchKernelGGL((bn_group_bwd_kernel<float>), dim3(cv), dim3(BNC_THREADS), 0, st, pixels, C, groups, (const float*)z, z_cs,
+        hipLaunchKernelGGL((bn_group_bwd_kernel<float>), dim3(cv), dim3(bnc_threads(pixels / groups)), 0, st, pixels, C, groups, (const float*)z, z_cs,
                            (const float*)dy, dy_cs, (const float*)y_out, y_cs, saved, gamma, relu, (float*)dz, dz_cs, red, dgamma_acc, dbeta_acc);
     else
-        hipLaunchKernelGGL((bn_group_bwd_kernel<bf16_t>), dim3(cv), dim3(BNC_THREADS), 0, st, pixels, C, groups, (const bf16_t*)z, z_cs,
+        hipLaunchKernelGGL((bn_group_bwd_kernel<bf16_t>), dim3(cv), dim3(bnc_threads(pixels / groups)), 0, st, pixels, C, groups, (const bf16_t*)z, z_cs,
                            (const bf16_t*)dy, dy_cs, (const bf16_t*)y_out, y_cs, saved, gamma, relu, (bf16_t*)dz, dz_cs, red, dgamma_acc, dbeta_acc);
     return check_launch("fs_bn_group_bwd");
 }

@@ -8,9 +8,11 @@
 // accumulation all happen here or inside the kernels.
 #include "common.h"
 
-// maps up to this many pixels take the one-launch column-owner BatchNorm (bn_col.hip); larger ones (the student's 12 x 64 x 128
-// and up) keep the grid-wide passes, where one block per channel vector would leave the chip idle
-static const long long BN_COL_MAX_PIXELS = 16384;
+// Maps up to this many pixels per group take the one-launch column-owner BatchNorm (bn_col.hip).  Measured on MI355X
+// (scratch/bn_micro.py, bf16, launch + kernel): 96 px 6.3 vs 7.2 us for the two grid-wide launches, 384 px 7.6 vs 7.3, 1536 px
+// 12.7 vs 7.5, 6144 px 36 vs 8.5 - one block per channel vector reads 16 bytes of every 128-byte line and streams at a few
+// GB/s, so beyond a few hundred pixels the two grid-wide passes win and stay.
+static const long long BN_COL_MAX_PIXELS = 512;
 
 extern "C" fs_status fs_conv_bn_act_train_fwd(void* stream, const fs_conv_desc* d, const void* x, const void* w_packed,
                                               const float* gamma, const float* beta, float* running_mean,
@@ -24,7 +26,7 @@ extern "C" fs_status fs_conv_bn_act_train_fwd(void* stream, const fs_conv_desc* 
     const long long count = (long long)d->N * d->Ho * d->Wo;
     const int groups = d->bn_groups > 1 ? d->bn_groups : 1;
     FS_REQUIRE(d->N % groups == 0, FS_ERR_INVALID, "fs_conv_bn_act_train_fwd: batch %d is not %d equal groups", d->N, groups);
-    if (count <= BN_COL_MAX_PIXELS || groups > 1) {      // small map: statistics + normalisation (+ split-K sum) in ONE launch
+    if (count / groups <= BN_COL_MAX_PIXELS || groups > 1) {      // small map: statistics + normalisation (+ split-K sum) in ONE launch
         int slices = 1;
         fs_status s = fs::conv_fwd_deferred(stream, &c, x, w_packed, z, workspace, workspace_bytes, &slices);
         if (s != FS_OK) return s;
@@ -53,7 +55,7 @@ extern "C" fs_status fs_conv_bn_act_train_bwd(void* stream, const fs_conv_desc* 
     const float* invstd = saved + C;
     const int groups = d->bn_groups > 1 ? d->bn_groups : 1;
     fs_status s;
-    if (pixels <= BN_COL_MAX_PIXELS || groups > 1) {
+    if (pixels / groups <= BN_COL_MAX_PIXELS || groups > 1) {
         s = fs_bn_group_bwd(stream, pixels, C, groups, z, d->y_cs, dy, dy_cs, y, d->y_cs, saved, gamma, d->dtype, relu, dz, C, red,
                             dgamma_acc, dbeta_acc);                  // both reductions + the input gradient: one launch
         if (s != FS_OK) return s;
