@@ -77,6 +77,10 @@ _BRANCH_LANES = int(os.environ.get("FS_BRANCH_LANES", "5"))
 # Eager training passes replay each MixedOp from pre-built launch programs (fasterseg_amd/program.py); FS_MIXEDOP_PROGRAMS=0
 # keeps the per-module autograd path.
 _PROGRAMS = bool(int(os.environ.get("FS_MIXEDOP_PROGRAMS", "1")))
+# ... also inside a capture (one program per MixedOp on its own lane instead of five per-module autograd chains): fewer nodes,
+# and the five input gradients of a MixedOp are summed by one kernel instead of four autograd adds.  FS_CAPTURE_PROGRAMS=0
+# captures the per-module path.
+_CAPTURE_PROGRAMS = bool(int(os.environ.get("FS_CAPTURE_PROGRAMS", "1")))
 _lane_pool = {}
 
 
@@ -115,21 +119,33 @@ def _run_tasks(tasks):
     main = torch.cuda.current_stream()
     pool = layer_lanes(main)
     used, slot, pending = [], 0, []
+
+    def lane_for(k):
+        lane = pool[k % len(pool)]
+        if lane not in used:
+            lane.wait_stream(main)                         # fork: the previous layer's outputs are complete on `main`
+            used.append(lane)
+        return lane
     for op, x, alpha, ratios in tasks:
-        coef = op._coefficients(x, alpha, ratios)          # also selects the widths of the five primitives
+        widths = [None, None]
+        coef = op._coefficients(x, alpha, ratios, widths)  # also selects the widths of the five primitives
+        prog = None
+        if _PROGRAMS and _CAPTURE_PROGRAMS and op.training and torch.is_grad_enabled():
+            prog = op._program(FN.as_nhwc(x), coef, widths[0], widths[1])
+        if prog is not None:          # the whole MixedOp (five primitives, their sum, and in backward the sum of the five input
+            with torch.cuda.stream(lane_for(slot)):        # gradients) as one launch program on one lane
+                pending.append((FN.mixed_op_program(FN.as_nhwc(x), coef, prog), None))
+            slot += 1
+            continue
         outs = []
         for prim in op._ops:
-            lane = pool[slot % len(pool)]
-            slot += 1
-            if lane not in used:
-                lane.wait_stream(main)                     # fork: the previous layer's outputs are complete on `main`
-                used.append(lane)
-            with torch.cuda.stream(lane):
+            with torch.cuda.stream(lane_for(slot)):
                 outs.append(prim(x))
+            slot += 1
         pending.append((outs, coef))
     for lane in used:
         main.wait_stream(lane)                             # one join per layer
-    return [FN.weighted_sum(outs, coef) for outs, coef in pending]
+    return [outs if coef is None else FN.weighted_sum(outs, coef) for outs, coef in pending]
 
 
 def _run_branches(ops, x):
