@@ -124,6 +124,14 @@ class SupernetStep:
         # train_search.py:94-98 SGD + :249 clip_grad_norm_(5), one launch over the flat buffers
         self.optimizer = FlatSGD(self.sync, cfg.lr, cfg.momentum, cfg.weight_decay, max_norm=cfg.grad_clip,
                                  pack_dtype=compute_dtype)
+        # Width sampling (np.random.choice for "random", torch.rand for the Gumbel noise) runs on the host RNGs: every rank must
+        # draw the SAME sub-network, or a parameter would be updated on one rank and skipped (grad=None) on another.  Rank 0's
+        # seed wins, whatever the others were given.
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            box = [seed]
+            dist.broadcast_object_list(box, src=0)
+            seed = int(box[0])
         np.random.seed(seed)
         torch.manual_seed(seed)
         self.architect = None
