@@ -217,6 +217,7 @@ def run_student_infer(args, world, rank, backend):
                              "ms/frame: %s)" % (len(eng.calls), getattr(eng, "graph_lanes", 1),
                                                 sum(1 for c in eng.calls if c["fn"] == "fs_zoom_cell_fwd"), eng.fused_cells,
                                                 eng.shared_resizes, eng.fused_resizes, getattr(eng, "capture_log", [])),
+                   "conv_autotune": "3x3 s1 layers [label, pixels, cin, cout, chosen, candidates us]: %s" % (eng.autotuned,),
                    "cells": "[label, choice, fused us, split us (alone, cache-warm), frame ms with the choice flipped]: %s" % (eng.cell_log,)},
         "parity": parity,
         "alg_gflop_per_frame": round(eng.total_flops / 1e9, 3), "alg_mb_per_frame": round(eng.total_bytes / 1e6, 1),

@@ -101,6 +101,7 @@ _SPECIAL = {
     "fs_struct_size": ([c_int], c_int),
     "fs_packed_weight_elems": ([c_int, c_int, c_int, c_int], c_ll),
     "fs_debug_force_conv_cfg": ([c_int], None),
+    "fs_debug_stem_mfma": ([c_int], None),
     "fs_packed_weight_frag_elems": ([c_int, c_int, c_int], c_ll),
     "fs_sgd_chunk_elems": ([], c_int),
     "fs_zoom_cell_supported": ([ctypes.POINTER(ZoomDesc)], c_int),

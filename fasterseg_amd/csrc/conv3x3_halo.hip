@@ -25,12 +25,12 @@ struct HaloArgs {
     const float* shift;
     float* stats;
     int N, H, W, Cin, Cout;
+    int Ho, Wo;                 // output size (= H, W at stride 1)
     int x_cs, y_cs;
     int tiles_x, tiles_y, tiles_n, nchunks;
     int flags;
 };
 
-constexpr int HALO_W = 18;
 constexpr int HPITCH = 80;                 // 64 data bytes + 16 pad per halo pixel
 
 template <typename T> struct MmaH;
@@ -49,18 +49,27 @@ template <> struct MmaH<bf16_t> {
 
 constexpr int hmax(int a, int b) { return a > b ? a : b; }
 
-template <typename T, int WAVES_M, int WAVES_N, int WM_T, int WN_T>
+// STRIDE 2: the block's 8 x 16 OUTPUT pixels read a 17 x 33 input patch.  It is staged with its even and odd columns
+// de-interleaved (LDS column = (hx & 1) * 17 + hx / 2), so that tap s of 16 consecutive output columns is again 16
+// consecutive LDS pixels (s = 0: even columns ox, s = 1: odd columns ox, s = 2: even columns ox + 1) and the A-fragment
+// reads stay conflict-free; the patch is 45 KB per channel chunk, so it is single-buffered (the chunk loop of these layers
+// is 1-2 iterations long: Cin = 32 / 64).
+template <typename T, int WAVES_M, int WAVES_N, int WM_T, int WN_T, int STRIDE = 1>
 __global__ __launch_bounds__(256) void conv3x3_halo_kernel(HaloArgs p) {
     constexpr int VEC = Elem<T>::VEC;
     constexpr int CK = 4 * VEC;                           // input channels per chunk (64 bytes)
     constexpr int TH = 2 * WAVES_M * WM_T;                // output rows per block
-    constexpr int HALO_PIX = (TH + 2) * HALO_W;
+    constexpr int HALO_W = 15 * STRIDE + 3;               // input columns of the patch: 18 / 33
+    constexpr int HALO_H = (TH - 1) * STRIDE + 3;
+    constexpr int NBUF = STRIDE == 1 ? 2 : 1;
+    constexpr int EVEN_COLS = 17;                         // stride 2: columns 0, 2, .., 32 come first, then 1, 3, .., 31
+    constexpr int HALO_PIX = HALO_H * HALO_W;
     constexpr int HALO_VECS = HALO_PIX * 4;
     constexpr int A_ITEMS = (HALO_VECS + 255) / 256;
     constexpr int HALO_BYTES = HALO_PIX * HPITCH;
     constexpr int OUT_PITCH = 32 * (int)sizeof(T) + 16;
     constexpr int OUT_BYTES = 4 * 32 * OUT_PITCH;
-    constexpr int SMEM = hmax(2 * HALO_BYTES, OUT_BYTES);
+    constexpr int SMEM = hmax(NBUF * HALO_BYTES, OUT_BYTES);
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
 
@@ -83,11 +92,12 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(HaloArgs p) {
         const int v = tid + i * 256;
         const int pix = v >> 2, slot = v & 3;
         const int hy = pix / HALO_W, hx = pix - hy * HALO_W;
-        const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+        const int iy = STRIDE * y0 - 1 + hy, ix = STRIDE * x0 - 1 + hx;
         const bool ok = (v < HALO_VECS) && ((unsigned)iy < (unsigned)p.H) && ((unsigned)ix < (unsigned)p.W);
         a_keep[i] = ok ? 0xffffffffu : 0u;
         a_off[i] = ok ? ((((long long)img * p.H + iy) * p.W + ix) * p.x_cs + slot * VEC) * (long long)sizeof(T) : 0ll;
-        a_lds[i] = (v < HALO_VECS) ? pix * HPITCH + slot * 16 : -1;
+        const int lcol = STRIDE == 1 ? hx : (hx & 1) * EVEN_COLS + (hx >> 1);
+        a_lds[i] = (v < HALO_VECS) ? (hy * HALO_W + lcol) * HPITCH + slot * 16 : -1;
     }
     u32x4 a_reg[A_ITEMS];
     uint32_t a_cmask[A_ITEMS];
@@ -148,7 +158,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(HaloArgs p) {
 
     // A fragment base: m-tile i of this wave covers halo rows (wm*WM_T + i)*2 + {0,1}, columns 0..15
     const int l31 = lane & 31;
-    const int frag_base = (((wm * WM_T) * 2 + (l31 >> 4)) * HALO_W + (l31 & 15)) * HPITCH + (lane >> 5) * 16;
+    const int frag_base = (STRIDE * ((wm * WM_T) * 2 + (l31 >> 4)) * HALO_W + (l31 & 15)) * HPITCH + (lane >> 5) * 16;
 
     load_halo(0);
     load_b(0, 0, 0);
@@ -157,7 +167,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(HaloArgs p) {
     store_halo(0);
     __syncthreads();
     for (int c = 0; c < p.nchunks; ++c) {
-        const int buf = c & 1;
+        const int buf = NBUF == 2 ? (c & 1) : 0;
         const bool more = (c + 1) < p.nchunks;
         if (more) load_halo(c + 1);
         const unsigned char* hal = smem + buf * HALO_BYTES + frag_base;
@@ -170,7 +180,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(HaloArgs p) {
                 u32x4 af[WM_T];
 #pragma unroll
                 for (int i = 0; i < WM_T; ++i)
-                    af[i] = *reinterpret_cast<const u32x4*>(hal + ((i * 2 + r) * HALO_W + s) * HPITCH + kk * 32);
+                    af[i] = *reinterpret_cast<const u32x4*>(hal + ((STRIDE * i * 2 + r) * HALO_W + (STRIDE == 1 ? s : (s & 1) * EVEN_COLS + (s >> 1))) * HPITCH + kk * 32);
 #pragma unroll
                 for (int i = 0; i < WM_T; ++i)
 #pragma unroll
@@ -180,7 +190,8 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(HaloArgs p) {
             if (tap < 6) load_b(slot, c, tap + 3);
             else if (more) load_b(slot, c + 1, tap - 6);
         }
-        if (more) store_halo(buf ^ 1);
+        if (NBUF == 1 && more) __syncthreads();          // single buffer: every wave is done reading before it is refilled
+        if (more) store_halo(NBUF == 2 ? (buf ^ 1) : 0);
         __syncthreads();
     }
 
@@ -207,7 +218,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(HaloArgs p) {
                 for (int r = 0; r < 16; ++r) {
                     const int prow = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);     // pixel index in the m-tile
                     const int oy = row0 + (prow >> 4), ox = x0 + (prow & 15);
-                    const bool pv = oy < p.H && ox < p.W;
+                    const bool pv = oy < p.Ho && ox < p.Wo;
                     const float v = pv ? acc[i][j][r] : 0.f;
                     s1 += v;
                     s2 += v * v;
@@ -221,8 +232,8 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(HaloArgs p) {
                     const int prow = ps * RPP + lane / LPR;
                     const int seg = lane % LPR;
                     const int oy = row0 + (prow >> 4), ox = x0 + (prow & 15);
-                    if (oy < p.H && ox < p.W)
-                        stg16(y + (((long long)img * p.H + oy) * p.W + ox) * p.y_cs + cbase + seg * (16 / (int)sizeof(T)),
+                    if (oy < p.Ho && ox < p.Wo)
+                        stg16(y + (((long long)img * p.Ho + oy) * p.Wo + ox) * p.y_cs + cbase + seg * (16 / (int)sizeof(T)),
                               *reinterpret_cast<const u32x4*>(sOut + prow * OUT_PITCH + seg * 16));
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -231,14 +242,14 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(HaloArgs p) {
                 for (int r = 0; r < 16; ++r) {
                     const int prow = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     const int oy = row0 + (prow >> 4), ox = x0 + (prow & 15);
-                    const bool pv = oy < p.H && ox < p.W;
+                    const bool pv = oy < p.Ho && ox < p.Wo;
                     const float v = pv ? acc[i][j][r] : 0.f;
                     s1 += v;
                     s2 += v * v;
                     if (pv && cvalid) {
                         float o = v * sc + sh;
                         if (relu) o = fmaxf(o, 0.f);
-                        Elem<T>::store(y + (((long long)img * p.H + oy) * p.W + ox) * p.y_cs + co, o);
+                        Elem<T>::store(y + (((long long)img * p.Ho + oy) * p.Wo + ox) * p.y_cs + co, o);
                     }
                 }
             }
@@ -277,20 +288,37 @@ __global__ void pack_weight_frag_kernel(const float* __restrict__ w, long long o
     }
 }
 
-template <typename T, int WAVES_M, int WAVES_N, int WM_T, int WN_T>
+template <typename T, int WAVES_M, int WAVES_N, int WM_T, int WN_T, int STRIDE = 1>
 static void launch_halo(hipStream_t st, HaloArgs& a) {
     constexpr int TH = 2 * WAVES_M * WM_T;
     constexpr int BN = WAVES_N * WN_T * 32;
-    a.tiles_x = (a.W + 15) / 16;
-    a.tiles_y = (a.H + TH - 1) / TH;
+    a.tiles_x = (a.Wo + 15) / 16;
+    a.tiles_y = (a.Ho + TH - 1) / TH;
     a.tiles_n = (a.Cout + BN - 1) / BN;
     const long long blocks = (long long)a.N * a.tiles_y * a.tiles_x * a.tiles_n;
-    hipLaunchKernelGGL((conv3x3_halo_kernel<T, WAVES_M, WAVES_N, WM_T, WN_T>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<T, WAVES_M, WAVES_N, WM_T, WN_T, STRIDE>), dim3((unsigned)blocks), dim3(256), 0, st, a);
 }
 
-template <typename T> static void dispatch_halo(hipStream_t st, HaloArgs& a) {
-    if (a.Cout <= 32) launch_halo<T, 4, 1, 1, 1>(st, a);          // 8x16 px  x 32 ch
-    else if (a.Cout <= 64 || (a.Cout % 128 != 0 && a.Cout % 128 <= 64)) launch_halo<T, 2, 2, 2, 1>(st, a);   // 8x16 x 64
+// Output-channel tile: 32, 64 or 128 per block (always 8 x 16 pixels).  `force` (FS_CONV_TILE_* in fs_conv_desc.flags) picks one;
+// otherwise the widest tile that wastes no half-empty channel block AND still gives every CU a block: a 192->128 layer on a
+// 64 x 128 map is 64 blocks of 128 channels (a quarter of the chip, 21.8 us) but 256 blocks of 32.
+template <typename T> static void dispatch_halo(hipStream_t st, HaloArgs& a, int force, int stride) {
+    const long long pix_tiles = (long long)a.N * ((a.Ho + 7) / 8) * ((a.Wo + 15) / 16);
+    int tile = force;
+    if (tile == 0) {
+        if (a.Cout <= 32) tile = 32;
+        else if (a.Cout <= 64 || (a.Cout % 128 != 0 && a.Cout % 128 <= 64)) tile = 64;
+        else tile = 128;
+        while (tile > 32 && pix_tiles * ((a.Cout + tile - 1) / tile) < 256) tile >>= 1;
+    }
+    if (stride == 2) {
+        if (tile == 32) launch_halo<T, 4, 1, 1, 1, 2>(st, a);
+        else if (tile == 64) launch_halo<T, 2, 2, 2, 1, 2>(st, a);
+        else launch_halo<T, 2, 2, 2, 2, 2>(st, a);
+        return;
+    }
+    if (tile == 32) launch_halo<T, 4, 1, 1, 1>(st, a);             // 8x16 px x 32 ch
+    else if (tile == 64) launch_halo<T, 2, 2, 2, 1>(st, a);        // 8x16 x 64
     else launch_halo<T, 2, 2, 2, 2>(st, a);                        // 8x16 x 128
 }
 
@@ -326,8 +354,9 @@ extern "C" fs_status fs_conv3x3_s1_fwd(void* stream, const fs_conv_desc* d, cons
                                        const float* shift, void* y, float* stats) {
     FS_REQUIRE(d && x && w_frag && y, FS_ERR_INVALID, "fs_conv3x3_s1_fwd: null argument");
     FS_REQUIRE(d->dtype == FS_F32 || d->dtype == FS_BF16, FS_ERR_INVALID, "fs_conv3x3_s1_fwd: bad dtype");
-    FS_REQUIRE(d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1 && d->Ho == d->H && d->Wo == d->W && !(d->flags & ~FS_CONV_RELU),
-               FS_ERR_UNSUPPORTED, "fs_conv3x3_s1_fwd: only 3x3 / stride 1 / pad 1 (got %dx%d s%d p%d)", d->R, d->S, d->stride, d->pad);
+    FS_REQUIRE(d->R == 3 && d->S == 3 && (d->stride == 1 || d->stride == 2) && d->pad == 1 && d->Ho == (d->H - 1) / d->stride + 1 &&
+                   d->Wo == (d->W - 1) / d->stride + 1 && !(d->flags & ~(FS_CONV_RELU | FS_CONV_TILE_MASK)),
+               FS_ERR_UNSUPPORTED, "fs_conv3x3_s1_fwd: only 3x3 / stride 1 or 2 / pad 1 (got %dx%d s%d p%d)", d->R, d->S, d->stride, d->pad);
     const int vec = vec_elems(d->dtype);
     FS_REQUIRE(d->Cin % vec == 0 && d->x_cs % vec == 0 && d->x_cs >= d->Cin && d->y_cs >= d->Cout, FS_ERR_INVALID,
                "fs_conv3x3_s1_fwd: bad channel counts/strides");
@@ -336,12 +365,15 @@ extern "C" fs_status fs_conv3x3_s1_fwd(void* stream, const fs_conv_desc* d, cons
     a.x = (const unsigned char*)x; a.w = (const unsigned char*)w_frag; a.y = (unsigned char*)y;
     a.scale = scale; a.shift = shift; a.stats = stats;
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout;
+    a.Ho = d->Ho; a.Wo = d->Wo;
     a.x_cs = d->x_cs; a.y_cs = d->y_cs;
     a.nchunks = (d->Cin + 4 * vec - 1) / (4 * vec);
-    a.flags = d->flags;
+    a.flags = d->flags & FS_CONV_RELU;
+    const int force = (d->flags & FS_CONV_TILE_MASK) == FS_CONV_TILE_32 ? 32 : (d->flags & FS_CONV_TILE_MASK) == FS_CONV_TILE_64 ? 64
+                      : (d->flags & FS_CONV_TILE_MASK) == FS_CONV_TILE_128 ? 128 : 0;
     if (!(aligned16(y) && (d->y_cs % vec == 0))) a.flags |= 0x100;
     FS_CENSUS(FS_CENSUS_CONV_HALO | (stats ? FS_CENSUS_STATS : 0), d);
-    if (d->dtype == FS_F32) dispatch_halo<float>((hipStream_t)stream, a);
-    else dispatch_halo<bf16_t>((hipStream_t)stream, a);
+    if (d->dtype == FS_F32) dispatch_halo<float>((hipStream_t)stream, a, force, d->stride);
+    else dispatch_halo<bf16_t>((hipStream_t)stream, a, force, d->stride);
     return check_launch("fs_conv3x3_s1_fwd");
 }

@@ -84,9 +84,9 @@ class InferenceEngine:
         self.vec = K.vec_of(dtype)
         # 3x3/s1 layers with at least this many output pixels run on the LDS-halo kernel (conv3x3_halo.hip)
         self.halo_min_pixels = int(os.environ.get("FS_HALO_MIN_PIXELS", halo_min_pixels))
-        # per-layer halo vs implicit-GEMM choice by timing both at build: measured on the student it moves 7 layers and
-        # saves ~6 us of 447 per frame - within run-to-run noise - so it is opt-in
-        self.autotune = bool(int(os.environ.get("FS_ENGINE_AUTOTUNE", "0")))
+        # per-layer kernel choice for 3x3 / stride-1 convs (LDS-halo with a 32 / 64 / 128-channel tile, or the implicit GEMM) by
+        # timing every candidate at build
+        self.autotune = bool(int(os.environ.get("FS_ENGINE_AUTOTUNE", "1")))
         self.autotuned = []
         self.n_lanes = max(1, int(os.environ.get("FS_ENGINE_LANES", lanes)))
         self.input = torch.zeros(self.input_shape, dtype=torch.float32, device=self.device)
@@ -339,8 +339,8 @@ class InferenceEngine:
             src_hw, (H, W) = (H, W), vres[:2]
             label = "%s[<-%dx%d%s]" % (label, src_hw[0], src_hw[1], "+relu" if vres[2] else "")
         _, _, Ho, Wo = out.shape
-        halo_ok = k == 3 and stride == 1 and pad == 1 and vres is None
-        use_halo = halo_ok and N * H * W >= self.halo_min_pixels
+        halo_ok = k == 3 and stride in (1, 2) and pad == 1 and vres is None
+        use_halo = halo_ok and stride == 1 and N * H * W >= self.halo_min_pixels
         xp, x_cs = self._ptr(x)
         yp, y_cs = self._ptr(out)
         yp += out_off * (2 if self.dtype == torch.bfloat16 else 4)
@@ -349,28 +349,35 @@ class InferenceEngine:
             d.vr_H, d.vr_W, d.vr_relu = src_hw[0], src_hw[1], int(vres[2])
         self._keep.append(d)
 
-        def variant(halo):
-            if halo:        # LDS-halo 3x3 kernel with the fragment-packed filter bank
+        def variant(halo, tile=0):
+            dd = d
+            if halo:        # LDS-halo 3x3 kernel with the fragment-packed filter bank; tile = forced output-channel tile (0: heuristic)
                 wp = K.pack_weight_frag(weight.detach().to(self.device), self.dtype, cout, cin)
+                if tile:
+                    dd = ConvDesc.from_buffer_copy(bytes(d))
+                    dd.flags |= {32: 0x1000, 64: 0x2000, 128: 0x3000}[tile]
+                    self._keep.append(dd)
             else:
                 wp = K.pack_weight(weight.detach().to(self.device), self.dtype, cout, cin)
-            args = (ctypes.byref(d), ctypes.c_void_p(xp), ctypes.c_void_p(wp.data_ptr()), K._p(scale), K._p(shift), ctypes.c_void_p(yp), None)
-            return "fs_conv3x3_s1_fwd" if halo else "fs_conv2d_fwd", args, wp
-        fn, args, wp = variant(use_halo)
-        # near the threshold neither kernel wins consistently (the halo kernel needs enough tiles, the implicit GEMM re-gathers
-        # every pixel nine times): time both on the device and keep the faster one for this layer
-        if halo_ok and self.autotune and self.halo_min_pixels // 8 <= N * H * W <= self.halo_min_pixels * 4:
-            other = variant(not use_halo)
-            t_cur, t_other = self._time_call(fn, args), self._time_call(other[0], other[1])
-            self.autotuned.append((label, N * H * W, cin, cout, fn, round(t_cur * 1e3, 2), round(t_other * 1e3, 2)))
-            if t_other < 0.97 * t_cur:
-                fn, args, wp = other
+            args = (ctypes.byref(dd), ctypes.c_void_p(xp), ctypes.c_void_p(wp.data_ptr()), K._p(scale), K._p(shift), ctypes.c_void_p(yp), None)
+            return ("fs_conv3x3_s1_fwd" if halo else "fs_conv2d_fwd"), args, wp, dd
+        fn, args, wp, dsel = variant(use_halo)
+        # Which kernel (LDS-halo with a 32 / 64 / 128-channel tile, or the implicit GEMM) is fastest for a 3x3 layer depends on
+        # how many blocks each gives on this map: every candidate is timed on the device at build and the fastest kept
+        # (FS_ENGINE_AUTOTUNE=0: the heuristics only).
+        if halo_ok and self.autotune and N * Ho * Wo >= 512:
+            cands = [("halo", variant(True)), ("igemm", variant(False))]
+            cands += [("halo%d" % t, variant(True, t)) for t in (32, 64, 128) if t <= max(32, K.round_up(cout, 32)) * 2 and t <= 128]
+            timed = [(self._time_call(v[0], v[1]), name, v) for name, v in cands]
+            best = min(timed, key=lambda tv: tv[0])
+            self.autotuned.append((label, N * H * W, cin, cout, best[1], [(nm, round(t * 1e3, 2)) for t, nm, _ in timed]))
+            fn, args, wp, dsel = best[2]
         self._keep.append(wp)
         es = 2 if self.dtype == torch.bfloat16 else 4
         flops = 2.0 * N * Ho * Wo * cout * cin * k * k
         in_px = N * (src_hw[0] * src_hw[1] if src_hw else H * W)
         nbytes = es * (in_px * cin + cout * cin * k * k + N * Ho * Wo * cout)
-        self.calls.append(dict(fn=fn, args=args, desc=d, family="conv%dx%d" % (k, k), flops=flops, bytes=nbytes,
+        self.calls.append(dict(fn=fn, args=args, desc=dsel, family="conv%dx%d" % (k, k), flops=flops, bytes=nbytes,
                                label="%s %dx%d s%d %d->%d @%dx%d" % (label, k, k, stride, cin, cout, H, W)))
 
     # ---- 3a. a zoomed-conv cell: one fused launch, or (when that measures slower) its separate launches -----------------

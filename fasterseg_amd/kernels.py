@@ -250,13 +250,15 @@ def pack_weight_frag(w, dtype, cout=None, cin=None):
     return out
 
 
-def conv3x3_halo(x, w_frag, cout, scale=None, shift=None, relu=False, out=None, stats=None):
-    """3x3 / stride 1 / pad 1 conv through the halo-tiled kernel (same epilogue contract as conv2d)."""
+def conv3x3_halo(x, w_frag, cout, scale=None, shift=None, relu=False, out=None, stats=None, stride=1, tile=0):
+    """3x3 / pad 1 conv at stride 1 or 2 through the halo-tiled kernel (same epilogue contract as conv2d); tile = forced
+    output-channel tile (32 / 64 / 128, 0: heuristic)."""
     x_cs = require_nhwc(x, "x")
     N, Cin, H, W = x.shape
-    d = conv_desc(x.shape, x_cs, cout, 3, 3, 1, 1, 0, x.dtype, FS_CONV_RELU if relu else 0)
+    flags = (FS_CONV_RELU if relu else 0) | {0: 0, 32: 0x1000, 64: 0x2000, 128: 0x3000}[tile]
+    d = conv_desc(x.shape, x_cs, cout, 3, 3, stride, 1, 0, x.dtype, flags)
     if out is None:
-        out = empty_nhwc(N, cout, H, W, x.dtype, x.device)
+        out = empty_nhwc(N, cout, d.Ho, d.Wo, x.dtype, x.device)
     d.y_cs = channel_stride(out)
     call("fs_conv3x3_s1_fwd", _stream(), ctypes.byref(d), _p(x), _p(w_frag), _p(scale), _p(shift), _p(out), _p(stats))
     return out

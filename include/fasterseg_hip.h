@@ -36,6 +36,11 @@ typedef enum { FS_F32 = 0, FS_BF16 = 1 } fs_dtype;
 #define FS_CONV_RELU        1   /* y = max(y, 0) after scale/shift            (nn.ReLU, operations.py:74,147) */
 #define FS_CONV_TRANSPOSED  2   /* gather for the data gradient of a stride-2 conv (conv2d backward-input)   */
 #define FS_CONV_ACCUM       4   /* y += result (fp32 only), used by split accumulations                       */
+/* fs_conv3x3_s1_fwd only: output-channel tile per block instead of the heuristic (the engine times the candidates)   */
+#define FS_CONV_TILE_32     0x1000
+#define FS_CONV_TILE_64     0x2000
+#define FS_CONV_TILE_128    0x3000
+#define FS_CONV_TILE_MASK   0x3000
 
 typedef struct fs_conv_desc {
     int N, H, W, Cin;       /* input  (N,H,W,Cin)                                        */
@@ -152,6 +157,9 @@ fs_status fs_conv2d_wgrad_strided(void* stream, const fs_conv_desc* d, const voi
  * scale/shift/ReLU.  w_packed is [Cout][3][3][3] fp32. */
 fs_status fs_conv_stem_fwd(void* stream, int N, int H, int W, int Cout, const float* x_nchw, const float* w_packed,
                            const float* scale, const float* shift, void* y, int y_cs, int dtype, int relu);
+
+/* test hook: 0 = fs_conv_stem_fwd always takes the direct vector-ALU kernel, 1 (default) = bf16 outputs take the MFMA form */
+void fs_debug_stem_mfma(int on);
 
 /* --- bilinear resize, align_corners=True -------------------------------------------------------- */
 /* Replaces F.interpolate(mode='bilinear', align_corners=True) (operations.py:271,275,437,444;

@@ -133,6 +133,51 @@ def test_conv3x3_halo(case, dtype):
         assert float(wide[:, :32].abs().max()) == 0.0
 
 
+HALO_S2_CASES = [
+    # N, Cin, H, W, Cout
+    (1, 32, 64, 96, 64),          # stem.1 conv1 of the student (32 -> 64, stride 2), reduced map
+    (2, 64, 40, 72, 64),
+    (1, 32, 33, 47, 32),          # odd input size: ragged output tiles, last tap on the zero padding
+    (1, 24, 18, 34, 48),          # channel tails
+    (1, 96, 16, 32, 160),         # 128-wide tile + tail
+    (1, 8, 6, 10, 8),             # smaller than one tile
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("tile", [0, 32, 64, 128])
+@pytest.mark.parametrize("case", HALO_S2_CASES, ids=["%dx%dx%dx%d-%d" % c for c in HALO_S2_CASES])
+def test_conv3x3_halo_stride2(case, dtype, tile):
+    """The stride-2 form of the LDS-halo kernel (even / odd input columns de-interleaved in LDS) == F.conv2d(k3, s2, p1) for
+    every output-channel tile, incl. odd sizes and the BN-statistics epilogue (operations.py:298-306 at stride 2)."""
+    k = K()
+    N, Cin, H, W, Cout = case
+    x = q(rnd(N, Cin, H, W, seed=11), dtype)
+    w = q(rnd(Cout, Cin, 3, 3, seed=12, scale=(2.0 / (Cin * 9)) ** 0.5), dtype)
+    scale, shift = rnd(Cout, seed=13).abs() + 0.5, rnd(Cout, seed=14)
+    raw = F.conv2d(x, w, None, 2, 1)
+    ref = F.relu(raw * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    xd = k.to_nhwc(x.cuda(), dtype)
+    wf = k.pack_weight_frag(w.cuda(), dtype)
+    stats = torch.zeros(2 * Cout, device="cuda")
+    y = k.conv3x3_halo(xd, wf, Cout, scale.cuda(), shift.cuda(), relu=True, stats=stats, stride=2, tile=tile)
+    assert tuple(y.shape) == tuple(ref.shape)
+    check(y, ref, dtype, "stride-2 halo conv+affine+relu (tile %d)" % tile)
+    cnt = raw.numel() / Cout
+    assert torch.allclose(stats[:Cout].cpu(), raw.sum((0, 2, 3)), atol=2e-3 * cnt ** 0.5 + 1e-3, rtol=2e-3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("tile", [32, 64, 128])
+def test_conv3x3_halo_forced_tiles_stride1(dtype, tile):
+    k = K()
+    x = q(rnd(1, 64, 24, 40, seed=21), dtype)
+    w = q(rnd(96, 64, 3, 3, seed=22, scale=0.06), dtype)
+    ref = F.conv2d(x, w, None, 1, 1)
+    y = k.conv3x3_halo(k.to_nhwc(x.cuda(), dtype), k.pack_weight_frag(w.cuda(), dtype), 96, tile=tile)
+    check(y, ref, dtype, "halo tile %d" % tile)
+
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 def test_conv2d_into_channel_slice(dtype):
     """torch.cat fused away: the conv writes into a channel slice of a wider buffer and reads from one."""
@@ -199,6 +244,34 @@ def test_stem_conv(cout, dtype, hw):
     wp = k.pack_weight(w.cuda(), torch.float32)
     y = k.conv_stem(x.cuda(), wp, cout, scale.cuda(), shift.cuda(), True, dtype)
     check(y, q(ref, dtype) if dtype != torch.float32 else ref, dtype, "stem")
+
+
+@pytest.mark.parametrize("cout", [32, 48, 64, 8])
+@pytest.mark.parametrize("hw", [(34, 52), (26, 264), (17, 136), (128, 256)])
+def test_stem_mfma_form_matches_fp32_direct_form(cout, hw):
+    """The matrix-core stem (split-bf16 operands: x_hi*w_hi + x_lo*w_hi + x_hi*w_lo) against the fp32 vector-ALU stem and
+    against F.conv2d: the only difference allowed is the final bf16 rounding of the output (one ulp = 2^-8 relative)."""
+    from fasterseg_amd import _lib
+    k = K()
+    x = rnd(2, 3, hw[0], hw[1], seed=17) * 2.0
+    w = rnd(cout, 3, 3, 3, seed=18, scale=0.3)
+    scale, shift = rnd(cout, seed=19).abs() + 0.5, rnd(cout, seed=20)
+    ref = F.relu(F.conv2d(x, w, None, 2, 1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    wp = k.pack_weight(w.cuda(), torch.float32)
+    lib = _lib.lib()
+    try:
+        lib.fs_debug_stem_mfma(1)
+        y_mfma = k.conv_stem(x.cuda(), wp, cout, scale.cuda(), shift.cuda(), True, torch.bfloat16).float().cpu()
+        lib.fs_debug_stem_mfma(0)
+        y_valu = k.conv_stem(x.cuda(), wp, cout, scale.cuda(), shift.cuda(), True, torch.bfloat16).float().cpu()
+    finally:
+        lib.fs_debug_stem_mfma(1)
+    # both are the bf16 rounding of (nearly) the same fp32 value: the split drops x_lo*w_lo (2^-16 of sum|x*w| ~ 1e-4 here),
+    # so they differ by at most that plus one bf16 ulp of the result, and only where the rounding boundary is crossed
+    tol = 2e-4 + ref.abs() * 2.0 ** -7
+    assert ((y_mfma - y_valu).abs() <= tol).all(), float((y_mfma - y_valu).abs().max())
+    assert float(((y_mfma - y_valu).abs() > 0).float().mean()) < 0.05
+    assert ((y_mfma - ref).abs() <= tol).all()
 
 
 RESIZE_CASES = [((2, 32, 9, 12), (18, 24)), ((1, 64, 16, 32), (8, 16)), ((2, 16, 7, 14), (3, 7)), ((1, 32, 3, 7), (7, 14)),
