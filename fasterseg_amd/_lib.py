@@ -64,6 +64,12 @@ SIGNATURES = {
                           c_int, c_int],
     "fs_affine_act": [c_vp, c_ll, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int],
     "fs_channel_stats": [c_vp, c_ll, c_int, c_vp, c_int, c_int, c_vp],
+    "fs_channel_stats_g": [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_int, c_vp],
+    "fs_bn_train_apply_g": [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_float, c_float, c_vp, c_vp, c_vp, c_vp, c_vp,
+                            c_int, c_int, c_int],
+    "fs_bn_bwd_reduce_g": [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp],
+    "fs_bn_bwd_apply_g": [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_ll, c_int,
+                          c_int, c_vp, c_int, c_vp, c_vp, c_vp],
     "fs_bn_group_fwd": [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_float, c_float, c_vp, c_vp, c_vp, c_vp, c_vp,
                         c_int, c_int, c_int],
     "fs_bn_group_bwd": [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_vp,
@@ -71,6 +77,10 @@ SIGNATURES = {
     "fs_bn_bwd_reduce": [c_vp, c_ll, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_vp],
     "fs_bn_bwd_apply": [c_vp, c_ll, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_ll, c_int,
                         c_int, c_vp, c_int, c_vp, c_vp],
+    "fs_bn_act_train_fwd": [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_float, c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                            c_int, c_int, c_int],
+    "fs_bn_act_train_bwd": [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_vp,
+                            c_int, c_vp, c_vp],
     "fs_conv_bn_act_train_fwd": [c_vp, ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_float, c_float,
                                  c_vp, c_vp, c_vp, c_vp, c_vp, c_ll],
     "fs_conv_bn_act_train_bwd": [c_vp, ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp,

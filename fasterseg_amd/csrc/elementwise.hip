@@ -154,28 +154,35 @@ __global__ void ew_kernel(long long pixels, int cv, const T* __restrict__ x, int
 // Train-mode BN normalise pass with the statistics finalisation folded in: every thread derives scale/shift of its channel
 // vector from the raw (sum, sumsq) - a few flops - so the separate bn_finalize launch disappears; block 0 also publishes
 // mean / invstd / scale / shift for the backward and updates running statistics and num_batches_tracked.
+// `groups` > 1: consecutive ranges of pixels/groups pixels are normalised independently (stats / saved hold one block of 2C / 4C
+// floats per group), running statistics take the groups' updates one after the other (fs_conv_desc.bn_groups).
 template <typename T>
 __global__ void bn_train_apply_kernel(long long pixels, int cv, const T* __restrict__ x, int x_cs, const float* __restrict__ stats,
                                       float count, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                       float momentum, float* running_mean, float* running_var, long long* num_batches_tracked,
-                                      float* __restrict__ saved, T* __restrict__ y, int y_cs, int relu) {
+                                      float* __restrict__ saved, T* __restrict__ y, int y_cs, int relu, int groups) {
     constexpr int VEC = Elem<T>::VEC;
     const int C = cv * VEC;
+    const long long mg = pixels / groups;
     if (blockIdx.x == 0) {
-        if (threadIdx.x == 0 && num_batches_tracked) *num_batches_tracked += 1;
+        if (threadIdx.x == 0 && num_batches_tracked) *num_batches_tracked += groups;
         for (int c = threadIdx.x; c < C; c += blockDim.x) {
-            const float m = stats[c] / count;
-            const float var = fmaxf(stats[C + c] / count - m * m, 0.f);
-            const float is = 1.0f / sqrtf(var + eps);
-            const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-            saved[c] = m;
-            saved[C + c] = is;
-            saved[2 * C + c] = g * is;
-            saved[3 * C + c] = b - m * g * is;
-            if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
-            if (running_var) {
-                const float unbiased = count > 1.f ? var * (count / (count - 1.f)) : var;
-                running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+            for (int g_ = 0; g_ < groups; ++g_) {
+                const float* st = stats + (long long)g_ * 2 * C;
+                float* sv = saved + (long long)g_ * 4 * C;
+                const float m = st[c] / count;
+                const float var = fmaxf(st[C + c] / count - m * m, 0.f);
+                const float is = 1.0f / sqrtf(var + eps);
+                const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+                sv[c] = m;
+                sv[C + c] = is;
+                sv[2 * C + c] = g * is;
+                sv[3 * C + c] = b - m * g * is;
+                if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+                if (running_var) {
+                    const float unbiased = count > 1.f ? var * (count / (count - 1.f)) : var;
+                    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+                }
             }
         }
     }
@@ -184,12 +191,13 @@ __global__ void bn_train_apply_kernel(long long pixels, int cv, const T* __restr
          idx += (long long)gridDim.x * blockDim.x) {
         const long long pix = idx / cv;
         const int c = (int)(idx - pix * cv) * VEC;
+        const float* stats_g = groups > 1 ? stats + (pix / mg) * 2 * C : stats;
         float f[VEC];
         Elem<T>::unpack(ldg16(x + pix * x_cs + c), f);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
-            const float m = stats[c + i] / count;
-            const float var = fmaxf(stats[C + c + i] / count - m * m, 0.f);
+            const float m = stats_g[c + i] / count;
+            const float var = fmaxf(stats_g[C + c + i] / count - m * m, 0.f);
             const float is = 1.0f / sqrtf(var + eps);
             const float sc = (gamma ? gamma[c + i] : 1.f) * is;
             const float o = f[i] * sc + ((beta ? beta[c + i] : 0.f) - m * sc);
@@ -209,9 +217,15 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(long long pixels, int 
                                                           const T* __restrict__ dy, int dy_cs, const T* __restrict__ yo,
                                                           int y_cs, const float* __restrict__ mean,
                                                           const float* __restrict__ invstd, int relu,
-                                                          float* __restrict__ out, long long pix_per_block) {
+                                                          float* __restrict__ out, long long pix_per_block, long long group_pixels,
+                                                          int saved_stride) {
     constexpr int VEC = Elem<T>::VEC;
     __shared__ float red[2][256][VEC + 1];
+    // blockIdx.y = group: its pixel range, its output slot (2C floats) and its saved (mean, invstd) block
+    const long long g_first = blockIdx.y * group_pixels;
+    out += (long long)blockIdx.y * 2 * C;
+    if (MODE == 1) { mean += (long long)blockIdx.y * saved_stride; invstd += (long long)blockIdx.y * saved_stride; }
+    pixels = g_first + group_pixels;
     const int cv = C / VEC;
     const int rpb = 256 / cv;            // pixel rows processed per iteration
     const int tid = threadIdx.x;
@@ -224,7 +238,7 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(long long pixels, int 
         a0[i] = 0.f; a1[i] = 0.f; mu[i] = 0.f; is[i] = 1.f;
         if (MODE == 1) { mu[i] = mean[col * VEC + i]; is[i] = invstd[col * VEC + i]; }
     }
-    const long long p_begin = blockIdx.x * pix_per_block;
+    const long long p_begin = g_first + blockIdx.x * pix_per_block;
     long long p_end = p_begin + pix_per_block;
     if (p_end > pixels) p_end = pixels;
     if (active) {
@@ -266,19 +280,36 @@ __global__ void bn_bwd_apply_kernel(long long pixels, int cv, const T* __restric
                                     int dy_cs, const T* __restrict__ yo, int y_cs, const float* __restrict__ mean,
                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
                                     const float* __restrict__ red, float inv_count, int relu, T* __restrict__ dx,
-                                    int dx_cs, float* dgamma_acc, float* dbeta_acc) {
+                                    int dx_cs, float* dgamma_acc, float* dbeta_acc, int groups, int saved_stride,
+                                    float* __restrict__ red_total) {
     constexpr int VEC = Elem<T>::VEC;
     const int C = cv * VEC;
     const long long total = pixels * cv;
-    if (dgamma_acc && blockIdx.x == 0)          // parameter gradients: grad += this pass's reduction (one block, plain RMW)
-        for (int c = threadIdx.x; c < C; c += blockDim.x) {
-            dgamma_acc[c] += red[C + c];
-            dbeta_acc[c] += red[c];
+    const long long mg = pixels / groups;
+    if ((dgamma_acc || red_total) && blockIdx.x == 0)          // parameter gradients: grad += this pass's reduction, summed over
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {    // the groups in order (one block, plain RMW)
+            float sg = 0.f, sb = 0.f;
+            for (int g_ = 0; g_ < groups; ++g_) {
+                sg += red[(long long)g_ * 2 * C + C + c];
+                sb += red[(long long)g_ * 2 * C + c];
+            }
+            if (dgamma_acc) {
+                dgamma_acc[c] += sg;
+                dbeta_acc[c] += sb;
+            }
+            if (red_total) {
+                red_total[c] = sb;
+                red_total[C + c] = sg;
+            }
         }
     for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
         const long long pix = idx / cv;
         const int c = (int)(idx - pix * cv) * VEC;
+        const long long grp = groups > 1 ? pix / mg : 0;
+        const float* mean_g = mean + grp * saved_stride;
+        const float* invstd_g = invstd + grp * saved_stride;
+        const float* red_g = red + grp * 2 * C;
         float f[VEC], g[VEC];
         Elem<T>::unpack(ldg16(x + pix * x_cs + c), f);
         Elem<T>::unpack(ldg16(dy + pix * dy_cs + c), g);
@@ -290,9 +321,9 @@ __global__ void bn_bwd_apply_kernel(long long pixels, int cv, const T* __restric
         }
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
-            const float is = invstd[c + i];
-            const float xh = (f[i] - mean[c + i]) * is;
-            f[i] = gamma[c + i] * is * (g[i] - red[c + i] * inv_count - xh * red[C + c + i] * inv_count);
+            const float is = invstd_g[c + i];
+            const float xh = (f[i] - mean_g[c + i]) * is;
+            f[i] = gamma[c + i] * is * (g[i] - red_g[c + i] * inv_count - xh * red_g[C + c + i] * inv_count);
         }
         stg16(dx + pix * dx_cs + c, Elem<T>::pack(f));
     }
@@ -550,18 +581,25 @@ static int reduce_blocks(long long pixels, int rpb, long long* ppb) {
     return (int)((pixels + per - 1) / per);
 }
 
-extern "C" fs_status fs_channel_stats(void* stream, long long pixels, int C, const void* x, int x_cs, int dtype, float* stats) {
+extern "C" fs_status fs_channel_stats_g(void* stream, long long pixels, int C, int groups, const void* x, int x_cs, int dtype,
+                                        float* stats) {
     fs_status s;
     if ((s = check_slice("fs_channel_stats", x, x_cs, C, dtype)) != FS_OK) return s;
     FS_REQUIRE(stats, FS_ERR_INVALID, "fs_channel_stats: null stats");
+    FS_REQUIRE(groups >= 1 && pixels % groups == 0, FS_ERR_INVALID, "fs_channel_stats: %lld pixels in %d groups", pixels, groups);
     const int cv = C / vec_elems(dtype);
     FS_REQUIRE(cv <= 256, FS_ERR_UNSUPPORTED, "fs_channel_stats: C=%d too large", C);
     long long ppb;
-    const int blocks = reduce_blocks(pixels, 256 / cv, &ppb);
-    DT_DISPATCH(dtype, hipLaunchKernelGGL((chan_reduce_kernel<T, 0>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, pixels, C,
+    const long long mg = pixels / groups;
+    const int blocks = reduce_blocks(mg, 256 / cv, &ppb);
+    DT_DISPATCH(dtype, hipLaunchKernelGGL((chan_reduce_kernel<T, 0>), dim3(blocks, groups), dim3(256), 0, (hipStream_t)stream, pixels, C,
                                           (const T*)x, x_cs, (const T*)nullptr, 0, (const T*)nullptr, 0, nullptr, nullptr, 0,
-                                          stats, ppb);)
+                                          stats, ppb, mg, 0);)
     return check_launch("fs_channel_stats");
+}
+
+extern "C" fs_status fs_channel_stats(void* stream, long long pixels, int C, const void* x, int x_cs, int dtype, float* stats) {
+    return fs_channel_stats_g(stream, pixels, C, 1, x, x_cs, dtype, stats);
 }
 
 extern "C" fs_status fs_bn_finalize(void* stream, int C, long long count, const float* stats, const float* gamma,
@@ -573,28 +611,38 @@ extern "C" fs_status fs_bn_finalize(void* stream, int C, long long count, const 
     return check_launch("fs_bn_finalize");
 }
 
-extern "C" fs_status fs_bn_bwd_reduce(void* stream, long long pixels, int C, const void* x, int x_cs, const void* dy, int dy_cs,
-                                      const void* y_out, int y_cs, const float* mean, const float* invstd, int dtype, int relu,
-                                      float* red) {
+// Grouped forms (fs_conv_desc.bn_groups): `saved` = [groups][4][C] (mean, invstd, scale, shift per group), `red` = [groups][2][C]
+// partial reductions; fs_bn_bwd_apply_g also writes their sum over the groups to red_total[2][C] when given.
+extern "C" fs_status fs_bn_bwd_reduce_g(void* stream, long long pixels, int C, int groups, const void* x, int x_cs, const void* dy,
+                                        int dy_cs, const void* y_out, int y_cs, const float* mean, const float* invstd,
+                                        int saved_stride, int dtype, int relu, float* red) {
     fs_status s;
     if ((s = check_slice("fs_bn_bwd_reduce", x, x_cs, C, dtype)) != FS_OK) return s;
     if ((s = check_slice("fs_bn_bwd_reduce", dy, dy_cs, C, dtype)) != FS_OK) return s;
     if (relu && (s = check_slice("fs_bn_bwd_reduce", y_out, y_cs, C, dtype)) != FS_OK) return s;
     FS_REQUIRE(mean && invstd && red, FS_ERR_INVALID, "fs_bn_bwd_reduce: null pointer");
+    FS_REQUIRE(groups >= 1 && pixels % groups == 0, FS_ERR_INVALID, "fs_bn_bwd_reduce: %lld pixels in %d groups", pixels, groups);
     const int cv = C / vec_elems(dtype);
     FS_REQUIRE(cv <= 256, FS_ERR_UNSUPPORTED, "fs_bn_bwd_reduce: C=%d too large", C);
     long long ppb;
-    const int blocks = reduce_blocks(pixels, 256 / cv, &ppb);
-    DT_DISPATCH(dtype, hipLaunchKernelGGL((chan_reduce_kernel<T, 1>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, pixels, C,
+    const long long mg = pixels / groups;
+    const int blocks = reduce_blocks(mg, 256 / cv, &ppb);
+    DT_DISPATCH(dtype, hipLaunchKernelGGL((chan_reduce_kernel<T, 1>), dim3(blocks, groups), dim3(256), 0, (hipStream_t)stream, pixels, C,
                                           (const T*)x, x_cs, (const T*)dy, dy_cs, (const T*)y_out, y_cs, mean, invstd, relu, red,
-                                          ppb);)
+                                          ppb, mg, saved_stride);)
     return check_launch("fs_bn_bwd_reduce");
 }
 
-extern "C" fs_status fs_bn_bwd_apply(void* stream, long long pixels, int C, const void* x, int x_cs, const void* dy, int dy_cs,
-                                     const void* y_out, int y_cs, const float* mean, const float* invstd, const float* gamma,
-                                     const float* red, long long count, int dtype, int relu, void* dx, int dx_cs,
-                                     float* dgamma_acc, float* dbeta_acc) {
+extern "C" fs_status fs_bn_bwd_reduce(void* stream, long long pixels, int C, const void* x, int x_cs, const void* dy, int dy_cs,
+                                      const void* y_out, int y_cs, const float* mean, const float* invstd, int dtype, int relu,
+                                      float* red) {
+    return fs_bn_bwd_reduce_g(stream, pixels, C, 1, x, x_cs, dy, dy_cs, y_out, y_cs, mean, invstd, 0, dtype, relu, red);
+}
+
+extern "C" fs_status fs_bn_bwd_apply_g(void* stream, long long pixels, int C, int groups, const void* x, int x_cs, const void* dy,
+                                       int dy_cs, const void* y_out, int y_cs, const float* mean, const float* invstd,
+                                       int saved_stride, const float* gamma, const float* red, long long count, int dtype, int relu,
+                                       void* dx, int dx_cs, float* red_total, float* dgamma_acc, float* dbeta_acc) {
     fs_status s;
     FS_REQUIRE((dgamma_acc == nullptr) == (dbeta_acc == nullptr), FS_ERR_INVALID, "fs_bn_bwd_apply: dgamma_acc/dbeta_acc go together");
     if ((s = check_slice("fs_bn_bwd_apply", x, x_cs, C, dtype)) != FS_OK) return s;
@@ -602,11 +650,21 @@ extern "C" fs_status fs_bn_bwd_apply(void* stream, long long pixels, int C, cons
     if ((s = check_slice("fs_bn_bwd_apply", dx, dx_cs, C, dtype)) != FS_OK) return s;
     if (relu && (s = check_slice("fs_bn_bwd_apply", y_out, y_cs, C, dtype)) != FS_OK) return s;
     FS_REQUIRE(mean && invstd && gamma && red && count > 0, FS_ERR_INVALID, "fs_bn_bwd_apply: bad argument");
+    FS_REQUIRE(groups >= 1 && pixels % groups == 0, FS_ERR_INVALID, "fs_bn_bwd_apply: %lld pixels in %d groups", pixels, groups);
     const int cv = C / vec_elems(dtype);
     DT_DISPATCH(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(grid_for(pixels * cv)), dim3(256), 0, (hipStream_t)stream,
                                           pixels, cv, (const T*)x, x_cs, (const T*)dy, dy_cs, (const T*)y_out, y_cs, mean, invstd,
-                                          gamma, red, 1.0f / (float)count, relu, (T*)dx, dx_cs, dgamma_acc, dbeta_acc);)
+                                          gamma, red, 1.0f / (float)count, relu, (T*)dx, dx_cs, dgamma_acc, dbeta_acc, groups,
+                                          saved_stride, red_total);)
     return check_launch("fs_bn_bwd_apply");
+}
+
+extern "C" fs_status fs_bn_bwd_apply(void* stream, long long pixels, int C, const void* x, int x_cs, const void* dy, int dy_cs,
+                                     const void* y_out, int y_cs, const float* mean, const float* invstd, const float* gamma,
+                                     const float* red, long long count, int dtype, int relu, void* dx, int dx_cs,
+                                     float* dgamma_acc, float* dbeta_acc) {
+    return fs_bn_bwd_apply_g(stream, pixels, C, 1, x, x_cs, dy, dy_cs, y_out, y_cs, mean, invstd, 0, gamma, red, count, dtype, relu, dx,
+                             dx_cs, nullptr, dgamma_acc, dbeta_acc);
 }
 
 extern "C" fs_status fs_dot(void* stream, long long pixels, int C, const void* x, int x_cs, const void* y, int y_cs, int dtype,
@@ -675,17 +733,26 @@ extern "C" fs_status fs_weighted_sum_dots(void* stream, long long pixels, int C,
     return check_launch("fs_weighted_sum_dots");
 }
 
-extern "C" fs_status fs_bn_train_apply(void* stream, long long pixels, int C, const void* x, int x_cs, const float* stats,
-                                       const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
-                                       float* running_var, long long* num_batches_tracked, float* saved, void* y, int y_cs,
-                                       int dtype, int relu) {
+extern "C" fs_status fs_bn_train_apply_g(void* stream, long long pixels, int C, int groups, const void* x, int x_cs,
+                                         const float* stats, const float* gamma, const float* beta, float eps, float momentum,
+                                         float* running_mean, float* running_var, long long* num_batches_tracked, float* saved,
+                                         void* y, int y_cs, int dtype, int relu) {
     fs_status s;
     if ((s = check_slice("fs_bn_train_apply", x, x_cs, C, dtype)) != FS_OK) return s;
     if ((s = check_slice("fs_bn_train_apply", y, y_cs, C, dtype)) != FS_OK) return s;
     FS_REQUIRE(stats && saved && pixels > 0, FS_ERR_INVALID, "fs_bn_train_apply: bad argument");
+    FS_REQUIRE(groups >= 1 && pixels % groups == 0, FS_ERR_INVALID, "fs_bn_train_apply: %lld pixels in %d groups", pixels, groups);
     const int cv = C / vec_elems(dtype);
     DT_DISPATCH(dtype, hipLaunchKernelGGL((bn_train_apply_kernel<T>), dim3(grid_for(pixels * cv)), dim3(256), 0, (hipStream_t)stream,
-                                          pixels, cv, (const T*)x, x_cs, stats, (float)pixels, gamma, beta, eps, momentum,
-                                          running_mean, running_var, num_batches_tracked, saved, (T*)y, y_cs, relu);)
+                                          pixels, cv, (const T*)x, x_cs, stats, (float)(pixels / groups), gamma, beta, eps, momentum,
+                                          running_mean, running_var, num_batches_tracked, saved, (T*)y, y_cs, relu, groups);)
     return check_launch("fs_bn_train_apply");
+}
+
+extern "C" fs_status fs_bn_train_apply(void* stream, long long pixels, int C, const void* x, int x_cs, const float* stats,
+                                       const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                                       float* running_var, long long* num_batches_tracked, float* saved, void* y, int y_cs,
+                                       int dtype, int relu) {
+    return fs_bn_train_apply_g(stream, pixels, C, 1, x, x_cs, stats, gamma, beta, eps, momentum, running_mean, running_var,
+                               num_batches_tracked, saved, y, y_cs, dtype, relu);
 }

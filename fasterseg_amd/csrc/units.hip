@@ -14,6 +14,43 @@
 // GB/s, so beyond a few hundred pixels the two grid-wide passes win and stay.
 static const long long BN_COL_MAX_PIXELS = 512;
 
+// BatchNorm(+ReLU) of an existing map z, forward / backward, the launch sequence chosen by the map size (FactorizedReduce's BN
+// after its two 1x1 convs, operations.py:521-526, and the grouped large-map case of the conv units below).
+extern "C" fs_status fs_bn_act_train_fwd(void* stream, long long pixels, int C, int groups, void* z, int z_cs, const float* gamma,
+                                         const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                                         long long* num_batches_tracked, float* stats, float* saved, void* y, int y_cs, int dtype,
+                                         int relu) {
+    FS_REQUIRE(groups >= 1 && pixels > 0 && pixels % groups == 0, FS_ERR_INVALID, "fs_bn_act_train_fwd: %lld pixels in %d groups",
+               pixels, groups);
+    if (pixels / groups <= BN_COL_MAX_PIXELS)
+        return fs_bn_group_fwd(stream, pixels, C, groups, z, z_cs, nullptr, 1, gamma, beta, eps, momentum, running_mean, running_var,
+                               num_batches_tracked, saved, y, y_cs, dtype, relu);
+    FS_REQUIRE(stats, FS_ERR_INVALID, "fs_bn_act_train_fwd: null stats");
+    fs_status s = fs_channel_stats_g(stream, pixels, C, groups, z, z_cs, dtype, stats);           // stats[groups][2][C], zeroed
+    if (s != FS_OK) return s;
+    return fs_bn_train_apply_g(stream, pixels, C, groups, z, z_cs, stats, gamma, beta, eps, momentum, running_mean, running_var,
+                               num_batches_tracked, saved, y, y_cs, dtype, relu);
+}
+
+extern "C" fs_status fs_bn_act_train_bwd(void* stream, long long pixels, int C, int groups, const void* z, int z_cs, const void* dy,
+                                         int dy_cs, const void* y, int y_cs, const float* saved, const float* gamma, float* red,
+                                         int dtype, int relu, void* dz, int dz_cs, float* dgamma_acc, float* dbeta_acc) {
+    FS_REQUIRE(groups >= 1 && pixels > 0 && pixels % groups == 0, FS_ERR_INVALID, "fs_bn_act_train_bwd: %lld pixels in %d groups",
+               pixels, groups);
+    FS_REQUIRE(saved && red, FS_ERR_INVALID, "fs_bn_act_train_bwd: null argument");
+    if (pixels / groups <= BN_COL_MAX_PIXELS)          // both reductions + the input gradient: one launch
+        return fs_bn_group_bwd(stream, pixels, C, groups, z, z_cs, dy, dy_cs, y, y_cs, saved, gamma, dtype, relu, dz, dz_cs, red,
+                               dgamma_acc, dbeta_acc);
+    const float* mean = saved;
+    const float* invstd = saved + C;
+    // red = [2][C] totals (what fs_bn_group_bwd leaves) followed, for groups > 1, by [groups][2][C] zeroed partials
+    float* part = groups > 1 ? red + 2 * C : red;
+    fs_status s = fs_bn_bwd_reduce_g(stream, pixels, C, groups, z, z_cs, dy, dy_cs, y, y_cs, mean, invstd, 4 * C, dtype, relu, part);
+    if (s != FS_OK) return s;
+    return fs_bn_bwd_apply_g(stream, pixels, C, groups, z, z_cs, dy, dy_cs, y, y_cs, mean, invstd, 4 * C, gamma, part, pixels / groups,
+                             dtype, relu, dz, dz_cs, groups > 1 ? red : nullptr, dgamma_acc, dbeta_acc);
+}
+
 extern "C" fs_status fs_conv_bn_act_train_fwd(void* stream, const fs_conv_desc* d, const void* x, const void* w_packed,
                                               const float* gamma, const float* beta, float* running_mean,
                                               float* running_var, long long* num_batches_tracked, float eps,
@@ -26,13 +63,19 @@ extern "C" fs_status fs_conv_bn_act_train_fwd(void* stream, const fs_conv_desc* 
     const long long count = (long long)d->N * d->Ho * d->Wo;
     const int groups = d->bn_groups > 1 ? d->bn_groups : 1;
     FS_REQUIRE(d->N % groups == 0, FS_ERR_INVALID, "fs_conv_bn_act_train_fwd: batch %d is not %d equal groups", d->N, groups);
-    if (count / groups <= BN_COL_MAX_PIXELS || groups > 1) {      // small map: statistics + normalisation (+ split-K sum) in ONE launch
+    if (count / groups <= BN_COL_MAX_PIXELS) {      // small map: statistics + normalisation (+ split-K sum) in ONE launch
         int slices = 1;
         fs_status s = fs::conv_fwd_deferred(stream, &c, x, w_packed, z, workspace, workspace_bytes, &slices);
         if (s != FS_OK) return s;
         return fs_bn_group_fwd(stream, count, C, groups, z, d->y_cs, slices > 1 ? (const float*)workspace : nullptr, slices, gamma, beta,
                                eps, momentum, running_mean, running_var, num_batches_tracked, saved, y, d->y_cs, d->dtype,
                                (d->flags & FS_CONV_RELU) ? 1 : 0);
+    }
+    if (groups > 1) {              // the conv's fused statistics are per launch, not per group: one reduction launch more
+        fs_status s = fs_conv2d_fwd_ws(stream, &c, x, w_packed, nullptr, nullptr, z, nullptr, workspace, workspace_bytes);
+        if (s != FS_OK) return s;
+        return fs_bn_act_train_fwd(stream, count, C, groups, z, d->y_cs, gamma, beta, eps, momentum, running_mean, running_var,
+                                   num_batches_tracked, stats, saved, y, d->y_cs, d->dtype, (d->flags & FS_CONV_RELU) ? 1 : 0);
     }
     fs_status s = fs_conv2d_fwd_ws(stream, &c, x, w_packed, nullptr, nullptr, z, stats, workspace, workspace_bytes);   // (+ sum / sumsq)
     if (s != FS_OK) return s;
@@ -56,14 +99,14 @@ extern "C" fs_status fs_conv_bn_act_train_bwd(void* stream, const fs_conv_desc* 
     const int groups = d->bn_groups > 1 ? d->bn_groups : 1;
     fs_status s;
     if (pixels / groups <= BN_COL_MAX_PIXELS || groups > 1) {
-        s = fs_bn_group_bwd(stream, pixels, C, groups, z, d->y_cs, dy, dy_cs, y, d->y_cs, saved, gamma, d->dtype, relu, dz, C, red,
-                            dgamma_acc, dbeta_acc);                  // both reductions + the input gradient: one launch
+        s = fs_bn_act_train_bwd(stream, pixels, C, groups, z, d->y_cs, dy, dy_cs, y, d->y_cs, saved, gamma, red, d->dtype, relu, dz, C,
+                                dgamma_acc, dbeta_acc);          // dz is dense: channel stride == Cout
         if (s != FS_OK) return s;
     } else {
         s = fs_bn_bwd_reduce(stream, pixels, C, z, d->y_cs, dy, dy_cs, y, d->y_cs, mean, invstd, d->dtype, relu, red);
         if (s != FS_OK) return s;
         s = fs_bn_bwd_apply(stream, pixels, C, z, d->y_cs, dy, dy_cs, y, d->y_cs, mean, invstd, gamma, red, pixels, d->dtype, relu,
-                            dz, C, dgamma_acc, dbeta_acc);          // dz is dense: channel stride == Cout
+                            dz, C, dgamma_acc, dbeta_acc);
         if (s != FS_OK) return s;
     }
     if (dw) {

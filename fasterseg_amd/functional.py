@@ -150,6 +150,26 @@ def fold_bn(gamma, beta, running_mean, running_var, eps):
     return scale.contiguous(), shift.contiguous()
 
 
+# > 1 while a module is evaluated ONCE on several inputs concatenated along the batch dimension (model_search: the from-down
+# and from-keep inputs of a supernet cell, reference model_search.py:322-329): every train-mode BatchNorm then normalises the
+# `_bn_groups` equal parts of the batch independently and applies their running-statistics updates one after the other, i.e.
+# the arithmetic of separate evaluations at half the launches (fs_conv_desc.bn_groups).
+_bn_groups = 1
+
+
+class bn_groups:
+    def __init__(self, groups):
+        self.groups = int(groups)
+
+    def __enter__(self):
+        global _bn_groups
+        self.prev, _bn_groups = _bn_groups, self.groups
+
+    def __exit__(self, *exc):
+        global _bn_groups
+        _bn_groups = self.prev
+
+
 def _zero_stats(c, device):
     return K.zeros_f32(2 * c, device)
 
@@ -201,7 +221,7 @@ class _ConvBNAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, running_mean, running_var, num_batches_tracked, cfg):
-        stride, pad, relu, training, momentum, eps, cout, cin = cfg
+        stride, pad, relu, training, momentum, eps, cout, cin, groups = cfg
         R, S = weight.shape[2], weight.shape[3]
         assert x.shape[1] == cin, "input has %d channels, conv expects %d" % (x.shape[1], cin)
         if not training:
@@ -220,12 +240,12 @@ class _ConvBNAct(torch.autograd.Function):
         else:
             wp, w_os, w_ts = packed_weight(weight, dtype, cout, cin), 0, 0
         d = K.ConvDesc(N, H, W, cin, cout, R, S, stride, pad, Ho, Wo, x.stride(3), cout, K.dtype_code(dtype),
-                       K.FS_CONV_RELU if relu else 0, w_os, w_ts)
+                       K.FS_CONV_RELU if relu else 0, w_os, w_ts, 0, 0, 0, groups)
         strides = (Ho * Wo * cout, 1, Wo * cout, cout)
         z = torch.empty_strided((N, cout, Ho, Wo), strides, dtype=dtype, device=dev)
         y = torch.empty_strided((N, cout, Ho, Wo), strides, dtype=dtype, device=dev)
-        saved = torch.empty(4 * cout, dtype=torch.float32, device=dev)      # mean | invstd | scale | shift
-        stats = K.zeros_f32(2 * cout, dev)
+        saved = torch.empty(groups * 4 * cout, dtype=torch.float32, device=dev)      # per group: mean | invstd | scale | shift
+        stats = K.zeros_f32(groups * 2 * cout, dev)
         ws, ws_bytes = K.stream_workspace(dev)
         K.call("fs_conv_bn_act_train_fwd", K._stream(), ctypes.byref(d), x.data_ptr(), wp.data_ptr(), gamma.data_ptr(),
                beta.data_ptr(), running_mean.data_ptr() if running_mean is not None else None,
@@ -243,14 +263,14 @@ class _ConvBNAct(torch.autograd.Function):
         if ctx.eval_mode:
             raise RuntimeError("fasterseg_amd: backward through eval-mode conv+BN is not part of the hot path")
         x, weight, gamma, beta, z, y, saved = ctx.saved_tensors
-        stride, pad, relu, training, momentum, eps, cout, cin = ctx.cfg
+        stride, pad, relu, training, momentum, eps, cout, cin, groups = ctx.cfg
         d = ctx.desc
         R, S = d.R, d.S
         dtype, dev = z.dtype, z.device
         dy = as_nhwc(dy, dtype)
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         sink = _grad_sink
-        red = K.zeros_f32(2 * cout, dev)
+        red = K.zeros_f32((groups + 1 if groups > 1 else 1) * 2 * cout, dev)       # totals, then the per-group partials
         gslot = bslot = None
         if ctx.needs_input_grad[2] and ctx.needs_input_grad[3]:
             gslot = _sink_slot(sink, gamma, cout)
@@ -283,7 +303,7 @@ class _ConvBNAct(torch.autograd.Function):
                wf_os, wf_ts, *K.stream_workspace(dev))
         if wslot is not None:
             sink.touched(weight)
-        dgamma, dbeta = red[cout:], red[:cout]
+        dgamma, dbeta = red[cout:2 * cout], red[:cout]
         if gslot is not None:
             sink.touched(gamma)
             sink.touched(beta)
@@ -299,7 +319,7 @@ def conv_bn_act(x, weight, gamma, beta, running_mean, running_var, stride, pad, 
     cin = weight.shape[1] if cin is None else cin
     if _tracer is not None:
         return _tracer.conv(x, weight, (gamma, beta, running_mean, running_var, eps), None, stride, pad, relu, training, cout, cin)
-    cfg = (stride, pad, relu, training, momentum, eps, cout, cin)
+    cfg = (stride, pad, relu, training, momentum, eps, cout, cin, _bn_groups if training else 1)
     return _ConvBNAct.apply(x, weight, gamma, beta, running_mean, running_var, num_batches_tracked if training else None, cfg)
 
 
@@ -435,7 +455,7 @@ class _FactorizedReduce(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w1, w2, gamma, beta, running_mean, running_var, cfg):
-        training, momentum, eps, half, cin = cfg
+        training, momentum, eps, half, cin, groups, nbt = cfg
         N, _, H, W = x.shape
         assert H % 2 == 0 and W % 2 == 0, "FactorizedReduce needs even spatial dims (reference torch.cat would fail too)"
         Ho, Wo = H // 2, W // 2
@@ -452,26 +472,22 @@ class _FactorizedReduce(torch.autograd.Function):
             ctx.mark_non_differentiable(y)
             return y
         z = K.empty_nhwc(N, 2 * half, Ho, Wo, x.dtype, x.device)
-        s1, s2 = _zero_stats(half, x.device), _zero_stats(half, x.device)
-        K.conv2d(x, p1, half, 1, 1, 2, 0, out=z[:, :half], stats=s1, out_hw=out_hw)
-        K.conv2d(x, p2, half, 1, 1, 2, -1, out=z[:, half:], stats=s2, out_hw=out_hw)
-        stats = torch.cat([s1[:half], s2[:half], s1[half:], s2[half:]])
-        mean, invstd, scale, shift = K.bn_finalize(stats, N * Ho * Wo, gamma.detach(), beta.detach(), eps, momentum,
-                                                   running_mean, running_var)
-        y = K.affine_act(z, scale, shift, True)
+        K.conv2d(x, p1, half, 1, 1, 2, 0, out=z[:, :half], out_hw=out_hw)
+        K.conv2d(x, p2, half, 1, 1, 2, -1, out=z[:, half:], out_hw=out_hw)
+        y, saved = K.bn_act_train(z, gamma.detach(), beta.detach(), eps, momentum, running_mean, running_var, nbt, True, groups)
         ctx.eval_mode = False
         ctx.cfg = cfg
-        ctx.save_for_backward(x, w1, w2, gamma, z, y, mean, invstd)
+        ctx.save_for_backward(x, w1, w2, gamma, z, y, saved)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         if ctx.eval_mode:
             raise RuntimeError("fasterseg_amd: backward through eval-mode conv+BN is not part of the hot path")
-        x, w1, w2, gamma, z, y, mean, invstd = ctx.saved_tensors
-        training, momentum, eps, half, cin = ctx.cfg
+        x, w1, w2, gamma, z, y, saved = ctx.saved_tensors
+        training, momentum, eps, half, cin, groups, nbt = ctx.cfg
         dy = as_nhwc(dy, z.dtype)
-        dz, dgamma, dbeta = K.bn_backward(z, dy, y, mean, invstd, gamma.detach(), True)
+        dz, dgamma, dbeta = K.bn_act_train_bwd(z, dy, y, saved, gamma.detach(), True, groups)
         da, db = dz[:, :half], dz[:, half:]
         g1 = g2 = gx = None
         if ctx.needs_input_grad[1]:
@@ -497,13 +513,15 @@ def _one(device):
 
 
 def factorized_reduce(x, w1, w2, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, half=None,
-                      cin=None):
+                      cin=None, num_batches_tracked=None):
     x = as_nhwc(x)
     half = w1.shape[0] if half is None else half
     cin = w1.shape[1] if cin is None else cin
     if _tracer is not None:
         return _tracer.factorized_reduce(x, w1, w2, (gamma, beta, running_mean, running_var, eps), training, half, cin)
-    return _FactorizedReduce.apply(x, w1, w2, gamma, beta, running_mean, running_var, (training, momentum, eps, half, cin))
+    return _FactorizedReduce.apply(x, w1, w2, gamma, beta, running_mean, running_var,
+                                   (training, momentum, eps, half, cin, _bn_groups if training else 1,
+                                    num_batches_tracked if training else None))
 
 
 class _Interpolate(torch.autograd.Function):
@@ -641,6 +659,65 @@ class _WeightedSum(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gc = K.weighted_sum_dots(dy, [as_nhwc(t, dy.dtype) for t in ctx.saved_tensors[1:]])
         return (gc,) + tuple(gxs)
+
+
+class _PairMerge(torch.autograd.Function):
+    """out = coef[0] * x[:n] + coef[1] * x[n:] for the output of a module evaluated once on two inputs concatenated along the
+    batch (bn_groups): the beta mixing of a cell's from-down / from-keep results (model_search.py:331-332).  Backward writes
+    both halves of dx with one launch - no slice / zero-pad / add nodes."""
+
+    @staticmethod
+    def forward(ctx, coef, x):
+        c = coef.detach()
+        if c.dtype != torch.float32 or not c.is_contiguous():
+            c = c.float().contiguous()
+        n = x.shape[0] // 2
+        out = K.weighted_sum([x[:n], x[n:]], c)
+        ctx.save_for_backward(c, x)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        c, x = ctx.saved_tensors
+        n = x.shape[0] // 2
+        dy = as_nhwc(dy, x.dtype)
+        gx = gc = None
+        if ctx.needs_input_grad[1]:
+            gx = K.empty_nhwc(*x.shape, x.dtype, x.device)
+            K.weighted_sum_bwd(dy, c, (True, True), outs=[gx[:n], gx[n:]])
+        if ctx.needs_input_grad[0]:
+            gc = K.weighted_sum_dots(dy, [x[:n], x[n:]])
+        return gc, gx
+
+
+def pair_merge(x, coef):
+    x = as_nhwc(x)
+    assert x.shape[0] % 2 == 0 and coef.numel() == 2
+    return _PairMerge.apply(coef, x)
+
+
+class _BatchPair(torch.autograd.Function):
+    """torch.cat([a, b], dim=0) of two NHWC maps of one shape (one copy launch each); backward = the two halves of dy."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        n, c, h, w = a.shape
+        out = K.empty_nhwc(2 * n, c, h, w, a.dtype, a.device)
+        K.copy_channels(a, out[:n])
+        K.copy_channels(b, out[n:])
+        ctx.n = n
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy[:ctx.n], dy[ctx.n:]
+
+
+def batch_pair(a, b):
+    a = as_nhwc(a)
+    b = as_nhwc(b, a.dtype)
+    assert a.shape == b.shape
+    return _BatchPair.apply(a, b)
 
 
 class _MixedOpProgram(torch.autograd.Function):

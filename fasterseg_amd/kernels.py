@@ -434,6 +434,36 @@ def bn_backward(z, dy, y_out, mean, invstd, gamma, relu, dgamma_acc=None, dbeta_
     return dz, red[C:], red[:C]
 
 
+BN_COL_MAX_PIXELS = 512        # csrc/units.hip: maps up to this many pixels per group take the one-launch column-owner BatchNorm
+
+
+def bn_act_train(z, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, relu, groups=1):
+    """Train-mode BatchNorm(+ReLU) of z with `groups` independent equal parts of the batch (fs_bn_act_train_fwd):
+    returns (y, saved) with saved = [groups][mean | invstd | scale | shift]."""
+    z_cs = require_nhwc(z, "z")
+    C = z.shape[1]
+    y = empty_nhwc(z.shape[0], C, z.shape[2], z.shape[3], z.dtype, z.device)
+    saved = torch.empty(groups * 4 * C, dtype=torch.float32, device=z.device)
+    pixels = _pix(z)
+    stats = zeros_f32(groups * 2 * C, z.device) if pixels // groups > BN_COL_MAX_PIXELS else None
+    call("fs_bn_act_train_fwd", _stream(), pixels, C, groups, _p(z), z_cs, _p(gamma), _p(beta), float(eps), float(momentum),
+         _p(running_mean), _p(running_var), _p(num_batches_tracked), _p(stats), _p(saved), _p(y), channel_stride(y),
+         dtype_code(z.dtype), int(relu))
+    return y, saved
+
+
+def bn_act_train_bwd(z, dy, y_out, saved, gamma, relu, groups=1, dgamma_acc=None, dbeta_acc=None):
+    """(dz, dgamma, dbeta) of bn_act_train; dgamma/dbeta are summed over the groups."""
+    z_cs, dy_cs = require_nhwc(z, "z"), require_nhwc(dy, "dy")
+    C = z.shape[1]
+    y_cs = require_nhwc(y_out, "y_out") if relu else 0
+    red = zeros_f32((groups + 1 if groups > 1 else 1) * 2 * C, z.device)
+    dz = empty_nhwc(z.shape[0], C, z.shape[2], z.shape[3], z.dtype, z.device)
+    call("fs_bn_act_train_bwd", _stream(), _pix(z), C, groups, _p(z), z_cs, _p(dy), dy_cs, _p(y_out) if relu else None, y_cs,
+         _p(saved), _p(gamma), _p(red), dtype_code(z.dtype), int(relu), _p(dz), channel_stride(dz), _p(dgamma_acc), _p(dbeta_acc))
+    return dz, red[C:2 * C], red[:C]
+
+
 def copy_channels(x, out):
     call("fs_copy_channels", _stream(), _pix(x), x.shape[1], _p(x), require_nhwc(x, "x"), _p(out), require_nhwc(out, "out"),
          dtype_code(x.dtype))
@@ -474,10 +504,11 @@ def weighted_sum(xs, coef, out=None):
     return out
 
 
-def weighted_sum_bwd(dy, coef, need):
-    """[coef[k] * dy if need[k] else None for k]."""
+def weighted_sum_bwd(dy, coef, need, outs=None):
+    """[coef[k] * dy if need[k] else None for k] (written into `outs` when given)."""
     dy_cs = require_nhwc(dy, "dy")
-    outs = [empty_nhwc(*dy.shape, dy.dtype, dy.device) if nd else None for nd in need]
+    if outs is None:
+        outs = [empty_nhwc(*dy.shape, dy.dtype, dy.device) if nd else None for nd in need]
     n, ptrs, strides = _operand_arrays(outs)
     call("fs_weighted_sum_bwd", _stream(), _pix(dy), dy.shape[1], n, dy.data_ptr(), dy_cs, coef.data_ptr(), ptrs, strides,
          dtype_code(dy.dtype))

@@ -111,11 +111,25 @@ def layer_lanes(stream):
     return pool
 
 
+# A cell that is fed both from the scale above (down) and from its own scale (keep) is evaluated ONCE on the two inputs
+# concatenated along the batch, its BatchNorms normalising the two halves independently (functional.bn_groups): the arithmetic
+# of the reference's two evaluations (model_search.py:322-329) at half the launches - the supernet step is launch-bound.
+# FS_PAIR_BATCH=0 evaluates the two inputs one after the other.
+_PAIR_BATCH = bool(int(os.environ.get("FS_PAIR_BATCH", "1")))
+
+
+def _eval(op, x, alpha, ratios, groups):
+    if groups == 1:
+        return op(x, alpha, ratios)
+    with FN.bn_groups(groups):
+        return op(x, alpha, ratios)
+
+
 def _run_tasks(tasks):
-    """tasks: [(mixed_op, x, alpha, ratios)] -> outputs.  While capturing, every primitive of every task runs on its own
+    """tasks: [(mixed_op, x, alpha, ratios, bn_groups)] -> outputs.  While capturing, every primitive of every task runs on its own
     stream; the alpha-weighted sums follow on the capturing stream after the join."""
     if not (_LAYER_LANES > 1 and len(tasks) > 1 and tasks[0][1].is_cuda and torch.cuda.is_current_stream_capturing()):
-        return [op(x, alpha, ratios) for op, x, alpha, ratios in tasks]
+        return [_eval(op, x, alpha, ratios, g) for op, x, alpha, ratios, g in tasks]
     main = torch.cuda.current_stream()
     pool = layer_lanes(main)
     used, slot, pending = [], 0, []
@@ -126,12 +140,13 @@ def _run_tasks(tasks):
             lane.wait_stream(main)                         # fork: the previous layer's outputs are complete on `main`
             used.append(lane)
         return lane
-    for op, x, alpha, ratios in tasks:
+    for op, x, alpha, ratios, groups in tasks:
         widths = [None, None]
         coef = op._coefficients(x, alpha, ratios, widths)  # also selects the widths of the five primitives
         prog = None
         if _PROGRAMS and _CAPTURE_PROGRAMS and op.training and torch.is_grad_enabled():
-            prog = op._program(FN.as_nhwc(x), coef, widths[0], widths[1])
+            with FN.bn_groups(groups):
+                prog = op._program(FN.as_nhwc(x), coef, widths[0], widths[1])
         if prog is not None:          # the whole MixedOp (five primitives, their sum, and in backward the sum of the five input
             with torch.cuda.stream(lane_for(slot)):        # gradients) as one launch program on one lane
                 pending.append((FN.mixed_op_program(FN.as_nhwc(x), coef, prog), None))
@@ -139,7 +154,7 @@ def _run_tasks(tasks):
             continue
         outs = []
         for prim in op._ops:
-            with torch.cuda.stream(lane_for(slot)):
+            with torch.cuda.stream(lane_for(slot)), FN.bn_groups(groups):
                 outs.append(prim(x))
             slot += 1
         pending.append((outs, coef))
@@ -224,13 +239,14 @@ class MixedOp(nn.Module):
         need_x, need_coef = x.requires_grad, coef.requires_grad
         if not (need_x or need_coef):
             return None
-        key = (ratio0, ratio1, tuple(x.shape), x.stride(3), x.dtype, need_x, need_coef, want_w, id(sink))
+        groups = FN._bn_groups
+        key = (ratio0, ratio1, tuple(x.shape), x.stride(3), x.dtype, need_x, need_coef, want_w, id(sink), groups)
         cache = self.__dict__.setdefault("_programs", {})
         prog = cache.get(key)
         if prog is None or not prog.valid():
             from . import program
             prog = cache[key] = program.lower_mixed_op(self, tuple(x.shape), x.stride(3), x.dtype, x.device, need_x, need_coef,
-                                                       want_w, sink)
+                                                       want_w, sink, groups)
         return prog
 
     def forward_latency(self, size, weights, ratios):
@@ -446,11 +462,14 @@ class Network_Multi_Path(nn.Module):
                     srcs = [(0, out_prev[j - 1][1])] if beta_pos[j][i - j - 1][0] else []
                     if beta_pos[j][i - j - 1][1]:
                         srcs.append((1, out_prev[j][0]))
+                groups = 1
+                if len(srcs) == 2 and _PAIR_BATCH and self.training and srcs[0][1].is_cuda:
+                    srcs, groups = [(2, FN.batch_pair(srcs[0][1], srcs[1][1]))], 2          # tag 2: both inputs in one batch
                 for tag, x in srcs:
-                    tasks.append((cell._op, x, alpha, (ratio[0], ratio[1])))
+                    tasks.append((cell._op, x, alpha, (ratio[0], ratio[1]), groups))
                     slots.append((j, tag, 0))
                     if cell._down:
-                        tasks.append((cell.downsample, x, alpha, (ratio[0], ratio[2])))
+                        tasks.append((cell.downsample, x, alpha, (ratio[0], ratio[2]), groups))
                         slots.append((j, tag, 1))
             res = dict(zip(slots, _run_tasks(tasks)))
             out = []
@@ -461,8 +480,11 @@ class Network_Multi_Path(nn.Module):
                     out.append((res[(j, 0, 0)], res.get((j, 0, 1))))
                 else:
                     b = betas[j][i - j - 1]
-                    out.append((_weighted_sum(b, [res.get((j, 0, 0)), res.get((j, 1, 0))]),
-                                _weighted_sum(b, [res.get((j, 0, 1)), res.get((j, 1, 1))])))
+                    if (j, 2, 0) in res:
+                        out.append((FN.pair_merge(res[(j, 2, 0)], b), FN.pair_merge(res[(j, 2, 1)], b) if (j, 2, 1) in res else 0))
+                    else:
+                        out.append((_weighted_sum(b, [res.get((j, 0, 0)), res.get((j, 1, 0))]),
+                                    _weighted_sum(b, [res.get((j, 0, 1)), res.get((j, 1, 1))])))
             out_prev = out
         ###################################
         up2 = lambda t: FN.interpolate(t, scale_factor=2)

@@ -343,10 +343,11 @@ class FactorizedReduce(nn.Module):
                 assert (half, cin) == (half2, cin2)
             else:
                 half, cin = self.conv1.out_channels, self.conv1.in_channels
-            b, use_batch = _bn_args(self.bn)
+            b, use_batch = _bn_args(self.bn, bump=False)
+            nbt = b.num_batches_tracked if (b.training and b.track_running_stats) else None
             assert b.num_features == 2 * half, "running_mean should contain %d elements not %d" % (2 * half, b.num_features)
             return FN.factorized_reduce(x, self.conv1.weight, self.conv2.weight, b.weight, b.bias, b.running_mean,
-                                        b.running_var, use_batch, 0.1 if b.momentum is None else b.momentum, b.eps, half, cin)
+                                        b.running_var, use_batch, 0.1 if b.momentum is None else b.momentum, b.eps, half, cin, nbt)
         if self.slimmable:
             return conv_bn(FN.as_nhwc(x), self.conv1, self.bn, relu=True)
         return x

@@ -33,7 +33,8 @@ _ALIGN = 256
 
 (OP_MEMSET, OP_PACK_WEIGHT, OP_CONV_FWD, OP_UNIT_FWD, OP_UNIT_BWD, OP_WGRAD_STRIDED, OP_CHANNEL_STATS, OP_BN_FINALIZE,
  OP_AFFINE_ACT, OP_BN_BWD_REDUCE, OP_BN_BWD_APPLY, OP_BILINEAR_FWD, OP_BILINEAR_BWD, OP_WSUM, OP_WSUM_BWD, OP_WSUM_DOTS,
- OP_AXPY, OP_CONV3X3_S1, OP_STEM, OP_COPY_CHANNELS, OP_EVENT_RECORD, OP_EVENT_WAIT, OP_ZOOM_CELL, OP_BILINEAR_ARGMAX) = range(24)      # enum in include/fasterseg_hip.h
+ OP_AXPY, OP_CONV3X3_S1, OP_STEM, OP_COPY_CHANNELS, OP_EVENT_RECORD, OP_EVENT_WAIT, OP_ZOOM_CELL, OP_BILINEAR_ARGMAX,
+ OP_BN_UNIT_FWD, OP_BN_UNIT_BWD) = range(26)      # enum in include/fasterseg_hip.h
 
 
 class Ref:
@@ -162,8 +163,9 @@ class MixedOpProgram:
 # lowering
 # ---------------------------------------------------------------------------------------------------
 class _Lowering:
-    def __init__(self, dtype, want_w, sink):
+    def __init__(self, dtype, want_w, sink, groups=1):
         self.f, self.b = _List(), _List()
+        self.groups = groups                  # BatchNorm groups: the batch is this many independently normalised inputs
         self.dtype = dtype
         self.dt = K.dtype_code(dtype)
         self.esize = 4 if dtype == torch.float32 else 2
@@ -216,10 +218,11 @@ class _Lowering:
         stride, pad = conv.stride[0], conv.padding[0]
         Ho, Wo = (x.H + 2 * pad - R) // stride + 1, (x.W + 2 * pad - S) // stride + 1
         wp, w_os, w_ts = self.filter(f, TMPF, w, cout, cin, False)
+        G = self.groups
         desc = ConvDesc(x.N, x.H, x.W, cin, cout, R, S, stride, pad, Ho, Wo, x.cs, cout, self.dt, K.FS_CONV_RELU if relu else 0,
-                        w_os, w_ts)
-        stats = f.alloc(TMPF, 2 * cout * 4, zero=True)
-        saved = f.alloc(SAVE, 4 * cout * 4)
+                        w_os, w_ts, 0, 0, 0, G)
+        stats = f.alloc(TMPF, G * 2 * cout * 4, zero=True)
+        saved = f.alloc(SAVE, G * 4 * cout * 4)
         z = self.new(f, SAVE, x.N, cout, Ho, Wo)
         y = self.new(f, SAVE, x.N, cout, Ho, Wo)
         momentum = 0.1 if b.momentum is None else float(b.momentum)
@@ -229,7 +232,7 @@ class _Lowering:
 
         def backward(dy, need_x):
             bl = self.b
-            red = bl.alloc(TMPB, 2 * cout * 4, zero=True)
+            red = bl.alloc(TMPB, (G + 1 if G > 1 else 1) * 2 * cout * 4, zero=True)
             dz = self.new(bl, TMPB, x.N, cout, Ho, Wo)
             wf, wf_os, wf_ts, dx = None, 0, 0, None
             if need_x:
@@ -285,23 +288,21 @@ class _Lowering:
             d = ConvDesc(x.N, x.H, x.W, cin, half, 1, 1, 2, pad, Ho, Wo, x.cs, C2, self.dt, 0, w_os, w_ts)
             descs.append(d)
             f.emit(OP_CONV_FWD, _Desc(d), x.ref, wp, NULL, NULL, z.ref + k * half * self.esize, NULL, Ref(WS, 0), K.WORKSPACE_BYTES)
-        stats = f.alloc(TMPF, 2 * C2 * 4, zero=True)
-        saved = f.alloc(SAVE, 4 * C2 * 4)
+        G = self.groups
+        stats = f.alloc(TMPF, G * 2 * C2 * 4, zero=True)
+        saved = f.alloc(SAVE, G * 4 * C2 * 4)
         momentum = 0.1 if b.momentum is None else float(b.momentum)
-        f.emit(OP_CHANNEL_STATS, z.pixels, C2, z.ref, z.cs, self.dt, stats)
-        f.emit(OP_BN_FINALIZE, C2, z.pixels, stats, self.param(b.weight), self.param(b.bias), float(b.eps), momentum,
-               self.param(b.running_mean), self.param(b.running_var), saved, saved + 4 * C2, saved + 8 * C2, saved + 12 * C2,
-               self.param(b.num_batches_tracked))
-        f.emit(OP_AFFINE_ACT, z.pixels, C2, z.ref, z.cs, saved + 8 * C2, saved + 12 * C2, y.ref, y.cs, self.dt, 1)
+        f.emit(OP_BN_UNIT_FWD, z.pixels, C2, G, z.ref, z.cs, self.param(b.weight), self.param(b.bias), float(b.eps), momentum,
+               self.param(b.running_mean), self.param(b.running_var), self.param(b.num_batches_tracked), stats, saved, y.ref, y.cs,
+               self.dt, 1)
 
         def backward(dy, need_x):
             bl = self.b
-            red = bl.alloc(TMPB, 2 * C2 * 4, zero=True)
+            red = bl.alloc(TMPB, (G + 1 if G > 1 else 1) * 2 * C2 * 4, zero=True)
             dz = self.new(bl, TMPB, x.N, C2, Ho, Wo)
             acc = (absolute(self.grad_slot(b.weight)), absolute(self.grad_slot(b.bias))) if self.want_w else (NULL, NULL)
-            bl.emit(OP_BN_BWD_REDUCE, z.pixels, C2, z.ref, z.cs, dy.ref, dy.cs, y.ref, y.cs, saved, saved + 4 * C2, self.dt, 1, red)
-            bl.emit(OP_BN_BWD_APPLY, z.pixels, C2, z.ref, z.cs, dy.ref, dy.cs, y.ref, y.cs, saved, saved + 4 * C2,
-                    absolute(b.weight), red, z.pixels, self.dt, 1, dz.ref, dz.cs, acc[0], acc[1])
+            bl.emit(OP_BN_UNIT_BWD, z.pixels, C2, G, z.ref, z.cs, dy.ref, dy.cs, y.ref, y.cs, saved, absolute(b.weight), red,
+                    self.dt, 1, dz.ref, dz.cs, acc[0], acc[1])
             dx = None
             for k, conv in enumerate((op.conv1, op.conv2)):
                 w = conv.weight
@@ -369,10 +370,12 @@ def _ones(device):
     return _one_vectors[key]
 
 
-def lower_mixed_op(mixed, x_shape, x_cs, dtype, device, need_x, need_coef, want_w, sink):
-    """Programs for `mixed` (ratios already set through set_prun_ratio) on an (N, C, H, W) NHWC input with channel stride x_cs."""
+def lower_mixed_op(mixed, x_shape, x_cs, dtype, device, need_x, need_coef, want_w, sink, groups=1):
+    """Programs for `mixed` (ratios already set through set_prun_ratio) on an (N, C, H, W) NHWC input with channel stride x_cs;
+    `groups` > 1: the batch is that many inputs the BatchNorms normalise independently (functional.bn_groups)."""
     N, C, H, W = x_shape
-    lo = _Lowering(dtype, want_w, sink)
+    assert N % groups == 0
+    lo = _Lowering(dtype, want_w, sink, groups)
     x = Buf(Ref(X, 0), N, C, H, W, x_cs, lo.esize)
     outs, backs = [], []
     for op in mixed._ops:

@@ -218,22 +218,50 @@ fs_status fs_bn_bwd_apply(void* stream, long long pixels, int C, const void* x, 
                           const void* y_out, int y_cs, const float* mean, const float* invstd, const float* gamma,
                           const float* red, long long count, int dtype, int relu, void* dx, int dx_cs,
                           float* dgamma_acc, float* dbeta_acc);
+/* Grouped forms of the grid-wide BatchNorm passes for LARGE maps (fs_conv_desc.bn_groups; fs_bn_group_fwd/bwd serve the small
+ * ones): `groups` equal consecutive pixel ranges with their own statistics.  stats: [groups][2][C] zeroed floats;
+ * mean/invstd: pointers into the first group's block of `saved` with saved_stride floats between groups (4*C for the
+ * [groups][4][C] layout); red: [groups][2][C] zeroed partials; count = pixels per group; red_total (nullable) receives the
+ * sum of the partials over the groups ([2][C]: dbeta, dgamma). */
+fs_status fs_channel_stats_g(void* stream, long long pixels, int C, int groups, const void* x, int x_cs, int dtype, float* stats);
+fs_status fs_bn_train_apply_g(void* stream, long long pixels, int C, int groups, const void* x, int x_cs, const float* stats,
+                              const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                              float* running_var, long long* num_batches_tracked, float* saved, void* y, int y_cs, int dtype,
+                              int relu);
+fs_status fs_bn_bwd_reduce_g(void* stream, long long pixels, int C, int groups, const void* x, int x_cs, const void* dy, int dy_cs,
+                             const void* y_out, int y_cs, const float* mean, const float* invstd, int saved_stride, int dtype,
+                             int relu, float* red);
+fs_status fs_bn_bwd_apply_g(void* stream, long long pixels, int C, int groups, const void* x, int x_cs, const void* dy, int dy_cs,
+                            const void* y_out, int y_cs, const float* mean, const float* invstd, int saved_stride,
+                            const float* gamma, const float* red, long long count, int dtype, int relu, void* dx, int dx_cs,
+                            float* red_total, float* dgamma_acc, float* dbeta_acc);
 
 /* --- train-mode fused units ------------------------------------------------------------------------ */
 /* One reference module = one host call (the supernet runs thousands of these per step on tiny maps, so the per-launch
  * host cost matters more than the kernels).
+ * fs_bn_act_train_fwd / _bwd: train-mode BatchNorm(+ReLU) of an existing map z (FactorizedReduce's BN over its two 1x1
+ *   stride-2 convs, search/operations.py:521-526), one launch for maps of <= 512 pixels per group (fs_bn_group_*), the two
+ *   grid-wide passes otherwise; buffers as for the conv units below (stats G*2*C zeroed, saved G*4*C, red (G+1)*2*C zeroed
+ *   when G > 1 else 2*C; G = groups).
  * fs_conv_bn_act_train_fwd: conv -> BatchNorm(batch statistics) -> [ReLU if d->flags & FS_CONV_RELU]
  *   (ConvNorm, search/operations.py:42-128; the conv+bn(+relu) pairs of BasicResidual*, :131-262).
- *   z (raw conv output) and y (normalised output) are NHWC buffers with channel stride d->y_cs; `stats` is 2*Cout zeroed
- *   floats of scratch; `saved` receives 4*Cout floats: mean, invstd, scale, shift (mean/invstd are needed by the
- *   backward).  Running statistics and num_batches_tracked (both may be null) are updated as by nn.BatchNorm2d.
+ *   z (raw conv output) and y (normalised output) are NHWC buffers with channel stride d->y_cs; `stats` is G*2*Cout zeroed
+ *   floats of scratch and `saved` receives G*4*Cout floats: mean, invstd, scale, shift per group (mean/invstd are needed by
+ *   the backward), G = max(1, d->bn_groups).  Running statistics and num_batches_tracked (both may be null) are updated as by nn.BatchNorm2d.
  *   `workspace` (nullable, see fs_conv2d_fwd_ws) lets the convs of both directions split K across blocks. */
+fs_status fs_bn_act_train_fwd(void* stream, long long pixels, int C, int groups, void* z, int z_cs, const float* gamma,
+                              const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                              long long* num_batches_tracked, float* stats, float* saved, void* y, int y_cs, int dtype, int relu);
+fs_status fs_bn_act_train_bwd(void* stream, long long pixels, int C, int groups, const void* z, int z_cs, const void* dy, int dy_cs,
+                              const void* y, int y_cs, const float* saved, const float* gamma, float* red, int dtype, int relu,
+                              void* dz, int dz_cs, float* dgamma_acc, float* dbeta_acc);
 fs_status fs_conv_bn_act_train_fwd(void* stream, const fs_conv_desc* d, const void* x, const void* w_packed,
                                    const float* gamma, const float* beta, float* running_mean, float* running_var,
                                    long long* num_batches_tracked, float eps, float momentum, float* stats, float* saved,
                                    void* z, void* y, void* workspace, long long workspace_bytes);
 /* Backward of the same unit (replaces the autograd of F.conv2d + F.batch_norm + relu): given dy (channel stride dy_cs)
- *   red[0..C) = dbeta, red[C..2C) = dgamma (red must be zeroed), optionally accumulated into dgamma_acc/dbeta_acc;
+ *   red[0..C) = dbeta, red[C..2C) = dgamma (red must be zeroed; with d->bn_groups = G > 1 it is (G+1)*2*C floats, the
+ *   per-group partials following the totals), optionally accumulated into dgamma_acc/dbeta_acc;
  *   dz (dense NHWC, channel stride Cout) = gradient w.r.t. the conv output;
  *   dw != null: weight gradient accumulated into a strided fp32 tensor (see fs_conv2d_wgrad_strided), needs x;
  *   dx != null: data gradient (N,H,W,Cin) with channel stride dx_cs, needs w_flip = fs_pack_weight(flip=1), dense
@@ -401,6 +429,8 @@ enum {
     FS_OP_EVENT_WAIT,        /* (event)  make the command's stream wait for the event                     */
     FS_OP_ZOOM_CELL,         /* fs_zoom_cell_fwd */
     FS_OP_BILINEAR_ARGMAX,   /* fs_bilinear_argmax */
+    FS_OP_BN_UNIT_FWD,       /* fs_bn_act_train_fwd */
+    FS_OP_BN_UNIT_BWD,       /* fs_bn_act_train_bwd */
     FS_OP_COUNT
 };
 fs_status fs_exec_program(void* stream, const long long* words, long long n_words, const unsigned char* blob,

@@ -24,7 +24,7 @@ CASES = [
 ]
 
 
-def _run(case, dtype, splits=0, seed=0):
+def _run(case, dtype, splits=0, seed=0, unit=False):
     from fasterseg_amd import kernels as K
     from fasterseg_amd._lib import call
     N, C, H, W, G, relu = case
@@ -48,15 +48,28 @@ def _run(case, dtype, splits=0, seed=0):
     rm_d, rv_d = rm.to(dev), rv.to(dev)
     nbt = torch.zeros((), dtype=torch.int64, device=dev)
     gd, bd = gamma.to(dev), beta.to(dev)
-    call("fs_bn_group_fwd", K._stream(), pixels, C, G, K._p(z), K.channel_stride(z), K._p(partials), splits, K._p(gd), K._p(bd), 1e-5, 0.1,
-         K._p(rm_d), K._p(rv_d), K._p(nbt), K._p(saved), K._p(y), K.channel_stride(y), K.dtype_code(dtype), relu)
+    if unit:          # fs_bn_act_train_fwd: chooses the one-launch kernel or the grouped grid-wide passes by the map size
+        stats = torch.zeros(G * 2 * C, dtype=torch.float32, device=dev)
+        call("fs_bn_act_train_fwd", K._stream(), pixels, C, G, K._p(z), K.channel_stride(z), K._p(gd), K._p(bd), 1e-5, 0.1,
+             K._p(rm_d), K._p(rv_d), K._p(nbt), K._p(stats), K._p(saved), K._p(y), K.channel_stride(y), K.dtype_code(dtype), relu)
+    else:
+        call("fs_bn_group_fwd", K._stream(), pixels, C, G, K._p(z), K.channel_stride(z), K._p(partials), splits, K._p(gd), K._p(bd), 1e-5, 0.1,
+             K._p(rm_d), K._p(rv_d), K._p(nbt), K._p(saved), K._p(y), K.channel_stride(y), K.dtype_code(dtype), relu)
     dyg = K.to_nhwc(dy.to(dev), dtype)
     dz = K.empty_nhwc(N, C, H, W, dtype, dev)
     red = torch.empty(2 * C, dtype=torch.float32, device=dev)
     dgacc, dbacc = torch.full((C,), 2.0, device=dev), torch.full((C,), -1.0, device=dev)
-    call("fs_bn_group_bwd", K._stream(), pixels, C, G, K._p(z), K.channel_stride(z), K._p(dyg), K.channel_stride(dyg), K._p(y), K.channel_stride(y),
-         K._p(saved), K._p(gd), K.dtype_code(dtype), relu, K._p(dz), K.channel_stride(dz), K._p(red), K._p(dgacc), K._p(dbacc))
+    if unit:
+        red = torch.zeros((G + 1 if G > 1 else 1) * 2 * C, dtype=torch.float32, device=dev)
+        call("fs_bn_act_train_bwd", K._stream(), pixels, C, G, K._p(z), K.channel_stride(z), K._p(dyg), K.channel_stride(dyg), K._p(y),
+             K.channel_stride(y), K._p(saved), K._p(gd), K._p(red), K.dtype_code(dtype), relu, K._p(dz), K.channel_stride(dz), K._p(dgacc),
+             K._p(dbacc))
+    else:
+        call("fs_bn_group_bwd", K._stream(), pixels, C, G, K._p(z), K.channel_stride(z), K._p(dyg), K.channel_stride(dyg), K._p(y),
+             K.channel_stride(y), K._p(saved), K._p(gd), K.dtype_code(dtype), relu, K._p(dz), K.channel_stride(dz), K._p(red), K._p(dgacc),
+             K._p(dbacc))
     torch.cuda.synchronize()
+    red = red[:2 * C]
     got = dict(y=y.float().cpu(), z=z.float().cpu(), dz=dz.float().cpu(), red=red.cpu(), saved=saved.cpu().view(G, 4, C), rm=rm_d.cpu(),
                rv=rv_d.cpu(), nbt=int(nbt), dgacc=dgacc.cpu(), dbacc=dbacc.cpu())
     # ---- reference, group after group
@@ -100,6 +113,35 @@ def test_bn_group_matches_torch_per_group(case, dtype):
     _close(got["saved"][:, 1], want["invstd"], torch.float32, "saved invstd", scale=float(want["invstd"].abs().max()))
     _close(got["rm"], want["rm"], torch.float32, "running_mean after %d sequential updates" % G)
     _close(got["rv"], want["rv"], torch.float32, "running_var")
+    assert got["nbt"] == G
+
+
+UNIT_CASES = [
+    (6, 64, 16, 32, 2, 1),        # 1536 px per group: the grid-wide grouped passes (blockIdx.y = group)
+    (4, 96, 32, 64, 2, 1),        # 4096 px per group
+    (6, 40, 24, 40, 3, 0),
+    (2, 128, 32, 64, 1, 1),       # one group, grid-wide
+    (4, 64, 8, 16, 2, 1),         # 256 px per group: routed to the one-launch kernel
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("case", UNIT_CASES, ids=["%dx%dx%dx%d-g%d-r%d" % c for c in UNIT_CASES])
+def test_bn_unit_matches_torch_per_group(case, dtype):
+    """fs_bn_act_train_fwd / _bwd across the size threshold (atomics in the grid-wide passes: fp32 bar 1e-4-level)."""
+    got, want, x = _run(case, dtype, unit=True)
+    N, C, H, W, G, relu = case
+    t32 = torch.float32
+    _close(got["y"], want["y"], dtype, "y")
+    _close(got["dz"], want["dz"], dtype, "dz")
+    _close(got["red"][C:], want["dgamma"], dtype, "dgamma", scale=5 * float(want["dgamma"].abs().max()))
+    _close(got["red"][:C], want["dbeta"], dtype, "dbeta", scale=5 * float(want["dbeta"].abs().max()))
+    _close(got["dgacc"] - 2.0, want["dgamma"], dtype, "dgamma accumulated", scale=5 * float(want["dgamma"].abs().max()))
+    _close(got["dbacc"] + 1.0, want["dbeta"], dtype, "dbeta accumulated", scale=5 * float(want["dbeta"].abs().max()))
+    _close(got["saved"][:, 0], want["mean"], t32, "saved mean", scale=5.0)
+    _close(got["saved"][:, 1], want["invstd"], t32, "saved invstd", scale=5 * float(want["invstd"].abs().max()))
+    _close(got["rm"], want["rm"], t32, "running_mean after %d sequential updates" % G, scale=5.0)
+    _close(got["rv"], want["rv"], t32, "running_var", scale=5.0)
     assert got["nbt"] == G
 
 

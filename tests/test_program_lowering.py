@@ -11,7 +11,8 @@ from fasterseg_amd.parallel import FlatGradientSync
 NARGS = {program.OP_MEMSET: 2, program.OP_PACK_WEIGHT: 10, program.OP_CONV_FWD: 9, program.OP_UNIT_FWD: 16, program.OP_UNIT_BWD: 23,
          program.OP_WGRAD_STRIDED: 7, program.OP_CHANNEL_STATS: 6, program.OP_BN_FINALIZE: 14, program.OP_AFFINE_ACT: 10,
          program.OP_BN_BWD_REDUCE: 13, program.OP_BN_BWD_APPLY: 19, program.OP_BILINEAR_FWD: 3, program.OP_BILINEAR_BWD: 4,
-         program.OP_WSUM: 9, program.OP_WSUM_BWD: 9, program.OP_WSUM_DOTS: 9, program.OP_AXPY: 9}
+         program.OP_WSUM: 9, program.OP_WSUM_BWD: 9, program.OP_WSUM_DOTS: 9, program.OP_AXPY: 9, program.OP_BN_UNIT_FWD: 18,
+         program.OP_BN_UNIT_BWD: 18}
 WIDTHS = [4. / 12, 6. / 12, 8. / 12, 10. / 12, 1.]
 
 
@@ -76,6 +77,7 @@ def test_mixed_op_lowering_structure(stride, want_w):
     assert f_ops.count(program.OP_UNIT_FWD) == units and b_ops.count(program.OP_UNIT_BWD) == units
     assert f_ops.count(program.OP_BILINEAR_FWD) == (4 if stride == 1 else 2)
     assert f_ops.count(program.OP_CONV_FWD) == (0 if stride == 1 else 2)
+    assert f_ops.count(program.OP_BN_UNIT_FWD) == b_ops.count(program.OP_BN_UNIT_BWD) == (0 if stride == 1 else 1)
     assert b_ops.count(program.OP_WSUM_BWD) == 1 and b_ops[-1] == program.OP_WSUM
     assert (program.OP_WSUM_DOTS in b_ops) == (not want_w)
     if want_w:

@@ -167,6 +167,88 @@ def test_mixed_op_program_matches_module_path(stride, phase, dtype):
         assert rel < tol, (k, rel)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("use_program", [False, True], ids=["modules", "program"])
+@pytest.mark.parametrize("geom", [(1, 16, 24), (2, 16, 24), (1, 32, 48)], ids=["s1-small", "s2-small", "s1-large"])
+def test_mixed_op_on_batched_pair_equals_two_evaluations(geom, use_program, dtype):
+    """One evaluation of a MixedOp on two inputs concatenated along the batch with functional.bn_groups(2) against the
+    reference's two evaluations one after the other (model_search.py:322-329): both outputs, both input gradients, d alpha,
+    all parameter gradients (sum of the two) and the BN running statistics / counters after the two sequential updates.
+    The large geometry (768 px per group at full size, 192 after stride 2 / zoom) exercises the grid-wide grouped BN passes."""
+    import copy
+    from fasterseg_amd import functional as FN
+    from fasterseg_amd import kernels as K
+    from fasterseg_amd import model_search
+    from fasterseg_amd.parallel import FlatGradientSync
+    stride, H, W = geom
+    torch.manual_seed(5)
+    m = model_search.MixedOp(48, 48 * stride, stride=stride, width_mult_list=WIDTHS).cuda().train()
+    for p in m.parameters():
+        if p.dim() == 1:
+            p.data.uniform_(0.5, 1.5)
+    state0 = copy.deepcopy(m.state_dict())
+    sync = FlatGradientSync(m.parameters())
+    n = 1 if H > 16 else 2
+    xa = K.to_nhwc(torch.randn(n, 32, H, W, device="cuda"), dtype)
+    xb = K.to_nhwc(torch.randn(n, 32, H, W, device="cuda") * 2.0 + 0.5, dtype)          # different statistics per input
+    coef0 = torch.softmax(torch.randn(5, device="cuda"), 0)
+    dya = K.to_nhwc(torch.randn(n, 40 * stride, H // stride, W // stride, device="cuda"), dtype)
+    dyb = K.to_nhwc(torch.randn(n, 40 * stride, H // stride, W // stride, device="cuda"), dtype)
+    saved_flag = model_search._PROGRAMS
+    got = []
+    try:
+        model_search._PROGRAMS = use_program
+        for batched in (False, True):
+            m.load_state_dict(state0)
+            sync.prepare(passes=2)
+            a, b = xa.clone().requires_grad_(True), xb.clone().requires_grad_(True)
+            coef = coef0.clone().requires_grad_(True)
+            if batched:
+                with FN.bn_groups(2):
+                    out = m(FN.batch_pair(a, b), coef, (8. / 12, 10. / 12))
+                assert (type(out.grad_fn).__name__ == "_MixedOpProgramBackward") == use_program
+                out.backward(torch.cat([dya, dyb], 0))
+                oa, ob = out[:n], out[n:]
+            else:
+                oa = m(a, coef, (8. / 12, 10. / 12))
+                ob = m(b, coef, (8. / 12, 10. / 12))
+                torch.autograd.backward([oa, ob], [dya, dyb])
+            sync.sync()
+            got.append({"oa": oa.detach().float().clone(), "ob": ob.detach().float().clone(), "da": a.grad.float().clone(),
+                        "db": b.grad.float().clone(), "dcoef": coef.grad.clone(), "flat": sync.flat.clone(),
+                        "touched": list(sync._touched),
+                        "running": torch.cat([t.float().reshape(-1) for _, t in m.named_buffers()])})
+    finally:
+        model_search._PROGRAMS = saved_flag
+    ref, new = got
+    tol = 2e-4 if dtype == torch.float32 else 3e-2
+    for k in ref:
+        if k == "touched":
+            assert ref[k] == new[k]
+            continue
+        rel = float((ref[k] - new[k]).norm() / (ref[k].norm() + 1e-12))
+        assert rel < tol, (k, rel)
+
+
+def test_supernet_pair_batching_equals_sequential_evaluation():
+    """Eager pretrain steps with every doubly-fed cell evaluated once on the batched pair (FS_PAIR_BATCH, default) vs the two
+    evaluations one after the other."""
+    from fasterseg_amd import model_search
+    saved_flag = model_search._PAIR_BATCH
+    try:
+        model_search._PAIR_BATCH = False
+        ref_losses, ref_w = _run(False)
+        model_search._PAIR_BATCH = True
+        new_losses, new_w = _run(False)
+    finally:
+        model_search._PAIR_BATCH = saved_flag
+    for a, b in zip(ref_losses, new_losses):
+        assert abs(a - b) <= 5e-3 * abs(a), (ref_losses, new_losses)
+    for k in ref_w:
+        rel = float((ref_w[k] - new_w[k]).norm() / (ref_w[k].norm() + 1e-12))
+        assert rel < 2e-2, (k, rel)
+
+
 def test_supernet_step_with_programs_equals_module_path():
     """Eager pretrain steps (all four passes, random widths included) with the MixedOp programs vs the per-module path."""
     from fasterseg_amd import model_search
