@@ -114,6 +114,7 @@ _SPECIAL = {
     "fs_debug_stem_mfma": ([c_int], None),
     "fs_packed_weight_frag_elems": ([c_int, c_int, c_int], c_ll),
     "fs_sgd_chunk_elems": ([], c_int),
+    "fs_sgd_tensor_chunks": ([c_ll, c_int, c_int, c_int], c_ll),
     "fs_zoom_cell_supported": ([ctypes.POINTER(ZoomDesc)], c_int),
     "fs_census_enable": ([c_int], None),
     "fs_census_read": ([c_vp, c_int], c_int),

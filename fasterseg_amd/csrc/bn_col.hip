@@ -264,6 +264,243 @@ __global__ __launch_bounds__(BNC_THREADS) void bn_group_bwd_kernel(long long pix
     }
 }
 
+// ---- register-resident variant for the smallest maps ----------------------------------------------------------------
+// Up to BNS_THREADS * BNS_UNROLL = 512 pixels per group and G = 1 or 2 groups: every lane requests ALL the 16-byte vectors it owns
+// (both groups, all operands) before the first is consumed and keeps them in registers, so the map is read ONCE - the
+// generic kernels above pay a second dependent round trip to L2 / HBM for the normalisation pass and run the groups one after
+// the other, and these launches are pure latency (24-48 blocks on a 256-CU device).  The groups' reductions share one
+// LDS exchange.  Same arithmetic and summation order per group as the generic kernels.
+constexpr int BNS_THREADS = 256;
+constexpr int BNS_UNROLL = 2;
+constexpr int BNS_WAVES = BNS_THREADS / 64;
+
+template <int N>
+__device__ __forceinline__ void block_sum_n(float (&a)[N], float* red /* [N][BNS_WAVES] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < N; ++i) a[i] = wave_sum(a[i]);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) red[i * BNS_WAVES + wave] = a[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < N; ++i) {         // fixed order: waves 0, 1, 2, 3
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < BNS_WAVES; ++w) s += red[i * BNS_WAVES + w];
+        a[i] = s;
+    }
+}
+
+template <typename T, int G>
+__global__ __launch_bounds__(BNS_THREADS) void bn_small_fwd_kernel(long long pixels, int C, T* __restrict__ z, int z_cs,
+                                                                    const float* __restrict__ partials, int splits,
+                                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                    float eps, float momentum, float* running_mean, float* running_var,
+                                                                    long long* num_batches_tracked, float* __restrict__ saved,
+                                                                    T* __restrict__ y, int y_cs, int relu) {
+    constexpr int VEC = Elem<T>::VEC;
+    __shared__ float red[G * 2 * VEC * BNS_WAVES];
+    __shared__ float affine[G * 2 * VEC];
+    const int tid = threadIdx.x;
+    const int c0 = blockIdx.x * VEC;
+    const int mg = (int)(pixels / G);
+    if (blockIdx.x == 0 && tid == 0 && num_batches_tracked) *num_batches_tracked += G;
+    u32x4 raw[G][BNS_UNROLL];
+    if (splits > 1) {                     // sum the split-K slabs of the producing conv; keep z for the backward
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int u = 0; u < BNS_UNROLL; ++u) {
+                const int m = tid + u * BNS_THREADS;
+                float v[VEC];
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) v[i] = 0.f;
+                if (m < mg) {
+                    const long long pix = (long long)g * mg + m;
+                    for (int s = 0; s < splits; ++s) {
+                        const float* src = partials + ((long long)s * pixels + pix) * C + c0;
+#pragma unroll
+                        for (int q = 0; q < VEC; q += 4) {
+                            const f32x4 t = *reinterpret_cast<const f32x4*>(src + q);
+                            v[q] += t[0]; v[q + 1] += t[1]; v[q + 2] += t[2]; v[q + 3] += t[3];
+                        }
+                    }
+                    raw[g][u] = Elem<T>::pack(v);
+                    stg16(z + pix * z_cs + c0, raw[g][u]);
+                } else {
+                    raw[g][u] = Elem<T>::pack(v);
+                }
+            }
+    } else {
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int u = 0; u < BNS_UNROLL; ++u) {
+                const int m = tid + u * BNS_THREADS;
+                raw[g][u] = ldg16(z + ((long long)g * mg + (m < mg ? m : 0)) * z_cs + c0);
+            }
+    }
+    float acc[G * 2 * VEC];               // per group: sum[VEC], sum of squares[VEC] of the STORED (rounded) map
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+#pragma unroll
+        for (int i = 0; i < 2 * VEC; ++i) acc[g * 2 * VEC + i] = 0.f;
+#pragma unroll
+        for (int u = 0; u < BNS_UNROLL; ++u) {
+            float v[VEC];
+            Elem<T>::unpack(raw[g][u], v);
+            if (tid + u * BNS_THREADS < mg) {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    acc[g * 2 * VEC + i] += v[i];
+                    acc[g * 2 * VEC + VEC + i] += v[i] * v[i];
+                }
+            }
+        }
+    }
+    block_sum_n<G * 2 * VEC>(acc, red);
+    if (tid < VEC) {
+        const int c = c0 + tid;
+        const float count = (float)mg;
+        const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+        float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 0.f;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {     // running statistics take the groups' updates in order
+            float sum1 = 0.f, sum2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i)
+                if (i == tid) { sum1 = acc[g * 2 * VEC + i]; sum2 = acc[g * 2 * VEC + VEC + i]; }
+            const float m_ = sum1 / count;
+            const float var = fmaxf(sum2 / count - m_ * m_, 0.f);
+            const float is = 1.0f / sqrtf(var + eps);
+            float* sv = saved + (long long)g * 4 * C;
+            sv[c] = m_;
+            sv[C + c] = is;
+            sv[2 * C + c] = ga * is;
+            sv[3 * C + c] = be - m_ * ga * is;
+            affine[g * 2 * VEC + tid] = ga * is;
+            affine[g * 2 * VEC + VEC + tid] = be - m_ * ga * is;
+            rm = (1.f - momentum) * rm + momentum * m_;
+            const float unbiased = count > 1.f ? var * (count / (count - 1.f)) : var;
+            rv = (1.f - momentum) * rv + momentum * unbiased;
+        }
+        if (running_mean) running_mean[c] = rm;
+        if (running_var) running_var[c] = rv;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        float sc[VEC], sh[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { sc[i] = affine[g * 2 * VEC + i]; sh[i] = affine[g * 2 * VEC + VEC + i]; }
+#pragma unroll
+        for (int u = 0; u < BNS_UNROLL; ++u) {
+            const int m = tid + u * BNS_THREADS;
+            if (m < mg) {
+                float v[VEC];
+                Elem<T>::unpack(raw[g][u], v);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    const float o = v[i] * sc[i] + sh[i];
+                    v[i] = relu ? fmaxf(o, 0.f) : o;
+                }
+                stg16(y + ((long long)g * mg + m) * y_cs + c0, Elem<T>::pack(v));
+            }
+        }
+    }
+}
+
+template <typename T, int G>
+__global__ __launch_bounds__(BNS_THREADS) void bn_small_bwd_kernel(long long pixels, int C, const T* __restrict__ z, int z_cs,
+                                                                    const T* __restrict__ dy, int dy_cs, const T* __restrict__ yo,
+                                                                    int y_cs, const float* __restrict__ saved,
+                                                                    const float* __restrict__ gamma, int relu, T* __restrict__ dz,
+                                                                    int dz_cs, float* __restrict__ red_out, float* dgamma_acc,
+                                                                    float* dbeta_acc) {
+    constexpr int VEC = Elem<T>::VEC;
+    __shared__ float red[G * 2 * VEC * BNS_WAVES];
+    const int tid = threadIdx.x;
+    const int c0 = blockIdx.x * VEC;
+    const int mg = (int)(pixels / G);
+    u32x4 rz[G][BNS_UNROLL], rg[G][BNS_UNROLL], ro[G][BNS_UNROLL];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int u = 0; u < BNS_UNROLL; ++u) {
+            const int m = tid + u * BNS_THREADS;
+            const long long mm = (long long)g * mg + (m < mg ? m : 0);
+            rz[g][u] = ldg16(z + mm * z_cs + c0);
+            rg[g][u] = ldg16(dy + mm * dy_cs + c0);
+            if (relu) ro[g][u] = ldg16(yo + mm * y_cs + c0);
+        }
+    float ga[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) ga[i] = gamma[c0 + i];
+    float acc[G * 2 * VEC];               // per group: sum g [VEC], sum g * xhat [VEC]
+    float gr[G][BNS_UNROLL][VEC], xh[G][BNS_UNROLL][VEC];
+    float is[G][VEC];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const float* sv = saved + (long long)g * 4 * C;
+        float mu[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { mu[i] = sv[c0 + i]; is[g][i] = sv[C + c0 + i]; }
+#pragma unroll
+        for (int i = 0; i < 2 * VEC; ++i) acc[g * 2 * VEC + i] = 0.f;
+#pragma unroll
+        for (int u = 0; u < BNS_UNROLL; ++u) {
+            const bool live = tid + u * BNS_THREADS < mg;
+            Elem<T>::unpack(rz[g][u], xh[g][u]);
+            Elem<T>::unpack(rg[g][u], gr[g][u]);
+            if (relu) {
+                float o[VEC];
+                Elem<T>::unpack(ro[g][u], o);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) gr[g][u][i] = o[i] > 0.f ? gr[g][u][i] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                xh[g][u][i] = (xh[g][u][i] - mu[i]) * is[g][i];
+                if (!live) gr[g][u][i] = 0.f;
+                acc[g * 2 * VEC + i] += gr[g][u][i];
+                acc[g * 2 * VEC + VEC + i] += gr[g][u][i] * xh[g][u][i];
+            }
+        }
+    }
+    block_sum_n<G * 2 * VEC>(acc, red);
+    const float inv = 1.0f / (float)mg;
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int u = 0; u < BNS_UNROLL; ++u) {
+            const int m = tid + u * BNS_THREADS;
+            if (m < mg) {
+                float o[VEC];
+#pragma unroll
+                for (int i = 0; i < VEC; ++i)
+                    o[i] = ga[i] * is[g][i] * (gr[g][u][i] - acc[g * 2 * VEC + i] * inv - xh[g][u][i] * acc[g * 2 * VEC + VEC + i] * inv);
+                stg16(dz + ((long long)g * mg + m) * dz_cs + c0, Elem<T>::pack(o));
+            }
+        }
+    if (tid < VEC) {                      // parameter gradients of this channel vector: summed over the groups in order, one writer
+        const int c = c0 + tid;
+        float b = 0.f, gsum = 0.f;
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int i = 0; i < VEC; ++i)
+                if (i == tid) { b += acc[g * 2 * VEC + i]; gsum += acc[g * 2 * VEC + VEC + i]; }
+        red_out[c] = b;
+        red_out[C + c] = gsum;
+        if (dgamma_acc) {
+            dgamma_acc[c] += gsum;
+            dbeta_acc[c] += b;
+        }
+    }
+}
+
 }  // namespace fs
 
 using namespace fs;
@@ -271,6 +508,12 @@ using namespace fs;
 // lanes per block: enough that a lane owns at most a few pixels of its column (one block serves the whole column)
 static inline int bnc_threads(long long pixels_per_group) {
     return pixels_per_group > 2048 ? 1024 : pixels_per_group > 512 ? 512 : 256;
+}
+
+// the register-resident kernels: one or two groups of at most BNS_THREADS * BNS_UNROLL pixels (FS_BN_SMALL=0: generic kernels only)
+static inline bool bn_small_ok(long long pixels, int groups) {
+    static const bool enabled = [] { const char* e = getenv("FS_BN_SMALL"); return !(e && e[0] == '0'); }();
+    return enabled && (groups == 1 || groups == 2) && pixels / groups <= BNS_THREADS * BNS_UNROLL;
 }
 
 static fs_status check_map(const char* fn, const void* p, int cs, int C, int dtype) {
@@ -295,6 +538,15 @@ extern "C" fs_status fs_bn_group_fwd(void* stream, long long pixels, int C, int 
     FS_REQUIRE(splits <= 1 || (partials && aligned16(partials) && C % 4 == 0), FS_ERR_INVALID, "fs_bn_group_fwd: bad split-K partials");
     const int cv = C / vec_elems(dtype);
     hipStream_t st = (hipStream_t)stream;
+    if (bn_small_ok(pixels, groups)) {
+#define FS_BN_SMALL_FWD(T, G)                                                                                                     \
+    hipLaunchKernelGGL((bn_small_fwd_kernel<T, G>), dim3(cv), dim3(BNS_THREADS), 0, st, pixels, C, (T*)z, z_cs, partials, splits, gamma, \
+                       beta, eps, momentum, running_mean, running_var, num_batches_tracked, saved, (T*)y, y_cs, relu)
+        if (dtype == FS_F32) { if (groups == 1) FS_BN_SMALL_FWD(float, 1); else FS_BN_SMALL_FWD(float, 2); }
+        else { if (groups == 1) FS_BN_SMALL_FWD(bf16_t, 1); else FS_BN_SMALL_FWD(bf16_t, 2); }
+#undef FS_BN_SMALL_FWD
+        return check_launch("fs_bn_group_fwd");
+    }
     if (dtype == FS_F32)
         hipLaunchKernelGGL((bn_group_fwd_kernel<float>), dim3(cv), dim3(bnc_threads(pixels / groups)), 0, st, pixels, C, groups, (float*)z, z_cs, partials, splits,
                            gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, saved, (float*)y, y_cs, relu);
@@ -317,6 +569,15 @@ extern "C" fs_status fs_bn_group_bwd(void* stream, long long pixels, int C, int 
     FS_REQUIRE((dgamma_acc == nullptr) == (dbeta_acc == nullptr), FS_ERR_INVALID, "fs_bn_group_bwd: dgamma_acc/dbeta_acc go together");
     const int cv = C / vec_elems(dtype);
     hipStream_t st = (hipStream_t)stream;
+    if (bn_small_ok(pixels, groups)) {
+#define FS_BN_SMALL_BWD(T, G)                                                                                                      \
+    hipLaunchKernelGGL((bn_small_bwd_kernel<T, G>), dim3(cv), dim3(BNS_THREADS), 0, st, pixels, C, (const T*)z, z_cs, (const T*)dy, dy_cs, \
+                       (const T*)y_out, y_cs, saved, gamma, relu, (T*)dz, dz_cs, red, dgamma_acc, dbeta_acc)
+        if (dtype == FS_F32) { if (groups == 1) FS_BN_SMALL_BWD(float, 1); else FS_BN_SMALL_BWD(float, 2); }
+        else { if (groups == 1) FS_BN_SMALL_BWD(bf16_t, 1); else FS_BN_SMALL_BWD(bf16_t, 2); }
+#undef FS_BN_SMALL_BWD
+        return check_launch("fs_bn_group_bwd");
+    }
     if (dtype == FS_F32)
         hipLaunchKernelGGL((bn_group_bwd_kernel<float>), dim3(cv), dim3(bnc_threads(pixels / groups)), 0, st, pixels, C, groups, (const float*)z, z_cs,
                            (const float*)dy, dy_cs, (const float*)y_out, y_cs, saved, gamma, relu, (float*)dz, dz_cs, red, dgamma_acc, dbeta_acc);

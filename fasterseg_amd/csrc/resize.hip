@@ -149,9 +149,10 @@ __device__ __forceinline__ float tap_weight(const Tap& t, int i) {
     return w;
 }
 
-// DYL: 0 = dy NHWC (T, vectors), 1 = dy NCHW (TO scalar planes)
+constexpr int BWD_TAPS = 6;          // output columns per input column gathered in one go (x2 up-sample: at most 6, see cand_range)
+
 template <typename T>
-__global__ void bilinear_bwd_kernel(int N, int Hi, int Wi, int Ho, int Wo, int cv, float rh, float rw,
+__global__ __launch_bounds__(256) void bilinear_bwd_kernel(int N, int Hi, int Wi, int Ho, int Wo, int cv, float rh, float rw,
                                     const T* __restrict__ dy, int dy_cs, const T* __restrict__ yo, int yo_cs, int relu,
                                     T* __restrict__ dx, int dx_cs) {
     constexpr int VEC = Elem<T>::VEC;
@@ -169,13 +170,62 @@ __global__ void bilinear_bwd_kernel(int N, int Hi, int Wi, int Ho, int Wo, int c
         float acc[VEC];
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+        // The contributing output columns are compacted first (at most BWD_TAPS for the x2 / x0.5 resamples of the zoomed
+        // convs), so that a row's loads are issued together instead of one dependent round trip per candidate - the maps are
+        // tiny and this kernel is pure latency.  Same taps, same attribution, same summation order as the plain double loop.
+        int cols[BWD_TAPS];
+        float colw[BWD_TAPS];
+        int nw = 0;
+        bool overflow = false;
+        for (int ow = wlo; ow <= whi; ++ow) {
+            const float ww = tap_weight(make_tap(rw, ow, Wi), iw);
+            if (ww == 0.f) continue;
+            if (nw == BWD_TAPS) { overflow = true; break; }
+#pragma unroll
+            for (int k = 0; k < BWD_TAPS; ++k)
+                if (k == nw) { cols[k] = ow; colw[k] = ww; }
+            ++nw;
+        }
+        if (!overflow) {
+#pragma unroll
+            for (int k = 0; k < BWD_TAPS; ++k)
+                if (k >= nw) { cols[k] = nw ? wlo : 0; colw[k] = 0.f; }
+            for (int oh = hlo; oh <= hhi; ++oh) {
+                const float wh = tap_weight(make_tap(rh, oh, Hi), ih);
+                if (wh == 0.f) continue;
+                const long long orow = ((long long)n * Ho + oh) * Wo;
+                u32x4 rg[BWD_TAPS], ro[BWD_TAPS];
+#pragma unroll
+                for (int k = 0; k < BWD_TAPS; ++k) {
+                    rg[k] = ldg16(dy + (orow + cols[k]) * dy_cs + c);
+                    if (relu) ro[k] = ldg16(yo + (orow + cols[k]) * yo_cs + c);
+                }
+#pragma unroll
+                for (int k = 0; k < BWD_TAPS; ++k) {
+                    if (k < nw) {
+                        float g[VEC];
+                        Elem<T>::unpack(rg[k], g);
+                        if (relu) {
+                            float o[VEC];
+                            Elem<T>::unpack(ro[k], o);
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) g[i] = o[i] > 0.f ? g[i] : 0.f;
+                        }
+                        const float w = wh * colw[k];
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) acc[i] += w * g[i];
+                    }
+                }
+            }
+            stg16(dx + (((long long)n * Hi + ih) * Wi + iw) * dx_cs + c, Elem<T>::pack(acc));
+            continue;
+        }
         for (int oh = hlo; oh <= hhi; ++oh) {
             const float wh = tap_weight(make_tap(rh, oh, Hi), ih);
             if (wh == 0.f) continue;
             for (int ow = wlo; ow <= whi; ++ow) {
                 const float ww = tap_weight(make_tap(rw, ow, Wi), iw);
-                if (ww == 0.f) continue;
-                const long long opix = ((long long)n * Ho + oh) * Wo + ow;
+                if (ww == 0.f) continue;                const long long opix = ((long long)n * Ho + oh) * Wo + ow;
                 float g[VEC];
                 Elem<T>::unpack(ldg16(dy + opix * dy_cs + c), g);
                 if (relu) {

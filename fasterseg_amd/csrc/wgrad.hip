@@ -195,8 +195,14 @@ static fs_status wgrad_impl(void* stream, const fs_conv_desc* d, const void* x, 
     a.tiles_ci = (d->Cin + BCH - 1) / BCH;
     const int taps = d->R * d->S;
     const long long other = (long long)tiles_co * a.tiles_ci * taps;
-    long long slabs = (2048 + other - 1) / other;              // aim for ~2k blocks
-    const long long max_slabs = (M + 4 * KC - 1) / (4 * KC);   // at least 4 chunks per block
+    // Pixel slabs: every slab adds one fp32 atomic per gradient element, and on the supernet's maps (192 .. 12288 pixels, 96 - 384
+    // channels) those atomics were 40 % of the kernel at ~2k blocks of >= 4 chunks (scratch/wgrad_micro.py on MI355X, the nine
+    // commonest C3 geometries weighted by their launch counts: 41.9 ms/step; plain stores instead of atomics: 24.6).  ~1k blocks
+    // of >= 8 chunks: 34.7 ms; 512 / 4: 35.1; 256 / 8: 42.1; 4096 / 2: 65.5.  FS_WGRAD_BLOCKS / FS_WGRAD_MIN_CHUNKS override.
+    static const int target_blocks = [] { const char* e = getenv("FS_WGRAD_BLOCKS"); return e && atoi(e) > 0 ? atoi(e) : 1024; }();
+    static const int min_chunks = [] { const char* e = getenv("FS_WGRAD_MIN_CHUNKS"); return e && atoi(e) > 0 ? atoi(e) : 8; }();
+    long long slabs = (target_blocks + other - 1) / other;
+    const long long max_slabs = (M + min_chunks * KC - 1) / (min_chunks * KC);
     if (slabs > max_slabs) slabs = max_slabs;
     if (slabs < 1) slabs = 1;
     long long slab = (M + slabs - 1) / slabs;

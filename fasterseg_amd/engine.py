@@ -644,22 +644,70 @@ class InferenceEngine:
                 lane = 0 if not deps else min(range(n_lanes), key=lambda l: tails[l])
             c["lane"] = lane
             tails[lane] = i
+        self._finish_lanes()
+
+    def _finish_lanes(self):
+        """Cross-lane edges (event waits / signals) and the per-lane split-K workspaces for the current lane assignment."""
+        n_lanes = max(self.n_lanes, 1 + max(c["lane"] for c in self.calls))
         for c in self.calls:
             c["signal"] = False
         for i, c in enumerate(self.calls):
             c["waits"] = [d for d in c["deps"] if self.calls[d]["lane"] != c["lane"]]
             for d in c["waits"]:
                 self.calls[d]["signal"] = True
-        self.lane_tails = tails
         # one split-K scratch buffer per lane (calls of a lane are ordered, lanes run concurrently): the implicit-GEMM conv
         # splits long contractions of launch-latency-sized layers across blocks when it gets a workspace
         if bool(int(os.environ.get("FS_ENGINE_SPLITK", "1"))):
-            if getattr(self, "_workspaces", None) is None:
-                self._workspaces = [torch.empty(K.WORKSPACE_BYTES, dtype=torch.uint8, device=self.device) for _ in range(n_lanes)]
+            ws = getattr(self, "_workspaces", None) or []
+            while len(ws) < n_lanes:
+                ws.append(torch.empty(K.WORKSPACE_BYTES, dtype=torch.uint8, device=self.device))
+            self._workspaces = ws
             for c in self.calls:
                 if c["fn"] == "fs_conv2d_fwd":
                     c["fn"] = "fs_conv2d_fwd_ws"
-                    c["args"] = c["args"] + (ctypes.c_void_p(self._workspaces[c["lane"]].data_ptr()), K.WORKSPACE_BYTES)
+                    c["base_args"] = c["args"]
+                if c["fn"] == "fs_conv2d_fwd_ws":
+                    c["args"] = c["base_args"] + (ctypes.c_void_p(ws[c["lane"]].data_ptr()), K.WORKSPACE_BYTES)
+
+    def _schedule(self, durs, n_lanes, edge_us=1.5):
+        """List scheduling with measured launch durations (HEFT): calls are ordered by the length of the dependency path that
+        still follows them and each goes to the lane where it can start first (an edge that crosses lanes costs an event,
+        ~`edge_us`).  The trace-order greedy of `_assign_lanes` serialised independent chains behind each other: in the searched
+        arch_1 frame the 1/16 branch only started after the five launch-latency-sized 1/32 cells of the other branch
+        (profiles/r02_c2_infer_bf16_frame_timeline.csv).  Reorders self.calls (a topological order) and sets lanes."""
+        n = len(self.calls)
+        succ = [[] for _ in range(n)]
+        for i, c in enumerate(self.calls):
+            for d in c["deps"]:
+                succ[d].append(i)
+        rank = [0.0] * n
+        for i in range(n - 1, -1, -1):                     # trace order is topological
+            rank[i] = durs[i] + max([rank[j] for j in succ[i]] or [0.0])
+        order = sorted(range(n), key=lambda i: (-rank[i], i))
+        lane_free = [0.0] * n_lanes
+        finish, lane_of = [0.0] * n, [0] * n
+        for i in order:
+            deps = self.calls[i]["deps"]
+            best = None
+            for l in range(n_lanes):
+                start = lane_free[l]
+                for d in deps:
+                    start = max(start, finish[d] + (edge_us * 1e-3 if lane_of[d] != l else 0.0))
+                if best is None or start < best[0] - 1e-9:
+                    best = (start, l)
+            lane_of[i] = best[1]
+            finish[i] = best[0] + durs[i]
+            lane_free[best[1]] = finish[i]
+        remap = {old: new for new, old in enumerate(order)}
+        calls = []
+        for old in order:
+            c = self.calls[old]
+            c["deps"] = sorted(remap[d] for d in c["deps"])
+            c["lane"] = lane_of[old]
+            calls.append(c)
+        self.calls = calls
+        self._finish_lanes()
+        return max(finish)
 
     # ---- 4. run ----------------------------------------------------------------------------------------
     def _launch_all(self):
@@ -806,7 +854,30 @@ class InferenceEngine:
             ms = self._time_graph(g)
             self.capture_log.append((lanes, round(ms, 4)))
             if best is None or ms < best[0]:
-                best = (ms, g, lanes, self._side_streams)
+                best = (ms, g, lanes, self._side_streams, None)
+        # FS_ENGINE_HEFT=1: also try list-scheduled variants of the same launches (measured durations, 2..6 lanes), kept only if
+        # the frame gets faster.  Off by default: on the searched arch_1 frame the scheduler's estimate is 0.3145 ms (the
+        # dependency-critical path of the isolated launch times) but every variant replays in 0.378-0.381 ms, the same as the
+        # trace-order greedy - in the frame the kernels run cold and share the CUs, the chain is not the limit.
+        if self.n_lanes > 1 and bool(int(os.environ.get("FS_ENGINE_HEFT", "0"))):
+            durs = [p_["ms"] for p_ in self.profile(repeats=10, rounds=1)]
+            greedy = [(dict(c), list(c["deps"])) for c in self.calls]
+            for lanes in (2, 3, 4, 6):
+                self.calls = [dict(c, deps=list(d)) for c, d in greedy]
+                est = self._schedule(durs, lanes)
+                used = 1 + max(c["lane"] for c in self.calls)
+                for _ in range(2):
+                    g = self._capture_once(used)
+                    ms = self._time_graph(g)
+                    self.capture_log.append(("heft%d" % lanes, round(ms, 4), round(est, 4)))
+                    if ms < best[0]:
+                        best = (ms, g, used, self._side_streams, [dict(c) for c in self.calls])
+            if best[4] is None:
+                self.calls = [dict(c, deps=list(d)) for c, d in greedy]
+                self._finish_lanes()
+            else:
+                self.calls = best[4]
+                self.n_lanes = best[2]
         self.graph, self.graph_lanes, self._side_streams = best[1], best[2], best[3]
         # the same plan issued directly from the C executor (no hipGraph): cheaper on the host per launch
         self.use_program = False

@@ -32,7 +32,6 @@ class FlatSGD:
         dev = sync.flat.device
         if dev.type != "cuda":
             raise RuntimeError("FlatSGD runs on the HIP kernels only (no CPU path)")
-        chunk = _lib.lib().fs_sgd_chunk_elems()
         table = np.zeros(len(params), _TENSOR)
         chunks = []
         self.pack_dtype = pack_dtype
@@ -55,7 +54,7 @@ class FlatSGD:
                 fwd = self.pack_fwd.data_ptr() + pack_off[i] * esize
                 flip = self.pack_flip.data_ptr() + pack_off[i] * esize
             table[i] = (p.data_ptr(), sync.offsets[i], p.numel(), I, taps, fwd, flip)
-            n = (p.numel() + chunk - 1) // chunk
+            n = int(_lib.lib().fs_sgd_tensor_chunks(p.numel(), I, taps, int(fwd != 0)))      # blocks of the update kernel
             chunks.append(np.stack([np.full(n, i, np.int32), np.arange(n, dtype=np.int32)], 1))
         self._ptrs = [(i, params[i].data_ptr()) for i in range(0, len(params), 61)]
         self.table = torch.from_numpy(table.view(np.uint8).copy()).to(dev)

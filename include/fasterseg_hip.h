@@ -320,6 +320,10 @@ typedef struct fs_sgd_tensor {
     void* pack_flip;        /* ... and the [I][R][S][O] 180-degree-rotated copy the data-gradient conv reads (both nullable) */
 } fs_sgd_tensor;
 int fs_sgd_chunk_elems(void);
+/* Blocks the update kernel needs for one tensor: `chunks` holds (tensor index, 0 .. fs_sgd_tensor_chunks - 1) pairs, one per block.
+ * Filters (taps > 1) and tensors with resident packs are walked in 16 x 256 (output channel x (input channel, tap)) tiles, the rest
+ * in runs of fs_sgd_chunk_elems() elements. */
+long long fs_sgd_tensor_chunks(long long numel, int I, int taps, int has_packs);
 fs_status fs_sgd_momentum_multi(void* stream, const fs_sgd_tensor* tensors, const int* chunks, int n_chunks,
                                 const unsigned char* touched, const float* grads, float* momentum_buf,
                                 const float* grad_scale, float lr, float momentum, float weight_decay, int pack_dtype,

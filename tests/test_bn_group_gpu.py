@@ -21,6 +21,11 @@ CASES = [
     (6, 64, 16, 32, 2, 1),        # two groups of 3 images
     (4, 32, 7, 14, 2, 0),
     (4, 48, 14, 28, 4, 1),
+    (3, 192, 8, 16, 1, 1),        # 384 px: register-resident kernel, both unroll slots live
+    (6, 96, 8, 16, 2, 1),         # ... two groups of 384 px
+    (2, 64, 8, 16, 1, 0),         # exactly 256 px
+    (3, 40, 5, 7, 1, 1),          # 105 px: fewer pixels than lanes
+    (2, 24, 16, 32, 2, 1),        # two groups of 512 px: the largest register-resident case
 ]
 
 

@@ -82,3 +82,28 @@ def test_resize_rewrites_off_and_aggressive():
     assert t.ops[1].get("dead") and t.ops[2]["vres"] == (32, 64, False) and t.ops[2]["x"] is t.ops[0]["out"]
     assert not t.ops[3].get("dead") and t.ops[4].get("vres") is None
     assert e.fused_resizes == 1
+
+
+def test_list_scheduler_puts_independent_chains_on_separate_lanes(monkeypatch):
+    """`_schedule` (HEFT with measured durations): a trunk that forks into a long and a short chain which join again.  The
+    result must be a topological order with remapped dependencies, every cross-lane edge an event wait, the two chains on
+    different lanes, and the estimated makespan the critical path (+ the two lane-crossing edges), not the serial sum."""
+    monkeypatch.setenv("FS_ENGINE_SPLITK", "0")
+    e = engine.InferenceEngine.__new__(engine.InferenceEngine)
+    e.n_lanes, e.device = 3, "cpu"
+    #        0 -> 1 -> 2 -> 3 -> 4 (long chain, 10 us each)     0 -> 5 -> 6 (short chain, 4 us each)     (4, 6) -> 7
+    deps = {0: [], 1: [0], 2: [1], 3: [2], 4: [3], 5: [0], 6: [5], 7: [4, 6]}
+    e.calls = [dict(fn="fs_zoom_cell_fwd", args=(), deps=list(deps[i]), label=str(i)) for i in range(8)]
+    durs = [0.010] * 5 + [0.004] * 2 + [0.010]
+    est = e._schedule(durs, 3)
+    labels = [c["label"] for c in e.calls]
+    pos = {l: k for k, l in enumerate(labels)}
+    for k, c in enumerate(e.calls):
+        assert all(d < k for d in c["deps"])                                   # topological
+        assert sorted(labels[d] for d in c["deps"]) == sorted(str(d) for d in deps[int(c["label"])])     # same edges
+        assert c["waits"] == [d for d in c["deps"] if e.calls[d]["lane"] != c["lane"]]
+    long_lane = {e.calls[pos[str(i)]]["lane"] for i in (1, 2, 3, 4)}
+    short_lane = {e.calls[pos[str(i)]]["lane"] for i in (5, 6)}
+    assert len(long_lane) == 1 and len(short_lane) == 1 and long_lane != short_lane
+    assert e.calls[pos["0"]]["signal"] and e.calls[pos["6"]]["signal"] or e.calls[pos["4"]]["signal"]
+    assert abs(est - 0.060) < 0.004, est                                        # critical path 6 x 10 us (+ edges), serial sum is 68
