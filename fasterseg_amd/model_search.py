@@ -247,7 +247,38 @@ class MixedOp(nn.Module):
             from . import program
             prog = cache[key] = program.lower_mixed_op(self, tuple(x.shape), x.stride(3), x.dtype, x.device, need_x, need_coef,
                                                        want_w, sink, groups)
+            if x.stride(3) == x.shape[1]:          # call site, for prewarm_programs(): everything in the key but the widths
+                site = (x.shape[0], x.shape[2], x.shape[3], x.dtype, x.device, need_x, need_coef, want_w, groups)
+                self.__dict__.setdefault("_sites", {}).setdefault(site, (ratio0, ratio1))
         return prog
+
+    def prewarm_programs(self):
+        """Lower the programs of EVERY width combination this MixedOp can be asked for at the call sites seen so far (same
+        input geometry / gradient needs, the sampled ratios ranging over the width list): a "random" or Gumbel pass draws new
+        widths every step, and lowering on first use (~1 ms of Python each, 25 combinations x ~74 MixedOps) would otherwise be
+        spread over the first hundreds of training steps.  Call inside the same gradient-sink state as the passes (the
+        programs hard-code the flat-buffer slices).  Returns the number of programs built."""
+        sampled = self.__dict__.get("_ratio_sampled")
+        if sampled is None:
+            return 0
+        want_now = self._ops[1].conv1.weight.requires_grad
+        built = 0
+        for site, (r0_seen, r1_seen) in list(self.__dict__.get("_sites", {}).items()):
+            n, h, w, dtype, device, need_x, need_coef, want_w, groups = site
+            if want_w != want_now:
+                continue
+            for r0 in (self._width_mult_list if sampled[0] else [r0_seen]):
+                for r1 in (self._width_mult_list if sampled[1] else [r1_seen]):
+                    self.set_prun_ratio((r0, r1))
+                    cin = self._ops[1].conv1.active_channels()[1]
+                    x = torch.empty_strided((n, cin, h, w), (h * w * cin, 1, w * cin, cin), dtype=dtype, device=device)
+                    x.requires_grad_(need_x)
+                    coef = torch.empty(len(self._ops), device=device).requires_grad_(need_coef)
+                    before = len(self.__dict__.get("_programs", {}))
+                    with FN.bn_groups(groups):
+                        self._program(x, coef, r0, r1)
+                    built += len(self.__dict__.get("_programs", {})) - before
+        return built
 
     def forward_latency(self, size, weights, ratios):
         """sum_k latency_k * w_k * r_score0 * r_score1 (reference :80-93) as ONE dot product with a cached device vector of
@@ -275,6 +306,7 @@ class MixedOp(nn.Module):
 
 
 _latency_vectors = {}      # (five LUT latencies, device, dtype) -> device vector
+_SAMPLED = object()        # stands in for a sampled width in _cell_ratio probes
 
 
 class Cell(nn.Module):
@@ -444,6 +476,7 @@ class Network_Multi_Path(nn.Module):
         beta_pos = _positive_table(betas)
 
         out_prev = [[stem(input), None]]  # stem: one cell
+        probe = [[_SAMPLED] * len(r) for r in ratios]          # which entries of a cell's (in, out, down) widths are sampled
         # i: layer | j: scale
         for i, cells in enumerate(self.cells):
             # every MixedOp evaluation of this layer (reference :303-333: cell(out_prev[..], alpha, ratio) = its `_op` and,
@@ -453,6 +486,11 @@ class Network_Multi_Path(nn.Module):
                 alpha = alphas[j][i - j]
                 ratio = self._cell_ratio(i, j, ratios)
                 assert (cell._down and (ratio[2] is not None)) or ((not cell._down) and (ratio[2] is None))
+                if "_ratio_sampled" not in cell._op.__dict__:
+                    which = [r is _SAMPLED for r in self._cell_ratio(i, j, probe)]
+                    cell._op.__dict__["_ratio_sampled"] = (which[0], which[1])
+                    if cell._down:
+                        cell.downsample.__dict__["_ratio_sampled"] = (which[0], which[2])
                 # sources -- 0: from down; 1: from keep
                 if j == 0:
                     srcs = [(1, out_prev[0][0])]

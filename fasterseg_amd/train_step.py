@@ -134,6 +134,7 @@ class SupernetStep:
             seed = int(box[0])
         np.random.seed(seed)
         torch.manual_seed(seed)
+        self._prewarmed = not bool(int(os.environ.get("FS_PREWARM_PROGRAMS", "1")))
         self.architect = None
         if not pretrain:
             if lut is not None:
@@ -313,7 +314,39 @@ class SupernetStep:
         loss = self._phase_loss("w", imgs, target)
         self.sync.sync()
         self.optimizer.step()
+        if not self._prewarmed:               # after the first step every MixedOp has seen its call sites
+            self._prewarmed = True
+            self.prewarm_programs()
         return loss, loss_arch
+
+    def prewarm_programs(self):
+        """One-time setup, like the hipGraph capture of the fixed-width passes: lower the launch programs of every width
+        combination the eager ("random" / Gumbel) passes can draw, then move the (now static) Python object graph - 40 k
+        parameter tensors, ~2 k programs - out of the cyclic garbage collector's reach (gc.freeze): cProfile showed a
+        supernet step spending more host time in first-use lowering and in generation-2 collections than in issuing its
+        launches.  FS_PREWARM_PROGRAMS=0 keeps lowering on first use."""
+        import gc
+        from . import functional as FN
+        from . import kernels as K
+        from . import model_search
+        mixed = [m for m in self.model.modules() if isinstance(m, model_search.MixedOp)]
+        built = 0
+        for phase in (("a", "w") if self.architect is not None else ("w",)):
+            self._set_phase(phase)
+            if phase == "w":
+                self.sync.prepare(passes=len(self._specs()))
+            try:
+                for m in mixed:
+                    built += m.prewarm_programs()
+            finally:
+                if phase == "w":          # leave the sink state without a (collective) sync
+                    FN._grad_sink = None
+                    K.zero_pool.stop()
+        self._set_phase("w")
+        self.programs_prewarmed = built
+        gc.collect()
+        gc.freeze()
+        return built
 
     def _step_eager(self, imgs, target, imgs_search=None, target_search=None):
         loss_arch = None

@@ -249,6 +249,26 @@ def test_supernet_pair_batching_equals_sequential_evaluation():
         assert rel < 2e-2, (k, rel)
 
 
+def test_prewarmed_programs_cover_every_random_width_draw():
+    """After the first graphed step SupernetStep.prewarm_programs() has lowered every width combination of every MixedOp call
+    site: later steps, whose "random" passes draw new widths each time, build no further program."""
+    from fasterseg_amd import model_search
+    from fasterseg_amd.train_step import SupernetStep
+    st = SupernetStep(pretrain=True, cfg=SmallSearch, seed=11, use_graphs=True)
+    imgs, tgt = _batch()
+    np.random.seed(21)
+    st.step(imgs, tgt)
+    assert st.programs_prewarmed > 0
+    mixed = [m for m in st.model.modules() if isinstance(m, model_search.MixedOp)]
+    count = lambda: sum(len(m.__dict__.get("_programs", {})) for m in mixed)
+    n0 = count()
+    nw = len(SmallSearch.width_mult_list)
+    assert n0 >= len(mixed) * nw, (n0, len(mixed))          # at least one sampled ratio per MixedOp
+    losses = [float(st.step(imgs, tgt)[0]) for _ in range(4)]
+    assert count() == n0, "a random-width pass lowered a program after the prewarm"
+    assert all(np.isfinite(losses))
+
+
 def test_supernet_step_with_programs_equals_module_path():
     """Eager pretrain steps (all four passes, random widths included) with the MixedOp programs vs the per-module path."""
     from fasterseg_amd import model_search
