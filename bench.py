@@ -57,6 +57,7 @@ def parse():
     ap.add_argument("--min-seconds", type=float, default=0.5, help="minimum length of every timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-class-map", action="store_true", help="skip the class-map (evaluator) variant of the C2 engine")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU budget of each cpu_baseline sample")
     ap.add_argument("--dump-plan", default=None, help="write the per-launch table of the C2 plan (json) here")
     args = ap.parse_args()
@@ -238,7 +239,7 @@ def run_student_infer(args, world, rank, backend):
         if args.dump_plan:
             with open(args.dump_plan, "w") as f:
                 json.dump(rows, f, indent=1)
-    if rank == 0 and "c2cls" not in getattr(args, "skip", ()):
+    if rank == 0 and not args.no_class_map:
         # the evaluator path: same network, class map (uint8) instead of fp32 logits as the output
         eng_c = engine.InferenceEngine(net, shape, dtype=dtype, output="classes")
         cls = eng_c(x.cuda())

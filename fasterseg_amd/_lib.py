@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfasterseg_hip.so")
 
-EXPECTED_ABI = 201          # FS_ABI_VERSION of include/fasterseg_hip.h these bindings were written against
+EXPECTED_ABI = 202          # FS_ABI_VERSION of include/fasterseg_hip.h these bindings were written against
 FS_F32, FS_BF16 = 0, 1
 FS_CONV_RELU, FS_CONV_TRANSPOSED, FS_CONV_ACCUM = 1, 2, 4
 
@@ -97,9 +97,10 @@ SIGNATURES = {
     "fs_ohem_ce_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_int, c_ll, c_vp],
     "fs_kl_distill_fwd": [c_vp, c_vp, c_vp, c_ll, c_int, c_ll, c_vp, c_vp, c_vp],
     "fs_ohem_ce_up_fwd": [c_vp, ctypes.POINTER(LogitsDesc), c_vp, c_vp, c_int, c_vp, c_vp, c_vp],
-    "fs_ohem_ce_up_bwd": [c_vp, ctypes.POINTER(LogitsDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "fs_ohem_ce_up_bwd": [c_vp, ctypes.POINTER(LogitsDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll],
     "fs_kl_distill_up_fwd": [c_vp, ctypes.POINTER(LogitsDesc), c_vp, ctypes.POINTER(LogitsDesc), c_vp, c_vp, c_vp, c_vp],
-    "fs_kl_distill_up_bwd": [c_vp, ctypes.POINTER(LogitsDesc), c_vp, ctypes.POINTER(LogitsDesc), c_vp, c_vp, c_vp, c_vp, c_vp],
+    "fs_kl_distill_up_bwd": [c_vp, ctypes.POINTER(LogitsDesc), c_vp, ctypes.POINTER(LogitsDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                             c_ll],
     "fs_kl_distill_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_int, c_ll, c_vp],
     "fs_exec_program": [c_vp, c_vp, c_ll, c_vp, c_vp, c_int],
     "fs_exec_program_streams": [c_vp, c_int, c_vp, c_ll, c_vp, c_vp, c_int],
@@ -115,6 +116,7 @@ _SPECIAL = {
     "fs_packed_weight_frag_elems": ([c_int, c_int, c_int], c_ll),
     "fs_sgd_chunk_elems": ([], c_int),
     "fs_sgd_tensor_chunks": ([c_ll, c_int, c_int, c_int], c_ll),
+    "fs_loss_up_workspace_bytes": ([ctypes.POINTER(LogitsDesc)], c_ll),
     "fs_zoom_cell_supported": ([ctypes.POINTER(ZoomDesc)], c_int),
     "fs_census_enable": ([c_int], None),
     "fs_census_read": ([c_vp, c_int], c_int),

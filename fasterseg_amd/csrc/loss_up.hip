@@ -8,9 +8,14 @@
 // interpolation (align_corners=True, same tap arithmetic and expression as resize.hip) per full-resolution pixel on the fly:
 //   *_up_fwd   one lane per full-resolution pixel: 4 taps x C logits from L2 -> lse / nll / p_target (OHEM) or KL (distill);
 //              the only HBM traffic is three floats per pixel out.
-//   *_up_bwd   the transpose of the interpolation as a GATHER: one wave per low-resolution pixel, lanes over the
-//              full-resolution pixels whose taps touch it (recomputing their logits), wave-reduced per class:
-//              d lo[i,j,c] = sum_p w(p -> i,j) * dL/dlogit_p[c].  No atomics, deterministic, no full-resolution tensor.
+//   *_up_bwd   the transpose of the interpolation, d lo[i,j,c] = sum_p w(p -> i,j) * dL/dlogit_p[c], in two launches without
+//              atomics or a full-resolution tensor.  (1) cells: the full-resolution pixels between four neighbouring
+//              low-resolution pixels all interpolate between the SAME four logit vectors, so a wave (x8 heads) or a block
+//              (x16 / x32) takes one cell, loads the four vectors once, evaluates every pixel of the cell exactly once (pure
+//              ALU: interpolate, softmax gradient) and reduces its contributions to the four corners in a fixed order into
+//              workspace[cell][corner][class]; (2) a gather adds, per low-resolution pixel, the matching corners of its (up to)
+//              four cells.  The first version gathered per low-resolution pixel and re-evaluated every full-resolution pixel
+//              four times inside divergent loops: 565 us (OHEM) / 1057 us (KL) per launch on the student step's heads.
 #include "common.h"
 
 namespace fs {
@@ -70,26 +75,6 @@ __device__ __forceinline__ float lse_of(const float* v, int C) {
     return m + logf(s);
 }
 
-// full-resolution output pixels [lo, hi] whose taps may touch input index i (widened; callers re-test with make_tap)
-__device__ __forceinline__ void up_range(float scale, int i, int out_size, int& lo, int& hi) {
-    if (scale <= 0.f) {
-        lo = 0;
-        hi = out_size - 1;
-        return;
-    }
-    const float inv = 1.f / scale;
-    lo = (int)floorf((float)(i - 1) * inv) - 1;
-    hi = (int)ceilf((float)(i + 1) * inv) + 1;
-    if (lo < 0) lo = 0;
-    if (hi > out_size - 1) hi = out_size - 1;
-}
-__device__ __forceinline__ float up_weight(const Tap& t, int i) {
-    float w = 0.f;
-    if (t.i0 == i) w += t.l0;
-    if (t.i1 == i) w += t.l1;
-    return w;
-}
-
 // ---- OHEM cross-entropy ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void ohem_up_fwd_kernel(const T* __restrict__ lo, const long long* __restrict__ target, UpGeom g,
@@ -115,46 +100,233 @@ __global__ __launch_bounds__(256) void ohem_up_fwd_kernel(const T* __restrict__ 
     }
 }
 
-// one wave per low-resolution pixel; grad of the SUM over kept pixels of nll, times *scale
-template <typename T>
-__global__ __launch_bounds__(256) void ohem_up_bwd_kernel(const T* __restrict__ lo, const long long* __restrict__ target,
-                                                          const float* __restrict__ lse, const unsigned char* __restrict__ kept,
-                                                          const float* __restrict__ scale, UpGeom g, T* __restrict__ dlo) {
-    const int lane = threadIdx.x & 63;
-    const long long wave = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6;
-    const long long total = (long long)g.N * g.h * g.w;
-    if (wave >= total) return;
-    const int j = (int)(wave % g.w);
-    const long long r = wave / g.w;
-    const int i = (int)(r % g.h), n = (int)(r / g.h);
-    int ylo, yhi, xlo, xhi;
-    up_range(g.rh, i, g.H, ylo, yhi);
-    up_range(g.rw, j, g.W, xlo, xhi);
-    const int ncols = xhi - xlo + 1, count = (yhi - ylo + 1) * ncols;
-    float acc[LU_MAXC];
-#pragma unroll
-    for (int c = 0; c < LU_MAXC; ++c) acc[c] = 0.f;
-    for (int k = lane; k < count; k += 64) {
-        const int Y = ylo + k / ncols, X = xlo + k % ncols;
-        const float wgt = up_weight(make_tap(g.rh, Y, g.h), i) * up_weight(make_tap(g.rw, X, g.w), j);
+// ---- backward, shared by both losses ---------------------------------------------------------------------------------------
+constexpr int LU_SLOTS = 4 * LU_MAXC;        // workspace floats per cell: corner (a, b) -> [2a + b][class]
+
+// smallest destination index whose first tap (make_tap(...).i0, same float expression) is >= i
+__device__ __forceinline__ int first_dst(float scale, int i, int out_size) {
+    if (i <= 0) return 0;
+    if (scale <= 0.f) return out_size;
+    int d = (int)ceilf((float)i / scale);
+    if (d > out_size) d = out_size;
+    if (d < 0) d = 0;
+    while (d > 0 && (int)(scale * (float)(d - 1)) >= i) --d;
+    while (d < out_size && (int)(scale * (float)d) < i) ++d;
+    return d;
+}
+
+// One sweep over the pixels of cell (n, i, j) of geometry `g` for the four classes c0 .. c0+3:
+// S[corner][k] += sign * w_corner(p) * (softmax_{c0+k}(logits_p) - onehot).  Classes go four at a time (the kernel loops over the
+// quads) so that a lane holds 16 accumulators and 16 corner logits instead of 80 + 80: at 256 VGPRs one wave per SIMD was
+// resident and every per-pixel load (lse, target, kept) was an exposed HBM round trip - 1.2 ms per x8 head.
+// UNIFORM: `lo` has the cell geometry, its four corner vectors are loaded once; otherwise (a teacher map of another resolution)
+// the logits of every pixel are interpolated from `lo` / `gl` with loads.
+template <typename T, bool OHEM, bool UNIFORM>
+__device__ __forceinline__ void cell_sweep(float (&S)[16], float sign, int c0, const T* __restrict__ lo, const UpGeom& gl,
+                                           const UpGeom& g, int n, int i, int j, int Ya, int ny, int Xa, int nx, int first, int step,
+                                           const float* __restrict__ lse, const long long* __restrict__ target,
+                                           const unsigned char* __restrict__ kept) {
+    float L[4][4];
+    if (UNIFORM) {
+        const int i1 = i + (i < g.h - 1 ? 1 : 0), j1 = j + (j < g.w - 1 ? 1 : 0);
+        const T* r0 = lo + ((long long)n * g.h + i) * g.w * g.cs + c0;
+        const T* r1 = lo + ((long long)n * g.h + i1) * g.w * g.cs + c0;
+        QuadL<T>::load(r0 + (long long)j * g.cs, L[0]);
+        QuadL<T>::load(r0 + (long long)j1 * g.cs, L[1]);
+        QuadL<T>::load(r1 + (long long)j * g.cs, L[2]);
+        QuadL<T>::load(r1 + (long long)j1 * g.cs, L[3]);
+    }
+    const int count = ny * nx;
+    for (int k = first; k < count; k += step) {
+        const int dy_ = k / nx;
+        const int Y = Ya + dy_, X = Xa + (k - dy_ * nx);
         const long long p = ((long long)n * g.H + Y) * g.W + X;
-        if (wgt == 0.f || !kept[p]) continue;
-        float v[LU_MAXC];
-        interp_logits<T>(lo, g, n, Y, X, v);
         const float l = lse[p];
-        const int t = (int)target[p];
+        const float keep = OHEM ? (kept[p] ? sign : 0.f) : sign;
+        const int t = OHEM ? (int)target[p] : -1;
+        const Tap th = make_tap(g.rh, Y, g.h), tw = make_tap(g.rw, X, g.w);
+        float v[4];
+        if (UNIFORM) {
 #pragma unroll
-        for (int c = 0; c < LU_MAXC; ++c)
-            if (c < g.C) acc[c] += wgt * (expf(v[c] - l) - (c == t ? 1.f : 0.f));
+            for (int c = 0; c < 4; ++c) v[c] = th.l0 * (tw.l0 * L[0][c] + tw.l1 * L[1][c]) + th.l1 * (tw.l0 * L[2][c] + tw.l1 * L[3][c]);
+        } else {           // same expression as interp_logits, one quad
+            const Tap uh = make_tap(gl.rh, Y, gl.h), uw = make_tap(gl.rw, X, gl.w);
+            const T* r0 = lo + ((long long)n * gl.h + uh.i0) * gl.w * gl.cs + c0;
+            const T* r1 = lo + ((long long)n * gl.h + uh.i1) * gl.w * gl.cs + c0;
+            float p00[4], p01[4], p10[4], p11[4];
+            QuadL<T>::load(r0 + (long long)uw.i0 * gl.cs, p00);
+            QuadL<T>::load(r0 + (long long)uw.i1 * gl.cs, p01);
+            QuadL<T>::load(r1 + (long long)uw.i0 * gl.cs, p10);
+            QuadL<T>::load(r1 + (long long)uw.i1 * gl.cs, p11);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = uh.l0 * (uw.l0 * p00[c] + uw.l1 * p01[c]) + uh.l1 * (uw.l0 * p10[c] + uw.l1 * p11[c]);
+        }
+        const float w00 = keep * th.l0 * tw.l0, w01 = keep * th.l0 * tw.l1, w10 = keep * th.l1 * tw.l0, w11 = keep * th.l1 * tw.l1;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float gv = (c0 + c < g.C) ? expf(v[c] - l) - ((OHEM && c0 + c == t) ? 1.f : 0.f) : 0.f;
+            S[c] += w00 * gv;
+            S[4 + c] += w01 * gv;
+            S[8 + c] += w10 * gv;
+            S[12 + c] += w11 * gv;
+        }
     }
+}
+
+// The pixels a lane owns in its cell, loaded ONCE (interpolation weights, log-sum-exps, label, OHEM mask): the class-quad loop of
+// the common case - every lane owns at most MAXP pixels - then touches memory only for the four corner vectors of the quad.
+template <int MAXP>
+struct CellPixels {
+    float h0[MAXP], h1[MAXP], w0[MAXP], w1[MAXP];     // tap weights, already multiplied by keep (0 / 1) on the h side
+    float ls[MAXP], lt[MAXP];
+    int t[MAXP];
+};
+
+template <typename T, bool OHEM, int MAXP>
+__device__ __forceinline__ void cell_quad(float (&S)[16], float sign, int c0, const T* __restrict__ lo, const UpGeom& g, int n, int i,
+                                          int j, const CellPixels<MAXP>& px, const float (&lse)[MAXP]) {
+    float L[4][4];
+    const int i1 = i + (i < g.h - 1 ? 1 : 0), j1 = j + (j < g.w - 1 ? 1 : 0);
+    const T* r0 = lo + ((long long)n * g.h + i) * g.w * g.cs + c0;
+    const T* r1 = lo + ((long long)n * g.h + i1) * g.w * g.cs + c0;
+    QuadL<T>::load(r0 + (long long)j * g.cs, L[0]);
+    QuadL<T>::load(r0 + (long long)j1 * g.cs, L[1]);
+    QuadL<T>::load(r1 + (long long)j * g.cs, L[2]);
+    QuadL<T>::load(r1 + (long long)j1 * g.cs, L[3]);
+#pragma unroll
+    for (int m = 0; m < MAXP; ++m) {
+        // a lane without an m-th pixel (or a pixel OHEM dropped) has h0 = h1 = 0 and contributes nothing
+        float v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            v[c] = px.h0[m] * (px.w0[m] * L[0][c] + px.w1[m] * L[1][c]) + px.h1[m] * (px.w0[m] * L[2][c] + px.w1[m] * L[3][c]);
+        const float w00 = sign * px.h0[m] * px.w0[m], w01 = sign * px.h0[m] * px.w1[m];
+        const float w10 = sign * px.h1[m] * px.w0[m], w11 = sign * px.h1[m] * px.w1[m];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float gv = (c0 + c < g.C) ? expf(v[c] - lse[m]) - ((OHEM && c0 + c == px.t[m]) ? 1.f : 0.f) : 0.f;
+            S[c] += w00 * gv;
+            S[4 + c] += w01 * gv;
+            S[8 + c] += w10 * gv;
+            S[12 + c] += w11 * gv;
+        }
+    }
+}
+
+// WAVES = 1: four cells per block, one wave each; WAVES = 4: one cell per block.  KL: second sweep over the teacher.
+template <typename TS, typename TT, bool OHEM, int WAVES, int MAXP>
+__global__ __launch_bounds__(256) void up_bwd_cells_kernel(const TS* __restrict__ s_lo, UpGeom g, const TT* __restrict__ t_lo, UpGeom gt,
+                                                           const float* __restrict__ lse_s, const float* __restrict__ lse_t,
+                                                           const long long* __restrict__ target,
+                                                           const unsigned char* __restrict__ kept, float* __restrict__ ws) {
+    __shared__ float part[4][16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long cells = (long long)g.N * g.h * g.w;
+    const long long cell = WAVES == 1 ? blockIdx.x * 4ll + wave : (long long)blockIdx.x;
+    const bool live = cell < cells;
+    const long long cc = live ? cell : 0;
+    const int j = (int)(cc % g.w);
+    const long long r = cc / g.w;
+    const int i = (int)(r % g.h), n = (int)(r / g.h);
+    const int Ya = first_dst(g.rh, i, g.H), Yb = first_dst(g.rh, i + 1, g.H);
+    const int Xa = first_dst(g.rw, j, g.W), Xb = first_dst(g.rw, j + 1, g.W);
+    const int ny = live ? Yb - Ya : 0, nx = Xb - Xa;
+    const int first = WAVES == 1 ? lane : (int)threadIdx.x, step = WAVES == 1 ? 64 : 256;
+    const bool same = gt.h == g.h && gt.w == g.w;
+    const int count = ny * nx;
+    // common case (wave-uniform for WAVES = 1, block-uniform for WAVES = 4): per-pixel data in registers
+    // (MAXP = 0 compiles the register-resident path out: measured on the student step's heads, x32 cells 348 -> 184 us with
+    // it, x16 cells 348 -> 529 us and x8 cells 484 -> 506 us against it - its registers cost more occupancy than its loads save)
+    const bool fast = MAXP > 0 && count <= MAXP * step && (OHEM || same);
+    CellPixels<(MAXP > 0 ? MAXP : 1)> px;
+    if constexpr (MAXP > 0) if (fast) {
+#pragma unroll
+        for (int m = 0; m < MAXP; ++m) {
+            const int k = first + m * step;
+            const bool has = k < count;
+            const int kk = has ? k : 0;
+            const int dy_ = nx > 0 ? kk / nx : 0;
+            const int Y = Ya + dy_, X = Xa + (kk - dy_ * nx);
+            const long long p = has ? ((long long)n * g.H + Y) * g.W + X : 0;
+            const Tap th = make_tap(g.rh, Y, g.h), tw = make_tap(g.rw, X, g.w);
+            const float keep = has ? (OHEM ? (kept[p] ? 1.f : 0.f) : 1.f) : 0.f;
+            px.h0[m] = keep * th.l0; px.h1[m] = keep * th.l1; px.w0[m] = tw.l0; px.w1[m] = tw.l1;
+            px.ls[m] = lse_s[p];
+            px.lt[m] = OHEM ? 0.f : lse_t[p];
+            px.t[m] = OHEM ? (int)target[p] : -1;
+        }
+    }
+    for (int c0 = 0; c0 < g.C; c0 += 4) {
+        float S[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) S[k] = 0.f;
+        if constexpr (MAXP > 0) {
+            if (fast) {
+                cell_quad<TS, OHEM, MAXP>(S, 1.f, c0, s_lo, g, n, i, j, px, px.ls);
+                if (!OHEM) cell_quad<TT, false, MAXP>(S, -1.f, c0, t_lo, gt, n, i, j, px, px.lt);
+            }
+        }
+        if (!fast) {
+            cell_sweep<TS, OHEM, true>(S, 1.f, c0, s_lo, g, g, n, i, j, Ya, ny, Xa, nx, first, step, lse_s, target, kept);
+            if (!OHEM) {
+                if (same) cell_sweep<TT, false, true>(S, -1.f, c0, t_lo, gt, g, n, i, j, Ya, ny, Xa, nx, first, step, lse_t, nullptr, nullptr);
+                else cell_sweep<TT, false, false>(S, -1.f, c0, t_lo, gt, g, n, i, j, Ya, ny, Xa, nx, first, step, lse_t, nullptr, nullptr);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) S[k] = wave_sum(S[k]);
+        // workspace[cell][corner][class]: this quad's four classes of the four corners
+        if (WAVES == 1) {
+            if (live && lane == 0) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+                    *reinterpret_cast<f32x4*>(ws + cell * LU_SLOTS + a * LU_MAXC + c0) = f32x4{S[4 * a], S[4 * a + 1], S[4 * a + 2], S[4 * a + 3]};
+            }
+        } else {
+            __syncthreads();                              // `part` of the previous quad has been read
+            if (lane == 0) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) part[wave][k] = S[k];
+            }
+            __syncthreads();
+            if (live && threadIdx.x < 16)                 // fixed order: waves 0, 1, 2, 3
+                ws[cell * LU_SLOTS + (threadIdx.x >> 2) * LU_MAXC + c0 + (threadIdx.x & 3)] =
+                    ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
+        }
+    }
+}
+
+// d lo[n, i, j, c] = scale * sum of the corners of the neighbouring cells that ARE (i, j) (a clamped last row / column maps both
+// of its corners onto itself)
+template <typename T>
+__global__ __launch_bounds__(256) void up_bwd_gather_kernel(const float* __restrict__ ws, UpGeom g, const float* __restrict__ scale,
+                                                            T* __restrict__ dlo) {
+    const long long total = (long long)g.N * g.h * g.w * g.cs;
     const float s = *scale;
-    float mine = 0.f;
-#pragma unroll
-    for (int c = 0; c < LU_MAXC; ++c) {
-        const float tot = wave_sum(acc[c]);
-        if (lane == c) mine = tot * s;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % g.cs);
+        long long r = idx / g.cs;
+        const int j = (int)(r % g.w); r /= g.w;
+        const int i = (int)(r % g.h);
+        const int n = (int)(r / g.h);
+        float acc = 0.f;
+        if (c < g.C) {
+            for (int ci = i - 1; ci <= i; ++ci) {
+                if (ci < 0) continue;
+                for (int a = 0; a < 2; ++a) {
+                    if (ci + (a && ci < g.h - 1 ? 1 : 0) != i) continue;
+                    for (int cj = j - 1; cj <= j; ++cj) {
+                        if (cj < 0) continue;
+                        for (int b = 0; b < 2; ++b) {
+                            if (cj + (b && cj < g.w - 1 ? 1 : 0) != j) continue;
+                            acc += ws[(((long long)n * g.h + ci) * g.w + cj) * LU_SLOTS + (2 * a + b) * LU_MAXC + c];
+                        }
+                    }
+                }
+            }
+        }
+        Elem<T>::store(dlo + idx, acc * s);
     }
-    if (lane < g.cs) Elem<T>::store(dlo + (((long long)n * g.h + i) * g.w + j) * g.cs + lane, lane < g.C ? mine : 0.f);
 }
 
 // ---- KL distillation: KLDivLoss(log_softmax(student), softmax(teacher)), per-pixel sums ---------------------------------
@@ -183,47 +355,6 @@ __global__ __launch_bounds__(256) void kl_up_fwd_kernel(const TS* __restrict__ s
         lse_s[p] = ls;
         lse_t[p] = lt;
     }
-}
-
-template <typename TS, typename TT>
-__global__ __launch_bounds__(256) void kl_up_bwd_kernel(const TS* __restrict__ s_lo, UpGeom gs, const TT* __restrict__ t_lo, UpGeom gt,
-                                                        const float* __restrict__ lse_s, const float* __restrict__ lse_t,
-                                                        const float* __restrict__ scale, TS* __restrict__ dlo) {
-    const int lane = threadIdx.x & 63;
-    const long long wave = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6;
-    const long long total = (long long)gs.N * gs.h * gs.w;
-    if (wave >= total) return;
-    const int j = (int)(wave % gs.w);
-    const long long r = wave / gs.w;
-    const int i = (int)(r % gs.h), n = (int)(r / gs.h);
-    int ylo, yhi, xlo, xhi;
-    up_range(gs.rh, i, gs.H, ylo, yhi);
-    up_range(gs.rw, j, gs.W, xlo, xhi);
-    const int ncols = xhi - xlo + 1, count = (yhi - ylo + 1) * ncols;
-    float acc[LU_MAXC];
-#pragma unroll
-    for (int c = 0; c < LU_MAXC; ++c) acc[c] = 0.f;
-    for (int k = lane; k < count; k += 64) {
-        const int Y = ylo + k / ncols, X = xlo + k % ncols;
-        const float wgt = up_weight(make_tap(gs.rh, Y, gs.h), i) * up_weight(make_tap(gs.rw, X, gs.w), j);
-        if (wgt == 0.f) continue;
-        const long long p = ((long long)n * gs.H + Y) * gs.W + X;
-        float vs[LU_MAXC], vt[LU_MAXC];
-        interp_logits<TS>(s_lo, gs, n, Y, X, vs);
-        interp_logits<TT>(t_lo, gt, n, Y, X, vt);
-        const float ls = lse_s[p], lt = lse_t[p];
-#pragma unroll
-        for (int c = 0; c < LU_MAXC; ++c)
-            if (c < gs.C) acc[c] += wgt * (expf(vs[c] - ls) - expf(vt[c] - lt));
-    }
-    const float s = *scale;
-    float mine = 0.f;
-#pragma unroll
-    for (int c = 0; c < LU_MAXC; ++c) {
-        const float tot = wave_sum(acc[c]);
-        if (lane == c) mine = tot * s;
-    }
-    if (lane < gs.cs) Elem<TS>::store(dlo + (((long long)n * gs.h + i) * gs.w + j) * gs.cs + lane, lane < gs.C ? mine : 0.f);
 }
 
 static inline float lu_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
@@ -263,20 +394,43 @@ extern "C" fs_status fs_ohem_ce_up_fwd(void* stream, const fs_logits_desc* d, co
     return check_launch("fs_ohem_ce_up_fwd");
 }
 
+extern "C" long long fs_loss_up_workspace_bytes(const fs_logits_desc* d) {
+    if (!d || d->N <= 0 || d->h <= 0 || d->w <= 0) return 0;
+    return (long long)d->N * d->h * d->w * LU_SLOTS * (long long)sizeof(float);
+}
+
+// cells + gather launches of one backward; `big` cells (more than two wave iterations of pixels) take a whole block
+template <typename TS, typename TT, bool OHEM>
+static void launch_up_bwd(hipStream_t st, const UpGeom& g, const void* s_lo, const UpGeom& gt, const void* t_lo, const float* lse_s,
+                          const float* lse_t, const long long* target, const unsigned char* kept, const float* scale, float* ws,
+                          void* dlo) {
+    const long long cells = (long long)g.N * g.h * g.w;
+    const double area = ((double)g.H / g.h) * ((double)g.W / g.w);
+    if (area <= 100.0)           // x8 heads: cells of 8-9 x 8-9 pixels, one wave each
+        hipLaunchKernelGGL((up_bwd_cells_kernel<TS, TT, OHEM, 1, 0>), dim3((unsigned)((cells + 3) / 4)), dim3(256), 0, st, (const TS*)s_lo, g,
+                           (const TT*)t_lo, gt, lse_s, lse_t, target, kept, ws);
+    else if (area <= 400.0)      // x16: up to 17 x 17 pixels over a block
+        hipLaunchKernelGGL((up_bwd_cells_kernel<TS, TT, OHEM, 4, 0>), dim3((unsigned)cells), dim3(256), 0, st, (const TS*)s_lo, g,
+                           (const TT*)t_lo, gt, lse_s, lse_t, target, kept, ws);
+    else                         // x32: up to 33 x 33 pixels, five per lane held in registers; anything larger takes the looped path
+        hipLaunchKernelGGL((up_bwd_cells_kernel<TS, TT, OHEM, 4, 5>), dim3((unsigned)cells), dim3(256), 0, st, (const TS*)s_lo, g,
+                           (const TT*)t_lo, gt, lse_s, lse_t, target, kept, ws);
+    hipLaunchKernelGGL((up_bwd_gather_kernel<TS>), dim3(pixel_blocks(cells * g.cs)), dim3(256), 0, st, ws, g, scale, (TS*)dlo);
+}
+
 extern "C" fs_status fs_ohem_ce_up_bwd(void* stream, const fs_logits_desc* d, const void* logits_lo, const long long* target,
-                                       const float* lse, const unsigned char* kept, const float* scale, void* dlogits_lo) {
+                                       const float* lse, const unsigned char* kept, const float* scale, void* dlogits_lo,
+                                       float* workspace, long long workspace_bytes) {
     UpGeom g;
     FS_REQUIRE(make_geom(d, g), FS_ERR_INVALID, "fs_ohem_ce_up_bwd: bad descriptor");
     FS_REQUIRE(logits_lo && target && lse && kept && scale && dlogits_lo, FS_ERR_INVALID, "fs_ohem_ce_up_bwd: null argument");
-    const long long waves = (long long)g.N * g.h * g.w;
-    const unsigned blocks = (unsigned)((waves + 3) / 4);
+    FS_REQUIRE(workspace && workspace_bytes >= fs_loss_up_workspace_bytes(d), FS_ERR_INVALID,
+               "fs_ohem_ce_up_bwd: workspace of %lld bytes needed (fs_loss_up_workspace_bytes)", fs_loss_up_workspace_bytes(d));
     hipStream_t st = (hipStream_t)stream;
     if (d->dtype == FS_F32)
-        hipLaunchKernelGGL((ohem_up_bwd_kernel<float>), dim3(blocks), dim3(256), 0, st, (const float*)logits_lo, target, lse, kept, scale, g,
-                           (float*)dlogits_lo);
+        launch_up_bwd<float, float, true>(st, g, logits_lo, g, nullptr, lse, nullptr, target, kept, scale, workspace, dlogits_lo);
     else
-        hipLaunchKernelGGL((ohem_up_bwd_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)logits_lo, target, lse, kept, scale, g,
-                           (bf16_t*)dlogits_lo);
+        launch_up_bwd<bf16_t, bf16_t, true>(st, g, logits_lo, g, nullptr, lse, nullptr, target, kept, scale, workspace, dlogits_lo);
     return check_launch("fs_ohem_ce_up_bwd");
 }
 
@@ -301,16 +455,16 @@ extern "C" fs_status fs_kl_distill_up_fwd(void* stream, const fs_logits_desc* ds
 
 extern "C" fs_status fs_kl_distill_up_bwd(void* stream, const fs_logits_desc* ds, const void* student_lo, const fs_logits_desc* dt,
                                           const void* teacher_lo, const float* lse_s, const float* lse_t, const float* scale,
-                                          void* d_student_lo) {
+                                          void* d_student_lo, float* workspace, long long workspace_bytes) {
     UpGeom gs, gt;
     FS_REQUIRE(make_geom(ds, gs) && make_geom(dt, gt), FS_ERR_INVALID, "fs_kl_distill_up_bwd: bad descriptor");
     FS_REQUIRE(gs.N == gt.N && gs.H == gt.H && gs.W == gt.W && gs.C == gt.C, FS_ERR_INVALID,
                "fs_kl_distill_up_bwd: student and teacher must agree on N, C and the full resolution");
     FS_REQUIRE(student_lo && teacher_lo && lse_s && lse_t && scale && d_student_lo, FS_ERR_INVALID, "fs_kl_distill_up_bwd: null argument");
-    const long long waves = (long long)gs.N * gs.h * gs.w;
-    const dim3 grid((unsigned)((waves + 3) / 4));
+    FS_REQUIRE(workspace && workspace_bytes >= fs_loss_up_workspace_bytes(ds), FS_ERR_INVALID,
+               "fs_kl_distill_up_bwd: workspace of %lld bytes needed (fs_loss_up_workspace_bytes)", fs_loss_up_workspace_bytes(ds));
     hipStream_t st = (hipStream_t)stream;
-#define FS_KL_BWD(TS, TT) hipLaunchKernelGGL((kl_up_bwd_kernel<TS, TT>), grid, dim3(256), 0, st, (const TS*)student_lo, gs, (const TT*)teacher_lo, gt, lse_s, lse_t, scale, (TS*)d_student_lo)
+#define FS_KL_BWD(TS, TT) launch_up_bwd<TS, TT, false>(st, gs, student_lo, gt, teacher_lo, lse_s, lse_t, nullptr, nullptr, scale, workspace, d_student_lo)
     if (ds->dtype == FS_F32 && dt->dtype == FS_F32) FS_KL_BWD(float, float);
     else if (ds->dtype == FS_F32) FS_KL_BWD(float, bf16_t);
     else if (dt->dtype == FS_F32) FS_KL_BWD(bf16_t, float);

@@ -102,6 +102,14 @@ def _logits_desc(x, size):
     return LogitsDesc(N, h, w, C, cs, int(size[0]), int(size[1]), K.dtype_code(x.dtype))
 
 
+def _up_workspace(d, device):
+    """Scratch of the two-launch backward (per-cell corner sums), fs_loss_up_workspace_bytes."""
+    import ctypes
+    from . import _lib
+    n = int(_lib.lib().fs_loss_up_workspace_bytes(ctypes.byref(d)))
+    return torch.empty(n // 4, dtype=torch.float32, device=device)
+
+
 class _OhemCEUp(torch.autograd.Function):
     """_OhemCE on the bilinear up-sample of low-resolution logits, without the up-sampled tensor (fs_ohem_ce_up_fwd/_bwd):
     ProbOhemCrossEntropy2d(F.interpolate(pred_lo, size, 'bilinear', align_corners=True), target)
@@ -142,7 +150,9 @@ class _OhemCEUp(torch.autograd.Function):
         d = ctx.desc
         scale = (g.float() / count).reshape(1).contiguous()
         dx = K.empty_nhwc(d.N, d.C, d.h, d.w, x.dtype, x.device, cs=d.cs)
-        K.call("fs_ohem_ce_up_bwd", K._stream(), ctypes.byref(d), K._p(x), K._p(tgt), K._p(lse), K._p(kept), K._p(scale), K._p(dx))
+        ws = _up_workspace(d, x.device)
+        K.call("fs_ohem_ce_up_bwd", K._stream(), ctypes.byref(d), K._p(x), K._p(tgt), K._p(lse), K._p(kept), K._p(scale), K._p(dx),
+               K._p(ws), ws.numel() * 4)
         return dx, None, None, None, None
 
 
@@ -170,8 +180,9 @@ class _DistillKLUp(torch.autograd.Function):
         ds, dt = ctx.descs
         scale = (g.float() / (ds.N * ds.H * ds.W * ds.C)).reshape(1).contiguous()
         dx = K.empty_nhwc(ds.N, ds.C, ds.h, ds.w, s.dtype, s.device, cs=ds.cs)
+        ws = _up_workspace(ds, s.device)
         K.call("fs_kl_distill_up_bwd", K._stream(), ctypes.byref(ds), K._p(s), ctypes.byref(dt), K._p(t), K._p(buf[1]), K._p(buf[2]),
-               K._p(scale), K._p(dx))
+               K._p(scale), K._p(dx), K._p(ws), ws.numel() * 4)
         return dx, None, None
 
 

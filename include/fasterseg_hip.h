@@ -76,7 +76,7 @@ typedef struct fs_resize_desc {
 const char* fs_last_error(void);
 /* ABI revision of this header; fs_version() returns the one the library was built from.  Bindings check both this and
  * fs_struct_size() when they load the library (fasterseg_amd/_lib.py) - a stale .so must not be used silently. */
-#define FS_ABI_VERSION 201
+#define FS_ABI_VERSION 202
 int fs_version(void);
 int fs_struct_size(int which);   /* 0 fs_conv_desc, 1 fs_resize_desc, 2 fs_zoom_desc, 3 fs_sgd_tensor, 4 fs_logits_desc; -1 otherwise */
 /* test hook: force the tile configuration of fs_conv2d_fwd (0..6; -1 = heuristic).  Not for production use. */
@@ -382,8 +382,10 @@ int fs_census_read(fs_census_entry* out, int max_entries);      /* fills up to m
 /* The same two criteria computed straight from the LOW-resolution NHWC logits of a head: the bilinear (align_corners=True)
  * up-sample to (H, W) of train/model_seg.py:357-362 is evaluated per full-resolution pixel inside the kernels, so the
  * (B, 19, H, W) fp32 tensors (478 MB each at 12 x 512 x 1024) are never written.  Per-pixel outputs are indexed
- * p = (n * H + Y) * W + X.  The backward kernels are gathers (one wave per low-resolution pixel): deterministic, no atomics;
- * they write every channel of the low-resolution gradient (pad channels = 0). */
+ * p = (n * H + Y) * W + X.  The backward entry points run two launches - per-cell partial sums into `workspace`
+ * (fs_loss_up_workspace_bytes(d) bytes: N*h*w cells x 4 corners x 20 classes of fp32), then a gather per low-resolution pixel:
+ * every full-resolution pixel is evaluated once, no atomics, fixed summation order; they write every channel of the
+ * low-resolution gradient (pad channels = 0). */
 typedef struct fs_logits_desc {
     int N, h, w;            /* low-resolution logits (N, h, w, C), NHWC                              */
     int C, cs;              /* classes (<= 20) and channel stride (multiple of 4, C <= cs <= 64)     */
@@ -393,13 +395,16 @@ typedef struct fs_logits_desc {
 fs_status fs_ohem_ce_up_fwd(void* stream, const fs_logits_desc* d, const void* logits_lo, const long long* target, int ignore,
                             float* true_prob, float* nll, float* lse);
 /* dlogits_lo[n,i,j,c] = (*scale) * sum over kept pixels p of w(p -> i,j) * (softmax_c(p) - [c == target p]) */
+long long fs_loss_up_workspace_bytes(const fs_logits_desc* d);
 fs_status fs_ohem_ce_up_bwd(void* stream, const fs_logits_desc* d, const void* logits_lo, const long long* target, const float* lse,
-                            const unsigned char* kept, const float* scale, void* dlogits_lo);
+                            const unsigned char* kept, const float* scale, void* dlogits_lo, float* workspace,
+                            long long workspace_bytes);
 /* student and teacher may come at different low resolutions / dtypes; both are up-sampled to the same (H, W) */
 fs_status fs_kl_distill_up_fwd(void* stream, const fs_logits_desc* ds, const void* student_lo, const fs_logits_desc* dt,
                                const void* teacher_lo, float* kl, float* lse_s, float* lse_t);
 fs_status fs_kl_distill_up_bwd(void* stream, const fs_logits_desc* ds, const void* student_lo, const fs_logits_desc* dt,
-                               const void* teacher_lo, const float* lse_s, const float* lse_t, const float* scale, void* d_student_lo);
+                               const void* teacher_lo, const float* lse_s, const float* lse_t, const float* scale, void* d_student_lo,
+                               float* workspace, long long workspace_bytes);   /* workspace sized for ds */
 
 /* --- command-list executor ------------------------------------------------------------------------ */
 /* Replays a pre-built sequence of the launches above from one host call (csrc/program.hip describes the word encoding).
