@@ -142,3 +142,40 @@ def test_executor_rejects_malformed_programs():
         arr = (ctypes.c_longlong * len(words))(*words)
         assert lib.fs_exec_program(None, arr, len(words), blob, slots, program.N_SLOTS) == 1     # FS_ERR_INVALID
         assert b"fs_exec_program" in lib.fs_last_error()
+
+
+def test_lowering_with_bn_groups_sizes_the_per_group_buffers():
+    """groups=2 (one evaluation of the MixedOp on the batched from-down / from-keep pair): every fused unit's descriptor carries
+    bn_groups=2, the statistics / saved-moments / backward-reduction buffers are sized per group, and the FactorizedReduce BN
+    goes through the grouped BN unit ops."""
+    import ctypes
+    from fasterseg_amd._lib import ConvDesc
+    torch.manual_seed(0)
+    m = model_search.MixedOp(48, 96, stride=2, width_mult_list=WIDTHS).train()
+    for p in m.parameters():
+        p.requires_grad_(False)
+    m.set_prun_ratio((8. / 12, 10. / 12))
+    progs = {}
+    for g in (1, 2):
+        progs[g] = program.lower_mixed_op(m, (2 * g, 32, 16, 24), 32, torch.float32, torch.device("cpu"), need_x=True, need_coef=True,
+                                          want_w=False, sink=None, groups=g)
+    one, two = progs[1], progs[2]
+    assert two.out_shape[0] == 4 and two.out_shape[1:] == one.out_shape[1:]
+    assert two.n_launches == one.n_launches                      # same launches, twice the batch
+
+    def descs(prog):
+        fwd = decode(prog.f_words, prog.f_n, {program.SAVE: prog.save_bytes, program.TMPF: prog.tmpf_bytes})
+        out = []
+        for op, args in fwd:
+            if op == program.OP_UNIT_FWD:
+                off = args[0][1]
+                out.append(ConvDesc.from_buffer_copy(bytes(prog.f_blob)[off:off + ctypes.sizeof(ConvDesc)]))
+        return out, fwd
+    d1, f1 = descs(one)
+    d2, f2 = descs(two)
+    assert [d.bn_groups for d in d1] == [1] * len(d1) and [d.bn_groups for d in d2] == [2] * len(d2)
+    assert all(b.N == 2 * a.N and (b.Cin, b.Cout, b.H, b.W) == (a.Cin, a.Cout, a.H, a.W) for a, b in zip(d1, d2))
+    g1 = [args[2][1] for op, args in f1 if op == program.OP_BN_UNIT_FWD]
+    g2 = [args[2][1] for op, args in f2 if op == program.OP_BN_UNIT_FWD]
+    assert g1 == [1] and g2 == [2]
+    assert two.save_bytes > one.save_bytes and two.tmpb_bytes > one.tmpb_bytes
