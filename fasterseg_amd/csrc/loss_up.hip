@@ -15,7 +15,8 @@
 //              ALU: interpolate, softmax gradient) and reduces its contributions to the four corners in a fixed order into
 //              workspace[cell][corner][class]; (2) a gather adds, per low-resolution pixel, the matching corners of its (up to)
 //              four cells.  The first version gathered per low-resolution pixel and re-evaluated every full-resolution pixel
-//              four times inside divergent loops: 565 us (OHEM) / 1057 us (KL) per launch on the student step's heads.
+//              four times inside divergent loops: 565 us (OHEM, mean of the three heads) / 1057 us (KL) per launch on the
+//              student step's heads; now 491 / 528 / 184 us (x8 / x16 / x32 OHEM) and 592 us (KL), still latency-bound.
 #include "common.h"
 
 namespace fs {
@@ -173,48 +174,8 @@ __device__ __forceinline__ void cell_sweep(float (&S)[16], float sign, int c0, c
     }
 }
 
-// The pixels a lane owns in its cell, loaded ONCE (interpolation weights, log-sum-exps, label, OHEM mask): the class-quad loop of
-// the common case - every lane owns at most MAXP pixels - then touches memory only for the four corner vectors of the quad.
-template <int MAXP>
-struct CellPixels {
-    float h0[MAXP], h1[MAXP], w0[MAXP], w1[MAXP];     // tap weights, already multiplied by keep (0 / 1) on the h side
-    float ls[MAXP], lt[MAXP];
-    int t[MAXP];
-};
-
-template <typename T, bool OHEM, int MAXP>
-__device__ __forceinline__ void cell_quad(float (&S)[16], float sign, int c0, const T* __restrict__ lo, const UpGeom& g, int n, int i,
-                                          int j, const CellPixels<MAXP>& px, const float (&lse)[MAXP]) {
-    float L[4][4];
-    const int i1 = i + (i < g.h - 1 ? 1 : 0), j1 = j + (j < g.w - 1 ? 1 : 0);
-    const T* r0 = lo + ((long long)n * g.h + i) * g.w * g.cs + c0;
-    const T* r1 = lo + ((long long)n * g.h + i1) * g.w * g.cs + c0;
-    QuadL<T>::load(r0 + (long long)j * g.cs, L[0]);
-    QuadL<T>::load(r0 + (long long)j1 * g.cs, L[1]);
-    QuadL<T>::load(r1 + (long long)j * g.cs, L[2]);
-    QuadL<T>::load(r1 + (long long)j1 * g.cs, L[3]);
-#pragma unroll
-    for (int m = 0; m < MAXP; ++m) {
-        // a lane without an m-th pixel (or a pixel OHEM dropped) has h0 = h1 = 0 and contributes nothing
-        float v[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-            v[c] = px.h0[m] * (px.w0[m] * L[0][c] + px.w1[m] * L[1][c]) + px.h1[m] * (px.w0[m] * L[2][c] + px.w1[m] * L[3][c]);
-        const float w00 = sign * px.h0[m] * px.w0[m], w01 = sign * px.h0[m] * px.w1[m];
-        const float w10 = sign * px.h1[m] * px.w0[m], w11 = sign * px.h1[m] * px.w1[m];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float gv = (c0 + c < g.C) ? expf(v[c] - lse[m]) - ((OHEM && c0 + c == px.t[m]) ? 1.f : 0.f) : 0.f;
-            S[c] += w00 * gv;
-            S[4 + c] += w01 * gv;
-            S[8 + c] += w10 * gv;
-            S[12 + c] += w11 * gv;
-        }
-    }
-}
-
 // WAVES = 1: four cells per block, one wave each; WAVES = 4: one cell per block.  KL: second sweep over the teacher.
-template <typename TS, typename TT, bool OHEM, int WAVES, int MAXP>
+template <typename TS, typename TT, bool OHEM, int WAVES>
 __global__ __launch_bounds__(256) void up_bwd_cells_kernel(const TS* __restrict__ s_lo, UpGeom g, const TT* __restrict__ t_lo, UpGeom gt,
                                                            const float* __restrict__ lse_s, const float* __restrict__ lse_t,
                                                            const long long* __restrict__ target,
@@ -233,45 +194,14 @@ __global__ __launch_bounds__(256) void up_bwd_cells_kernel(const TS* __restrict_
     const int ny = live ? Yb - Ya : 0, nx = Xb - Xa;
     const int first = WAVES == 1 ? lane : (int)threadIdx.x, step = WAVES == 1 ? 64 : 256;
     const bool same = gt.h == g.h && gt.w == g.w;
-    const int count = ny * nx;
-    // common case (wave-uniform for WAVES = 1, block-uniform for WAVES = 4): per-pixel data in registers
-    // (MAXP = 0 compiles the register-resident path out: measured on the student step's heads, x32 cells 348 -> 184 us with
-    // it, x16 cells 348 -> 529 us and x8 cells 484 -> 506 us against it - its registers cost more occupancy than its loads save)
-    const bool fast = MAXP > 0 && count <= MAXP * step && (OHEM || same);
-    CellPixels<(MAXP > 0 ? MAXP : 1)> px;
-    if constexpr (MAXP > 0) if (fast) {
-#pragma unroll
-        for (int m = 0; m < MAXP; ++m) {
-            const int k = first + m * step;
-            const bool has = k < count;
-            const int kk = has ? k : 0;
-            const int dy_ = nx > 0 ? kk / nx : 0;
-            const int Y = Ya + dy_, X = Xa + (kk - dy_ * nx);
-            const long long p = has ? ((long long)n * g.H + Y) * g.W + X : 0;
-            const Tap th = make_tap(g.rh, Y, g.h), tw = make_tap(g.rw, X, g.w);
-            const float keep = has ? (OHEM ? (kept[p] ? 1.f : 0.f) : 1.f) : 0.f;
-            px.h0[m] = keep * th.l0; px.h1[m] = keep * th.l1; px.w0[m] = tw.l0; px.w1[m] = tw.l1;
-            px.ls[m] = lse_s[p];
-            px.lt[m] = OHEM ? 0.f : lse_t[p];
-            px.t[m] = OHEM ? (int)target[p] : -1;
-        }
-    }
     for (int c0 = 0; c0 < g.C; c0 += 4) {
         float S[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) S[k] = 0.f;
-        if constexpr (MAXP > 0) {
-            if (fast) {
-                cell_quad<TS, OHEM, MAXP>(S, 1.f, c0, s_lo, g, n, i, j, px, px.ls);
-                if (!OHEM) cell_quad<TT, false, MAXP>(S, -1.f, c0, t_lo, gt, n, i, j, px, px.lt);
-            }
-        }
-        if (!fast) {
-            cell_sweep<TS, OHEM, true>(S, 1.f, c0, s_lo, g, g, n, i, j, Ya, ny, Xa, nx, first, step, lse_s, target, kept);
-            if (!OHEM) {
-                if (same) cell_sweep<TT, false, true>(S, -1.f, c0, t_lo, gt, g, n, i, j, Ya, ny, Xa, nx, first, step, lse_t, nullptr, nullptr);
-                else cell_sweep<TT, false, false>(S, -1.f, c0, t_lo, gt, g, n, i, j, Ya, ny, Xa, nx, first, step, lse_t, nullptr, nullptr);
-            }
+        cell_sweep<TS, OHEM, true>(S, 1.f, c0, s_lo, g, g, n, i, j, Ya, ny, Xa, nx, first, step, lse_s, target, kept);
+        if (!OHEM) {
+            if (same) cell_sweep<TT, false, true>(S, -1.f, c0, t_lo, gt, g, n, i, j, Ya, ny, Xa, nx, first, step, lse_t, nullptr, nullptr);
+            else cell_sweep<TT, false, false>(S, -1.f, c0, t_lo, gt, g, n, i, j, Ya, ny, Xa, nx, first, step, lse_t, nullptr, nullptr);
         }
 #pragma unroll
         for (int k = 0; k < 16; ++k) S[k] = wave_sum(S[k]);
@@ -407,13 +337,10 @@ static void launch_up_bwd(hipStream_t st, const UpGeom& g, const void* s_lo, con
     const long long cells = (long long)g.N * g.h * g.w;
     const double area = ((double)g.H / g.h) * ((double)g.W / g.w);
     if (area <= 100.0)           // x8 heads: cells of 8-9 x 8-9 pixels, one wave each
-        hipLaunchKernelGGL((up_bwd_cells_kernel<TS, TT, OHEM, 1, 0>), dim3((unsigned)((cells + 3) / 4)), dim3(256), 0, st, (const TS*)s_lo, g,
+        hipLaunchKernelGGL((up_bwd_cells_kernel<TS, TT, OHEM, 1>), dim3((unsigned)((cells + 3) / 4)), dim3(256), 0, st, (const TS*)s_lo, g,
                            (const TT*)t_lo, gt, lse_s, lse_t, target, kept, ws);
-    else if (area <= 400.0)      // x16: up to 17 x 17 pixels over a block
-        hipLaunchKernelGGL((up_bwd_cells_kernel<TS, TT, OHEM, 4, 0>), dim3((unsigned)cells), dim3(256), 0, st, (const TS*)s_lo, g,
-                           (const TT*)t_lo, gt, lse_s, lse_t, target, kept, ws);
-    else                         // x32: up to 33 x 33 pixels, five per lane held in registers; anything larger takes the looped path
-        hipLaunchKernelGGL((up_bwd_cells_kernel<TS, TT, OHEM, 4, 5>), dim3((unsigned)cells), dim3(256), 0, st, (const TS*)s_lo, g,
+    else                         // x16 / x32: 17 x 17 / 33 x 33 pixels over a block
+        hipLaunchKernelGGL((up_bwd_cells_kernel<TS, TT, OHEM, 4>), dim3((unsigned)cells), dim3(256), 0, st, (const TS*)s_lo, g,
                            (const TT*)t_lo, gt, lse_s, lse_t, target, kept, ws);
     hipLaunchKernelGGL((up_bwd_gather_kernel<TS>), dim3(pixel_blocks(cells * g.cs)), dim3(256), 0, st, ws, g, scale, (TS*)dlo);
 }

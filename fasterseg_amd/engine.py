@@ -95,6 +95,17 @@ class InferenceEngine:
         # the geometry is supported, "auto" (default) = time the fused launch against the separate launches per cell at build
         self.fuse_cells = os.environ.get("FS_ENGINE_FUSE_CELLS", "auto" if fuse_cells is None else str(fuse_cells))
         self.cell_log = []
+        # FS_ENGINE_PLAN=<file>: tune once, reuse - the per-layer kernel choices and the per-cell fused / separate choices are
+        # written to <file>.<output> after a build that timed them and read back by later builds instead of timing (a plan
+        # tuned on an idle device can be replayed under a profiler, whose counters perturb the timings it would otherwise tune on)
+        self._plan_path = os.environ.get("FS_ENGINE_PLAN")
+        self._plan_in, self._plan_out = None, {"convs": [], "cells": []}
+        if self._plan_path:
+            self._plan_path = "%s.%s.%s" % (self._plan_path, output, "bf16" if dtype == torch.bfloat16 else "fp32")
+            if os.path.exists(self._plan_path):
+                import json
+                with open(self._plan_path) as f:
+                    self._plan_in = json.load(f)
         self._trace(net)
         self._fuse_cells()
         self._fuse_resizes()
@@ -102,10 +113,15 @@ class InferenceEngine:
         self._lower()
         self.graph = None
         if use_graph:
-            if self.fuse_cells == "auto":
+            if self.fuse_cells == "auto" and self._plan_in is None:
                 self._warm()
                 self._tune_cells()
             self._capture()
+        if self._plan_path and self._plan_in is None:
+            import json
+            self._plan_out["cells"] = [g["choice"] for g in self.groups if len(g["variants"]) > 1]
+            with open(self._plan_path, "w") as f:
+                json.dump(self._plan_out, f)
 
     # ---- 1. trace ----------------------------------------------------------------------------------
     def _trace(self, net):
@@ -368,8 +384,14 @@ class InferenceEngine:
         if halo_ok and self.autotune and N * Ho * Wo >= 512:
             cands = [("halo", variant(True)), ("igemm", variant(False))]
             cands += [("halo%d" % t, variant(True, t)) for t in (32, 64, 128) if t <= max(32, K.round_up(cout, 32)) * 2 and t <= 128]
-            timed = [(self._time_call(v[0], v[1]), name, v) for name, v in cands]
-            best = min(timed, key=lambda tv: tv[0])
+            if self._plan_in is not None:
+                want = self._plan_in["convs"][len(self._plan_out["convs"])]
+                best = (0.0, want, dict(cands)[want])
+                timed = []
+            else:
+                timed = [(self._time_call(v[0], v[1]), name, v) for name, v in cands]
+                best = min(timed, key=lambda tv: tv[0])
+            self._plan_out["convs"].append(best[1])
             self.autotuned.append((label, N * H * W, cin, cout, best[1], [(nm, round(t * 1e3, 2)) for t, nm, _ in timed]))
             fn, args, wp, dsel = best[2]
         self._keep.append(wp)
@@ -468,8 +490,12 @@ class InferenceEngine:
         del self.calls[first:]
         # prior from isolated (cache-warm) timings; _tune_cells() then decides on whole-frame time, where the filter banks and
         # the input are cold as they are in production
-        t_fused, t_chain = self._time_calls([fused]), self._time_calls(chain)
-        keep_fused = t_fused <= t_chain
+        if self._plan_in is not None:
+            t_fused = t_chain = 0.0
+            keep_fused = self._plan_in["cells"][len(self.cell_log)] == 0
+        else:
+            t_fused, t_chain = self._time_calls([fused]), self._time_calls(chain)
+            keep_fused = t_fused <= t_chain
         self.cell_log.append([fused["label"], "fused" if keep_fused else "split", round(t_fused * 1e3, 2), round(t_chain * 1e3, 2)])
         self.calls += [fused] if keep_fused else chain
         return dict(variants=[[fused], chain], choice=0 if keep_fused else 1, log=self.cell_log[-1])

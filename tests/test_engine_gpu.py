@@ -111,3 +111,24 @@ def test_teacher_engine_matches_eager_operator_path():
             eng = engine.InferenceEngine(net, shape, dtype=torch.float32, fuse_cells=cells)
             got = eng(x).float().cpu()
             assert float((got - want).abs().max()) <= 1e-3, (cells, float((got - want).abs().max()))
+
+
+def test_engine_plan_file_reproduces_the_tuned_plan(tmp_path, monkeypatch):
+    """FS_ENGINE_PLAN: the build that tunes writes its per-layer / per-cell choices, a later build reads them back instead of
+    timing and issues the same launches (and the same logits)."""
+    from fasterseg_amd import engine
+    shape = (1, 3, 256, 512)
+    net, x, want = _student(shape)
+    monkeypatch.setenv("FS_ENGINE_PLAN", str(tmp_path / "plan.json"))
+    with torch.no_grad():
+        a = engine.InferenceEngine(net, shape, dtype=torch.bfloat16)
+        ga = a(x.cuda()).clone()
+        assert os.path.exists(str(tmp_path / "plan.json") + ".logits.bf16")
+        b = engine.InferenceEngine(net, shape, dtype=torch.bfloat16)
+        gb = b(x.cuda()).clone()
+        torch.cuda.synchronize()
+    assert b._plan_in is not None and a._plan_in is None
+    assert sorted(c["label"] + c["fn"] for c in a.calls) == sorted(c["label"] + c["fn"] for c in b.calls)
+    assert [t[4] for t in a.autotuned] == [t[4] for t in b.autotuned]
+    assert torch.equal(ga, gb)
+    _check(gb, want, torch.bfloat16, "engine rebuilt from its plan file")

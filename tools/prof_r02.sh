@@ -13,10 +13,15 @@ if [ $what = all ] || [ $what = tests ]; then
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/r02_smoke.log 2>&1; tail -1 $O/r02_smoke.log
 fi
 if [ $what = all ] || [ $what = bench ]; then
-  timeout 900 python bench.py --dump-plan $O/r02_c2_plan_bf16.json > $O/r02_bench_default.json 2> $O/r02_bench_default.err
+  timeout 900 python bench.py > $O/r02_bench_default.json 2> $O/r02_bench_default.err
   python scratch/extract_bench.py $O/r02_bench_default.json
 fi
 if [ $what = all ] || [ $what = c2prof ]; then
+  # tune the plan once on the idle device, then replay exactly that plan under the profiler (FS_ENGINE_PLAN)
+  export FS_ENGINE_PLAN=$O/r02_c2_plan_choices.json
+  rm -f $FS_ENGINE_PLAN.*
+  timeout 300 python bench.py --workloads c2 --no-cpu-baseline --no-class-map --dump-plan $O/r02_c2_plan_bf16.json > $O/r02_bench_c2_planned.json 2>/dev/null
+  python scratch/extract_c2.py $O/r02_bench_c2_planned.json
   cd /tmp
   prof() {  # name, steps, rocprof args...
     name=$1; shift; steps=$1; shift
@@ -32,6 +37,7 @@ if [ $what = all ] || [ $what = c2prof ]; then
   python $R/tools/pmc_traffic.py $F $W bf16 $O/r02_pmc_traffic.json
   tail -3000 $F > $O/r02_c2_infer_bf16_pmc_FETCH_SIZE_tail.csv; tail -3000 $W > $O/r02_c2_infer_bf16_pmc_WRITE_SIZE_tail.csv
   head -1 $F > $O/r02_pmc_header.csv
+  unset FS_ENGINE_PLAN
   cd $R
 fi
 if [ $what = all ] || [ $what = steps ]; then
