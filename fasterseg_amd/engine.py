@@ -823,6 +823,9 @@ class InferenceEngine:
              len(self._prog_slots))
 
     def __del__(self):
+        import sys
+        if sys.is_finalizing():        # interpreter shutdown: the HIP runtime may already be gone, leave the events to the process exit
+            return
         try:
             lib = _lib.lib()
             for ev in getattr(self, "_events", []):

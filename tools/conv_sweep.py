@@ -6,7 +6,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from fasterseg_amd import kernels as K, _lib
 lib = _lib.lib()
 shapes = [(3, 96, 96, 32, 64), (3, 192, 192, 16, 32), (3, 384, 384, 8, 16), (3, 96, 96, 16, 32), (3, 192, 192, 8, 16), (3, 384, 384, 4, 8),
-          (3, 64, 80, 32, 64), (3, 32, 32, 32, 64), (2, 96, 96, 28, 56), (2, 192, 192, 14, 28), (2, 384, 384, 7, 14), (3, 192, 96, 32, 64)]
+          (3, 64, 80, 32, 64), (3, 32, 32, 32, 64), (2, 96, 96, 28, 56), (2, 192, 192, 14, 28), (2, 384, 384, 7, 14), (3, 192, 96, 32, 64),
+          # round 2: the from-down / from-keep pair of a cell evaluated as one batch (N = 6 pretrain, 4 search)
+          (6, 192, 192, 16, 32), (6, 384, 384, 8, 16), (6, 192, 192, 8, 16), (6, 384, 384, 4, 8), (4, 192, 192, 14, 28), (4, 384, 384, 7, 14),
+          (4, 192, 192, 7, 14), (4, 160, 128, 14, 28)]
+DTYPES = [torch.bfloat16] if os.environ.get("FS_SWEEP_DTYPE") == "bf16" else [torch.float32, torch.bfloat16]
 def bench(fn, iters=200):
     for _ in range(10): fn()
     torch.cuda.synchronize()
@@ -23,7 +27,7 @@ def bench(fn, iters=200):
     for _ in range(iters // 20): g.replay()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
-for dtype in (torch.float32, torch.bfloat16):
+for dtype in DTYPES:
     print("====", dtype)
     for (N, cin, cout, H, W) in shapes:
         x = K.to_nhwc(torch.randn(N, cin, H, W, device="cuda"), dtype)
