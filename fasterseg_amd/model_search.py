@@ -306,6 +306,9 @@ class MixedOp(nn.Module):
 
 
 _latency_vectors = {}      # (five LUT latencies, device, dtype) -> device vector
+# forward_latency(beta=False) as one dot product over tabulated LUT rows (Network_Multi_Path._forward_latency_linear);
+# FS_LINEAR_LATENCY=0 keeps the per-MixedOp evaluation for every call.
+_LINEAR_LATENCY = bool(int(os.environ.get("FS_LINEAR_LATENCY", "1")))
 _SAMPLED = object()        # stands in for a sampled width in _cell_ratio probes
 
 
@@ -354,6 +357,28 @@ def _weighted_sum(weights, tensors):
     for k in live:
         acc = FN.scale_accumulate(acc, tensors[k], weights[k])
     return acc
+
+
+class _Lin:
+    """A linear form sum_e coef[e] * x_e + const over the MixedOp latencies x_e (forward_latency with constant betas)."""
+    __slots__ = ("c", "k")
+
+    def __init__(self, c=None, k=0.0):
+        self.c, self.k = (c or {}), k
+
+    def __add__(self, o):
+        if isinstance(o, _Lin):
+            c = dict(self.c)
+            for e, v in o.c.items():
+                c[e] = c.get(e, 0.0) + v
+            return _Lin(c, self.k + o.k)
+        return _Lin(dict(self.c), self.k + float(o))
+    __radd__ = __add__
+
+    def __mul__(self, f):
+        f = float(f)
+        return _Lin({e: v * f for e, v in self.c.items()}, self.k * f)
+    __rmul__ = __mul__
 
 
 class Network_Multi_Path(nn.Module):
@@ -419,9 +444,10 @@ class Network_Multi_Path(nn.Module):
         return int(np.round(scale * self._Fch * width))
 
     # ------------------------------------------------------------------------------------------------------
-    def sample_prun_ratio(self, mode="arch_ratio"):
+    def sample_prun_ratio(self, mode="arch_ratio", read_indices=True):
         '''
         mode: "min"|"max"|"random"|"arch_ratio"(default)
+        read_indices=False (arch_ratio): leave the sampled width indices on the device (`_fs_index_t`), no host sync.
         '''
         assert mode in ["min", "max", "random", "arch_ratio"]
         counts = (self._layers - 1, self._layers - 1, self._layers - 2)
@@ -432,7 +458,7 @@ class Network_Multi_Path(nn.Module):
             # The reference reads `ratio.argmax()` on the host once per MixedOp (model_search.py:64-65): ~230 device syncs per
             # forward, each draining the launch queue.  Read all sampled indices back in ONE transfer instead.
             flat = [r for scale in ratios for r in scale]
-            if flat and flat[0].is_cuda and not torch.cuda.is_current_stream_capturing():
+            if read_indices and flat and flat[0].is_cuda and not torch.cuda.is_current_stream_capturing():
                 for r, k in zip(flat, torch.cat([r._fs_index_t for r in flat]).tolist()):
                     r._fs_index = k
             return ratios
@@ -540,7 +566,138 @@ class Network_Multi_Path(nn.Module):
         return tuple(FN.interpolate(p, size=(p.size(2), p.size(3)), out_nchw=1) for p in preds)
         ###################################
 
+    # ---- forward_latency with constant betas as ONE dot product ---------------------------------------------------------------
+    # With beta=False (two of the three calls of the architect's latency penalty, architect.py:66-72) the reference's layer
+    # recurrence (model_search.py:430-470) is LINEAR in the per-MixedOp latencies x_e = <LUT row, alpha row> * score_in * score_out
+    # with coefficients that depend only on the topology: total = const + <coef, x>.  The plan below derives coef once by running
+    # the same recurrence on linear forms, and tabulates the LUT rows of every width pair of every MixedOp on the device, so a call
+    # is ~15 tensor ops instead of ~500 scalar ones, and the Gumbel-width call needs NO host read-back of the sampled indices (the
+    # per-MixedOp path reads them to build its LUT keys: a device sync in the middle of the architecture step).
+    def _latency_plan(self, size):
+        from . import operations
+        lut = operations.latency_lookup_table
+        key = (self.arch_idx, tuple(size), len(lut), float(sum(lut.values())))
+        plans = self.__dict__.setdefault("_latency_plans", {})
+        if key in plans:
+            return plans[key]
+        k = self.arch_idx
+        W = self._width_mult_list
+        counts = (self._layers - 1, self._layers - 1, self._layers - 2)
+        offs = (0, counts[0], counts[0] + counts[1])
+        slot_probe = [[("slot", offs[s] + n) for n in range(counts[s])] for s in range(3)]
+        stem_latency, sz = 0.0, tuple(size)
+        for m in self.stem[k]:
+            latency, sz = m.forward_latency(sz)
+            stem_latency += float(latency)
+        evals, index = [], {}            # one variable per MixedOp that is evaluated
+
+        def variable(mixed, hw, r_in, r_out, alpha_row):
+            if id(mixed) not in index:
+                index[id(mixed)] = len(evals)
+                evals.append((mixed, hw, r_in, r_out, alpha_row))
+            return _Lin({index[id(mixed)]: 1.0})
+        alpha_off = (0, self._layers, 2 * self._layers - 1)
+        hw_prev = [[(sz[1], sz[2]), None]]
+        T = [[_Lin(k=stem_latency), _Lin()], [_Lin(), _Lin()], [_Lin(), _Lin()]]
+        half = 0.5                                                   # the constant betas (`_arch_tensors(beta=False)`)
+        for i, cells in enumerate(self.cells):
+            hw_out, latency = [], []
+            for j, cell in enumerate(cells):
+                r = self._cell_ratio(i, j, slot_probe)
+                row = alpha_off[j] + (i - j)
+                if j == 0 or i == j:
+                    hw = hw_prev[0][0] if j == 0 else hw_prev[j - 1][1]
+                    o = variable(cell._op, hw, r[0], r[1], row)
+                    d = variable(cell.downsample, hw, r[0], r[2], row) if cell._down else None
+                    hw_out.append((hw, (hw[0] // 2, hw[1] // 2) if cell._down else None))
+                    latency.append([o, d])
+                else:           # from down (0) and from keep (1): the same MixedOp on inputs of one size, weights b0 + b1
+                    hw = hw_prev[j][0]
+                    assert hw_prev[j - 1][1] == hw
+                    o = variable(cell._op, hw, r[0], r[1], row)
+                    d = variable(cell.downsample, hw, r[0], r[2], row) if cell._down else None
+                    hw_out.append((hw, (hw[0] // 2, hw[1] // 2) if cell._down else None))
+                    latency.append([half * o + half * o, (half * d + half * d) if d is not None else _Lin()])
+            hw_prev = hw_out
+            for ii, lat in enumerate(latency):          # the reference's recurrence, including its use of the leftover `j`
+                if ii == 0:
+                    if lat[0] is not None: T[ii][0] = T[ii][0] + lat[0]
+                    if lat[1] is not None: T[ii][1] = T[ii][0] + lat[1]
+                elif i == ii:
+                    if lat[0] is not None: T[ii][0] = T[ii - 1][1] + lat[0]
+                    if lat[1] is not None: T[ii][1] = T[ii - 1][1] + lat[1]
+                else:
+                    if lat[0] is not None: T[ii][0] = half * T[ii][0] + half * T[ii - 1][1] + lat[0]
+                    if lat[1] is not None: T[ii][1] = half * T[ii][0] + half * T[ii - 1][1] + lat[1]
+        total = T[0][0] + T[1][0] + T[2][0]
+        E, nW = len(evals), len(W)
+        n_slots = sum(counts)
+        table = torch.zeros(E, nW * nW, len(PRIMITIVES))
+        slot_in, slot_out, n_out = [], [], []
+        for e, (mixed, hw, r_in, r_out, _) in enumerate(evals):
+            opts_in = list(W) if isinstance(r_in, tuple) else [r_in]
+            opts_out = list(W) if isinstance(r_out, tuple) else [r_out]
+            slot_in.append(r_in[1] if isinstance(r_in, tuple) else n_slots)       # n_slots: the fixed-width pseudo slot
+            slot_out.append(r_out[1] if isinstance(r_out, tuple) else n_slots)
+            n_out.append(len(opts_out))
+            for a, w0 in enumerate(opts_in):
+                for b, w1 in enumerate(opts_out):
+                    mixed.set_prun_ratio((w0, w1))
+                    for q, op in enumerate(mixed._ops):
+                        table[e, a * len(opts_out) + b, q] = float(op.forward_latency((int(op.C_in * w0), hw[0], hw[1]))[0])
+        dev = getattr(self, self._arch_names[k]["alphas"][0]).device
+        coef = torch.tensor([total.c.get(e, 0.0) for e in range(E)], dtype=torch.float32)
+        plan = dict(E=E, const=float(total.k), coef=coef.to(dev), table=table.to(dev),
+                    slot_in=torch.tensor(slot_in, device=dev), slot_out=torch.tensor(slot_out, device=dev),
+                    n_out=torch.tensor(n_out, device=dev), alpha_rows=torch.tensor([ev[4] for ev in evals], device=dev),
+                    rows=torch.arange(E, device=dev), n_slots=n_slots, fixed={})
+        plans[key] = plan
+        return plan
+
+    def _forward_latency_linear(self, size, alpha, ratio):
+        k = self.arch_idx
+        plan = self._latency_plan(size)
+        mode = "max"
+        if ratio:
+            mode = self.prun_mode if self.prun_mode is not None else self._prun_modes[k]
+        dev = plan["coef"].device
+        nW = len(self._width_mult_list)
+        scores = None
+        if mode == "arch_ratio":
+            ratios = self.sample_prun_ratio(mode=mode, read_indices=False)          # same RNG draws as the per-MixedOp path
+            flat = [r for scale in ratios for r in scale]
+            idx = torch.cat([r._fs_index_t for r in flat])                          # sampled width index per slot, on the device
+            R = torch.stack(flat)                                                   # straight-through one-hots [slots, widths]
+            score = R.gather(1, idx[:, None]).squeeze(1)                            # = ratio[k] of `_width_and_score`
+            idx_ext = torch.cat([idx, idx.new_zeros(1)])
+            scores = torch.cat([score, score.new_ones(1)])
+            k_in, k_out = idx_ext[plan["slot_in"]], idx_ext[plan["slot_out"]]
+            L = plan["table"][plan["rows"], k_in * plan["n_out"] + k_out]
+        else:
+            if mode not in ("max", "min"):
+                return None                                                         # host-sampled widths: per-MixedOp path
+            if mode not in plan["fixed"]:
+                w = 0 if mode == "min" else nW - 1
+                idx_ext = torch.full((plan["n_slots"] + 1,), w, device=dev)
+                idx_ext[-1] = 0
+                k_in, k_out = idx_ext[plan["slot_in"]], idx_ext[plan["slot_out"]]
+                plan["fixed"][mode] = plan["table"][plan["rows"], k_in * plan["n_out"] + k_out]
+            L = plan["fixed"][mode]
+        if alpha:
+            names = self._arch_names[k]["alphas"]
+            A = torch.cat([F.softmax(getattr(self, n), dim=-1) for n in names])[plan["alpha_rows"]]
+            x = (L * A).sum(1)
+        else:
+            x = L.sum(1) * (1. / len(PRIMITIVES))
+        if scores is not None:
+            x = x * scores[plan["slot_in"]] * scores[plan["slot_out"]]
+        return plan["const"] + (plan["coef"] * x).sum()
+
     def forward_latency(self, size, alpha=True, beta=True, ratio=True):
+        if not beta and _LINEAR_LATENCY:
+            fast = self._forward_latency_linear(size, alpha, ratio)
+            if fast is not None:
+                return fast
         k = self.arch_idx
         stem = self.stem[k]
         alphas, betas = self._arch_tensors(alpha, beta)

@@ -67,6 +67,47 @@ def test_forward_latency_matches_reference():
         operations.latency_lookup_table.update(saved)
 
 
+@pytest.mark.parametrize("arch_idx", [0, 1])
+def test_linear_latency_equals_per_mixedop_evaluation(arch_idx):
+    """forward_latency(beta=False) as one dot product over tabulated LUT rows (no host read-back of the Gumbel widths) against
+    the per-MixedOp evaluation it replaces: same value, same gradients w.r.t. alpha and ratio, on perturbed architecture
+    parameters, for the Gumbel ("arch_ratio", arch 1) and the fixed-width ("max", arch 0) modes."""
+    from fasterseg_amd import model_search, operations
+    saved = dict(operations.latency_lookup_table)
+    operations.latency_lookup_table.clear()
+    operations.latency_lookup_table.update(load_json("latency_lut_1080ti.json"))
+    flag = model_search._LINEAR_LATENCY
+    try:
+        net = build()
+        g = torch.Generator().manual_seed(4)
+        for p in net._arch_parameters[arch_idx]:
+            p.data.add_(torch.randn(p.shape, generator=g) * 0.5)
+        net.arch_idx = arch_idx
+        net.prun_mode = None
+        for a, r in ((True, False), (False, True), (True, True), (False, False)):
+            got = []
+            for linear in (False, True):
+                model_search._LINEAR_LATENCY = linear
+                net.zero_grad()
+                torch.manual_seed(9)
+                lat = net.forward_latency((3, 1024, 2048), alpha=a, beta=False, ratio=r)
+                grads = {}
+                if torch.is_tensor(lat) and lat.requires_grad:
+                    lat.backward()
+                    grads = {n: getattr(net, n).grad.clone() for kind in ("alphas", "ratios") for n in net._arch_names[arch_idx][kind]
+                             if getattr(net, n).grad is not None}
+                got.append((float(lat.detach()) if torch.is_tensor(lat) else float(lat), grads))
+            (v0, g0), (v1, g1) = got
+            assert abs(v0 - v1) <= 2e-6 * abs(v0), (a, r, v0, v1)
+            assert set(g0) == set(g1), (a, r, sorted(g0), sorted(g1))
+            for n in g0:
+                assert torch.allclose(g0[n], g1[n], rtol=1e-4, atol=1e-6), (a, r, n, float((g0[n] - g1[n]).abs().max()))
+    finally:
+        model_search._LINEAR_LATENCY = flag
+        operations.latency_lookup_table.clear()
+        operations.latency_lookup_table.update(saved)
+
+
 def _rel_l2(got, store, key):
     want, step = golden_get(store, key)
     got = got.detach().float().cpu().numpy().reshape(-1)[::step]
