@@ -9,7 +9,7 @@
 #include "common.h"
 
 // Maps up to this many pixels per group take the one-launch column-owner BatchNorm (bn_col.hip).  Measured on MI355X
-// (scratch/bn_micro.py, bf16, launch + kernel): 96 px 6.3 vs 7.2 us for the two grid-wide launches, 384 px 7.6 vs 7.3, 1536 px
+// (tools/bn_micro.py, bf16, launch + kernel): 96 px 6.3 vs 7.2 us for the two grid-wide launches, 384 px 7.6 vs 7.3, 1536 px
 // 12.7 vs 7.5, 6144 px 36 vs 8.5 - one block per channel vector reads 16 bytes of every 128-byte line and streams at a few
 // GB/s, so beyond a few hundred pixels the two grid-wide passes win and stay.
 static const long long BN_COL_MAX_PIXELS = 512;

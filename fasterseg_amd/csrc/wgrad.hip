@@ -196,7 +196,7 @@ static fs_status wgrad_impl(void* stream, const fs_conv_desc* d, const void* x, 
     const int taps = d->R * d->S;
     const long long other = (long long)tiles_co * a.tiles_ci * taps;
     // Pixel slabs: every slab adds one fp32 atomic per gradient element, and on the supernet's maps (192 .. 12288 pixels, 96 - 384
-    // channels) those atomics were 40 % of the kernel at ~2k blocks of >= 4 chunks (scratch/wgrad_micro.py on MI355X, the nine
+    // channels) those atomics were 40 % of the kernel at ~2k blocks of >= 4 chunks (tools/wgrad_micro.py on MI355X, the nine
     // commonest C3 geometries weighted by their launch counts: 41.9 ms/step; plain stores instead of atomics: 24.6).  ~1k blocks
     // of >= 8 chunks: 34.7 ms; 512 / 4: 35.1; 256 / 8: 42.1; 4096 / 2: 65.5.  FS_WGRAD_BLOCKS / FS_WGRAD_MIN_CHUNKS override.
     static const int target_blocks = [] { const char* e = getenv("FS_WGRAD_BLOCKS"); return e && atoi(e) > 0 ? atoi(e) : 1024; }();

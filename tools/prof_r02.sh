@@ -14,14 +14,14 @@ if [ $what = all ] || [ $what = tests ]; then
 fi
 if [ $what = all ] || [ $what = bench ]; then
   timeout 900 python bench.py > $O/r02_bench_default.json 2> $O/r02_bench_default.err
-  python scratch/extract_bench.py $O/r02_bench_default.json
+  python tools/extract_bench.py $O/r02_bench_default.json
 fi
 if [ $what = all ] || [ $what = c2prof ]; then
   # tune the plan once on the idle device, then replay exactly that plan under the profiler (FS_ENGINE_PLAN)
   export FS_ENGINE_PLAN=$O/r02_c2_plan_choices.json
   rm -f $FS_ENGINE_PLAN.*
   timeout 300 python bench.py --workloads c2 --no-cpu-baseline --no-class-map --dump-plan $O/r02_c2_plan_bf16.json > $O/r02_bench_c2_planned.json 2>/dev/null
-  python scratch/extract_c2.py $O/r02_bench_c2_planned.json
+  python tools/extract_c2.py $O/r02_bench_c2_planned.json
   cd /tmp
   prof() {  # name, steps, rocprof args...
     name=$1; shift; steps=$1; shift
@@ -41,7 +41,7 @@ if [ $what = all ] || [ $what = c2prof ]; then
   cd $R
 fi
 if [ $what = all ] || [ $what = steps ]; then
-  bash scratch/gpu_prof_step.sh c3 3 r02_c3_supernet_pretrain_bf16 2>&1 | head -1
-  bash scratch/gpu_prof_step.sh c5 3 r02_c5_supernet_search_bf16 2>&1 | head -1
-  bash scratch/gpu_prof_step.sh c4 5 r02_c4_student_train_bf16 2>&1 | head -1
+  bash tools/prof_step.sh c3 3 r02_c3_supernet_pretrain_bf16 2>&1 | head -1
+  bash tools/prof_step.sh c5 3 r02_c5_supernet_search_bf16 2>&1 | head -1
+  bash tools/prof_step.sh c4 5 r02_c4_student_train_bf16 2>&1 | head -1
 fi
