@@ -647,7 +647,8 @@ class Network_Multi_Path(nn.Module):
                         table[e, a * len(opts_out) + b, q] = float(op.forward_latency((int(op.C_in * w0), hw[0], hw[1]))[0])
         dev = getattr(self, self._arch_names[k]["alphas"][0]).device
         coef = torch.tensor([total.c.get(e, 0.0) for e in range(E)], dtype=torch.float32)
-        plan = dict(E=E, const=float(total.k), coef=coef.to(dev), table=table.to(dev),
+        plan = dict(E=E, const=float(total.k), coef=coef.to(dev), table=table.to(dev), table_host=table, index=index,
+                    stem_latency=stem_latency, slots_host=(slot_in, slot_out, n_out),
                     slot_in=torch.tensor(slot_in, device=dev), slot_out=torch.tensor(slot_out, device=dev),
                     n_out=torch.tensor(n_out, device=dev), alpha_rows=torch.tensor([ev[4] for ev in evals], device=dev),
                     rows=torch.arange(E, device=dev), n_slots=n_slots, fixed={})
@@ -693,11 +694,97 @@ class Network_Multi_Path(nn.Module):
             x = x * scores[plan["slot_in"]] * scores[plan["slot_out"]]
         return plan["const"] + (plan["coef"] * x).sum()
 
+    # ---- forward_latency with live betas and constant alpha / widths (the architect's third call) ----------------------------
+    # Every assignment of the reference's recurrence is an affine map of the state (T00, T01, T10, T11, T20, T21, 1) whose
+    # entries are linear in the softmaxed betas: M_k = C_k + sum_b beta_b G_k[.,.,b].  All ~90 maps are built by ONE einsum and
+    # multiplied together by a log-depth tree of batched matmuls: ~12 tensor ops instead of ~350 scalar ones, same arithmetic up
+    # to fp32 summation order.
+    def _latency_beta_plan(self, size):
+        base = self._latency_plan(size)
+        if "beta" in base:
+            return base["beta"]
+        k = self.arch_idx
+        nW = len(self._width_mult_list)
+        slot_in, slot_out, n_out = base["slots_host"]
+        n_slots = base["n_slots"]
+        x = []                                         # per MixedOp: <LUT row at the maximum widths, uniform alpha>
+        for e in range(base["E"]):
+            k_in = nW - 1 if slot_in[e] < n_slots else 0
+            k_out = nW - 1 if slot_out[e] < n_slots else 0
+            x.append(float(base["table_host"][e, k_in * n_out[e] + k_out].sum()) * (1. / len(PRIMITIVES)))
+        index = base["index"]
+        rows = (0, self._layers - 2, self._layers - 3)                 # rows of betas[1], betas[2]
+        boff = (0, 0, 2 * rows[1])
+
+        def bsym(j, row, c):                                            # flat index of betas[j][row][c], python negative-row semantics
+            return boff[j] + (row % rows[j]) * 2 + c
+        nb = 2 * (rows[1] + rows[2])
+        ONE = 6
+        steps = []                                                      # (target, [(beta index or None, coefficient, source)])
+
+        def var(ii, c):
+            return 2 * ii + c
+        for i, cells in enumerate(self.cells):
+            lat = []
+            for j, cell in enumerate(cells):
+                xo = x[index[id(cell._op)]]
+                xd = x[index[id(cell.downsample)]] if cell._down else None
+                if j == 0 or i == j:
+                    lat.append(([(None, xo, ONE)], [(None, xd, ONE)] if xd is not None else None))
+                else:
+                    b0, b1 = bsym(j, i - j - 1, 0), bsym(j, i - j - 1, 1)
+                    lat.append(([(b0, xo, ONE), (b1, xo, ONE)], [(b0, xd, ONE), (b1, xd, ONE)] if xd is not None else []))
+            jl = len(cells) - 1                                         # the reference's leftover loop variable
+            for ii, (l0, l1) in enumerate(lat):
+                if ii == 0:
+                    steps.append((var(0, 0), [(None, 1.0, var(0, 0))] + l0))
+                    if l1 is not None:
+                        steps.append((var(0, 1), [(None, 1.0, var(0, 0))] + l1))
+                elif i == ii:
+                    steps.append((var(ii, 0), [(None, 1.0, var(ii - 1, 1))] + l0))
+                    if l1 is not None:
+                        steps.append((var(ii, 1), [(None, 1.0, var(ii - 1, 1))] + l1))
+                else:
+                    w0, w1 = bsym(jl, i - jl - 1, 0), bsym(jl, i - jl - 1, 1)
+                    steps.append((var(ii, 0), [(w1, 1.0, var(ii, 0)), (w0, 1.0, var(ii - 1, 1))] + l0))
+                    if l1 is not None:
+                        steps.append((var(ii, 1), [(w1, 1.0, var(ii, 0)), (w0, 1.0, var(ii - 1, 1))] + l1))
+        K_ = 1
+        while K_ < len(steps):
+            K_ *= 2
+        C = torch.eye(7).repeat(K_, 1, 1)
+        G = torch.zeros(K_, 7, 7, nb)
+        for n, (target, terms) in enumerate(steps):
+            C[n, target] = 0.0
+            for b, coef, src in terms:
+                if b is None:
+                    C[n, target, src] += coef
+                else:
+                    G[n, target, src, b] += coef
+        dev = base["coef"].device
+        s0 = torch.zeros(7)
+        s0[0], s0[ONE] = base["stem_latency"], 1.0
+        sel = torch.zeros(7)
+        sel[0] = sel[2] = sel[4] = 1.0
+        base["beta"] = dict(C=C.to(dev), G=G.to(dev), s0=s0.to(dev), sel=sel.to(dev))
+        return base["beta"]
+
+    def _forward_latency_beta(self, size):
+        plan = self._latency_beta_plan(size)
+        names = self._arch_names[self.arch_idx]["betas"]
+        bflat = torch.cat([F.softmax(getattr(self, n), dim=-1).reshape(-1) for n in names])
+        M = plan["C"] + torch.matmul(plan["G"], bflat)                  # [K, 7, 7]; step n applies M[n]
+        while M.shape[0] > 1:                                           # later steps multiply from the left
+            M = torch.bmm(M[1::2], M[0::2])
+        return torch.dot(plan["sel"], M[0] @ plan["s0"])
+
     def forward_latency(self, size, alpha=True, beta=True, ratio=True):
         if not beta and _LINEAR_LATENCY:
             fast = self._forward_latency_linear(size, alpha, ratio)
             if fast is not None:
                 return fast
+        if beta and not alpha and not ratio and _LINEAR_LATENCY:
+            return self._forward_latency_beta(size)
         k = self.arch_idx
         stem = self.stem[k]
         alphas, betas = self._arch_tensors(alpha, beta)

@@ -69,8 +69,9 @@ def test_forward_latency_matches_reference():
 
 @pytest.mark.parametrize("arch_idx", [0, 1])
 def test_linear_latency_equals_per_mixedop_evaluation(arch_idx):
-    """forward_latency(beta=False) as one dot product over tabulated LUT rows (no host read-back of the Gumbel widths) against
-    the per-MixedOp evaluation it replaces: same value, same gradients w.r.t. alpha and ratio, on perturbed architecture
+    """forward_latency(beta=False) as one dot product over tabulated LUT rows (no host read-back of the Gumbel widths), and
+    forward_latency(alpha=False, beta=True, ratio=False) as a tree product of per-assignment affine maps, against the
+    per-MixedOp evaluation they replace: same value, same gradients w.r.t. alpha, beta and ratio, on perturbed architecture
     parameters, for the Gumbel ("arch_ratio", arch 1) and the fixed-width ("max", arch 0) modes."""
     from fasterseg_amd import model_search, operations
     saved = dict(operations.latency_lookup_table)
@@ -84,24 +85,24 @@ def test_linear_latency_equals_per_mixedop_evaluation(arch_idx):
             p.data.add_(torch.randn(p.shape, generator=g) * 0.5)
         net.arch_idx = arch_idx
         net.prun_mode = None
-        for a, r in ((True, False), (False, True), (True, True), (False, False)):
+        for a, b, r in ((True, False, False), (False, False, True), (True, False, True), (False, False, False), (False, True, False)):
             got = []
             for linear in (False, True):
                 model_search._LINEAR_LATENCY = linear
                 net.zero_grad()
                 torch.manual_seed(9)
-                lat = net.forward_latency((3, 1024, 2048), alpha=a, beta=False, ratio=r)
+                lat = net.forward_latency((3, 1024, 2048), alpha=a, beta=b, ratio=r)
                 grads = {}
                 if torch.is_tensor(lat) and lat.requires_grad:
                     lat.backward()
-                    grads = {n: getattr(net, n).grad.clone() for kind in ("alphas", "ratios") for n in net._arch_names[arch_idx][kind]
-                             if getattr(net, n).grad is not None}
+                    grads = {n: getattr(net, n).grad.clone() for kind in ("alphas", "betas", "ratios")
+                             for n in net._arch_names[arch_idx][kind] if getattr(net, n).grad is not None}
                 got.append((float(lat.detach()) if torch.is_tensor(lat) else float(lat), grads))
             (v0, g0), (v1, g1) = got
-            assert abs(v0 - v1) <= 2e-6 * abs(v0), (a, r, v0, v1)
-            assert set(g0) == set(g1), (a, r, sorted(g0), sorted(g1))
+            assert abs(v0 - v1) <= 2e-6 * abs(v0), (a, b, r, v0, v1)
+            assert set(g0) == set(g1), (a, b, r, sorted(g0), sorted(g1))
             for n in g0:
-                assert torch.allclose(g0[n], g1[n], rtol=1e-4, atol=1e-6), (a, r, n, float((g0[n] - g1[n]).abs().max()))
+                assert torch.allclose(g0[n], g1[n], rtol=1e-4, atol=1e-6), (a, b, r, n, float((g0[n] - g1[n]).abs().max()))
     finally:
         model_search._LINEAR_LATENCY = flag
         operations.latency_lookup_table.clear()
