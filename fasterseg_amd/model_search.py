@@ -186,6 +186,15 @@ def _run_branches(ops, x):
     return outs
 
 
+class _PreCoef:
+    """The five coefficients of one MixedOp evaluation, already multiplied by the width scores (Network_Multi_Path computes
+    those of a whole pass in a few batched ops, see `_coefficient_rows`)."""
+    __slots__ = ("t",)
+
+    def __init__(self, t):
+        self.t = t
+
+
 class MixedOp(nn.Module):
 
     def __init__(self, C_in, C_out, stride=1, width_mult_list=[1.]):
@@ -206,6 +215,8 @@ class MixedOp(nn.Module):
         self.set_prun_ratio((ratio0, ratio1))
         if widths is not None:
             widths[:] = [ratio0, ratio1]
+        if isinstance(weights, _PreCoef):
+            return weights.t
         coef = weights                                 # sum_k w_k * r_score0 * r_score1 * op_k(x), reference :76-78
         if not torch.is_tensor(coef):
             coef = torch.stack([torch.as_tensor(w, dtype=torch.float32, device=x.device).reshape(()) for w in coef])
@@ -309,6 +320,8 @@ _latency_vectors = {}      # (five LUT latencies, device, dtype) -> device vecto
 # forward_latency(beta=False) as one dot product over tabulated LUT rows (Network_Multi_Path._forward_latency_linear);
 # FS_LINEAR_LATENCY=0 keeps the per-MixedOp evaluation for every call.
 _LINEAR_LATENCY = bool(int(os.environ.get("FS_LINEAR_LATENCY", "1")))
+# the MixedOp coefficients of a whole pass in a few batched ops (Network_Multi_Path._coefficient_rows); FS_BATCHED_COEFS=0: per MixedOp
+_BATCHED_COEFS = bool(int(os.environ.get("FS_BATCHED_COEFS", "1")))
 _SAMPLED = object()        # stands in for a sampled width in _cell_ratio probes
 
 
@@ -492,12 +505,49 @@ class Network_Multi_Path(nn.Module):
             return (ratios[j][i - j - 1], ratios[j][i - j], ratios[j + 1][i - j])
         return (ratios[j][i - j], ratios[j][i - j + 1], ratios[j + 1][i - j])
 
+    def _coefficient_rows(self, alphas, ratios, mode):
+        """{(layer, scale, 0 op | 1 downsample): _PreCoef} = alpha row * score(in width) * score(out width) (reference :64-78) for
+        every MixedOp of a pass in a handful of batched ops: one gather of the alpha rows, one gather of the Gumbel scores,
+        two multiplies, one unbind - whose backward is one stack instead of a zero-fill + copy + add per MixedOp and pass
+        (~2 k of the architecture step's launches).  None while capturing the first time (index tensors need a host copy)."""
+        plans = self.__dict__.setdefault("_coef_plans", {})
+        plan = plans.get(self.arch_idx)
+        dev = alphas[0].device
+        if plan is None:
+            if dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
+                return None
+            counts = (self._layers - 1, self._layers - 1, self._layers - 2)
+            offs = (0, counts[0], counts[0] + counts[1])
+            n_slots = sum(counts)
+            probe = [[("slot", offs[s] + n) for n in range(counts[s])] for s in range(3)]
+            alpha_off = (0, self._layers, 2 * self._layers - 1)
+            keys, rows, s_in, s_out = [], [], [], []
+            slot = lambda r: r[1] if isinstance(r, tuple) else n_slots
+            for i, cells in enumerate(self.cells):
+                for j, cell in enumerate(cells):
+                    r = self._cell_ratio(i, j, probe)
+                    for which, out in ((0, r[1]), (1, r[2])):
+                        if which == 1 and not cell._down:
+                            continue
+                        keys.append((i, j, which)); rows.append(alpha_off[j] + i - j); s_in.append(slot(r[0])); s_out.append(slot(out))
+            plan = plans[self.arch_idx] = dict(keys=keys, rows=torch.tensor(rows, device=dev), s_in=torch.tensor(s_in, device=dev),
+                                               s_out=torch.tensor(s_out, device=dev))
+        A = torch.cat(list(alphas))[plan["rows"]]
+        if mode == "arch_ratio":
+            flat = [r for scale in ratios for r in scale]
+            idx = torch.cat([r._fs_index_t for r in flat])
+            score = torch.stack(flat).gather(1, idx[:, None]).squeeze(1)
+            score = torch.cat([score, score.new_ones(1)])
+            A = A * score[plan["s_in"]][:, None] * score[plan["s_out"]][:, None]
+        return {key: _PreCoef(row) for key, row in zip(plan["keys"], A.unbind(0))}
+
     def forward(self, input):
         k = self.arch_idx
         stem, refine16, refine32 = self.stem[k], self.refine16[k], self.refine32[k]
         alphas, betas = self._arch_tensors()
         mode = self.prun_mode if self.prun_mode is not None else self._prun_modes[k]
         ratios = self.sample_prun_ratio(mode=mode)
+        coef_rows = self._coefficient_rows(alphas, ratios, mode) if _BATCHED_COEFS else None
         # one host read of the whole beta tables instead of one implicit sync per cell (reference :326-328)
         beta_pos = _positive_table(betas)
 
@@ -509,7 +559,7 @@ class Network_Multi_Path(nn.Module):
             # if the cell can down-sample, its `downsample`), listed first and run together (see _run_tasks)
             tasks, slots = [], []
             for j, cell in enumerate(cells):
-                alpha = alphas[j][i - j]
+                alpha = alphas[j][i - j] if coef_rows is None else None
                 ratio = self._cell_ratio(i, j, ratios)
                 assert (cell._down and (ratio[2] is not None)) or ((not cell._down) and (ratio[2] is None))
                 if "_ratio_sampled" not in cell._op.__dict__:
@@ -529,11 +579,13 @@ class Network_Multi_Path(nn.Module):
                 groups = 1
                 if len(srcs) == 2 and _PAIR_BATCH and self.training and srcs[0][1].is_cuda:
                     srcs, groups = [(2, FN.batch_pair(srcs[0][1], srcs[1][1]))], 2          # tag 2: both inputs in one batch
+                a_op = alpha if coef_rows is None else coef_rows[(i, j, 0)]
+                a_down = alpha if coef_rows is None else coef_rows.get((i, j, 1))
                 for tag, x in srcs:
-                    tasks.append((cell._op, x, alpha, (ratio[0], ratio[1]), groups))
+                    tasks.append((cell._op, x, a_op, (ratio[0], ratio[1]), groups))
                     slots.append((j, tag, 0))
                     if cell._down:
-                        tasks.append((cell.downsample, x, alpha, (ratio[0], ratio[2]), groups))
+                        tasks.append((cell.downsample, x, a_down, (ratio[0], ratio[2]), groups))
                         slots.append((j, tag, 1))
             res = dict(zip(slots, _run_tasks(tasks)))
             out = []
