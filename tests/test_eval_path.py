@@ -83,11 +83,13 @@ def _student(shape):
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
 @pytest.mark.parametrize("shape", [(1, 3, 1024, 2048), (2, 3, 128, 256)], ids=["1024x2048", "2x128x256"])
-def test_engine_class_map(shape, dtype):
+def test_engine_class_map(shape, dtype, monkeypatch):
     from fasterseg_amd import engine
     net, x, want = _student(shape)
+    # same (deterministic) plan for both engines: with timing-based kernel / cell selection two builds can pick different tile
+    # variants for a layer, whose bf16 results differ in rounding (seen once: 215 of 65 k pixels flipped between near-tied classes)
+    monkeypatch.setenv("FS_ENGINE_AUTOTUNE", "0")
     with torch.no_grad():
-        # same (deterministic) plan for both engines: with timing-based cell selection they could differ in rounding
         logits = engine.InferenceEngine(net, shape, dtype=dtype, fuse_cells="1")(x.cuda()).clone()
         eng = engine.InferenceEngine(net, shape, dtype=dtype, output="classes", fuse_cells="1")
         classes = eng(x.cuda()).clone()
