@@ -109,6 +109,51 @@ def test_linear_latency_equals_per_mixedop_evaluation(arch_idx):
         operations.latency_lookup_table.update(saved)
 
 
+@pytest.mark.parametrize("arch_idx,mode", [(1, "arch_ratio"), (0, "max"), (1, "random")])
+def test_batched_coefficients_equal_per_mixedop_products(arch_idx, mode):
+    """`_coefficient_rows` (alpha row x in-score x out-score of every MixedOp of a pass in a few batched ops) against
+    MixedOp._coefficients evaluated one MixedOp at a time (reference model_search.py:64-78): same values, same gradients w.r.t.
+    the alpha and ratio parameters."""
+    from fasterseg_amd import model_search
+    net = build()
+    g = torch.Generator().manual_seed(8)
+    for p in net._arch_parameters[arch_idx]:
+        p.data.add_(torch.randn(p.shape, generator=g) * 0.5)
+    net.arch_idx = arch_idx
+    x = torch.zeros(1)
+    results = []
+    for batched in (True, False):
+        net.zero_grad()
+        torch.manual_seed(3)
+        np.random.seed(3)
+        alphas, _ = net._arch_tensors()
+        ratios = net.sample_prun_ratio(mode=mode)
+        rows = net._coefficient_rows(alphas, ratios, mode) if batched else None
+        vals, total = {}, 0
+        w = torch.Generator().manual_seed(1)
+        for i, cells in enumerate(net.cells):
+            for j, cell in enumerate(cells):
+                r = net._cell_ratio(i, j, ratios)
+                for which, (op, out) in enumerate(((cell._op, r[1]), (getattr(cell, "downsample", None), r[2]))):
+                    if op is None or out is None:
+                        continue
+                    a = rows[(i, j, which)] if batched else alphas[j][i - j]
+                    c = op._coefficients(x, a, (r[0], out))
+                    vals[(i, j, which)] = c.detach().clone()
+                    total = total + (c * torch.randn(c.shape, generator=w)).sum()
+        total.backward()
+        grads = {n: getattr(net, n).grad.clone() for kind in ("alphas", "ratios") for n in net._arch_names[arch_idx][kind]
+                 if getattr(net, n).grad is not None}
+        results.append((vals, grads))
+    (v0, g0), (v1, g1) = results
+    assert set(v0) == set(v1) and len(v0) == sum(1 + int(c._down) for cells in net.cells for c in cells)
+    for key in v0:
+        assert torch.equal(v0[key], v1[key]), key
+    assert set(g0) == set(g1)
+    for n in g0:
+        assert torch.allclose(g0[n], g1[n], rtol=1e-5, atol=1e-7), (n, float((g0[n] - g1[n]).abs().max()))
+
+
 def _rel_l2(got, store, key):
     want, step = golden_get(store, key)
     got = got.detach().float().cpu().numpy().reshape(-1)[::step]
