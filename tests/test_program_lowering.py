@@ -179,3 +179,34 @@ def test_lowering_with_bn_groups_sizes_the_per_group_buffers():
     g2 = [args[2][1] for op, args in f2 if op == program.OP_BN_UNIT_FWD]
     assert g1 == [1] and g2 == [2]
     assert two.save_bytes > one.save_bytes and two.tmpb_bytes > one.tmpb_bytes
+
+
+def test_prewarm_enumerates_every_width_combination_of_a_call_site():
+    """MixedOp.prewarm_programs: after one call site has been seen (a lowering with some width pair), every (in, out) pair of the
+    width list is lowered for the sampled ratios, only the seen value for a fixed one; the programs land in the cache under the
+    keys later calls will look up, so those calls lower nothing."""
+    torch.manual_seed(0)
+    m = model_search.MixedOp(48, 48, stride=1, width_mult_list=WIDTHS).train()
+    for p in m.parameters():
+        p.requires_grad_(False)
+    r0, r1 = 8. / 12, 10. / 12
+    m.set_prun_ratio((r0, r1))
+    x = torch.empty_strided((2, 32, 16, 24), (16 * 24 * 32, 1, 24 * 32, 32)).requires_grad_(True)
+    coef = torch.ones(5, requires_grad=True)
+    assert m.prewarm_programs() == 0                         # no call site, no sampling information yet
+    assert m._program(x, coef, r0, r1) is not None
+    m.__dict__["_ratio_sampled"] = (True, False)             # in-width sampled, out-width fixed (e.g. the last layer's head width)
+    assert m.prewarm_programs() == len(WIDTHS) - 1
+    m.__dict__["_ratio_sampled"] = (True, True)
+    assert m.prewarm_programs() == len(WIDTHS) * len(WIDTHS) - len(WIDTHS)
+    assert len(m._programs) == len(WIDTHS) ** 2
+    before = dict(m._programs)
+    for w0 in WIDTHS:
+        for w1 in WIDTHS:
+            m.set_prun_ratio((w0, w1))
+            cin = m._ops[1].conv1.active_channels()[1]
+            xx = torch.empty_strided((2, cin, 16, 24), (16 * 24 * cin, 1, 24 * cin, cin)).requires_grad_(True)
+            prog = m._program(xx, coef, w0, w1)
+            assert prog is not None and prog.out_shape[0] == 2
+    assert m._programs == before, "a later call lowered a program the prewarm should have built"
+    assert m.prewarm_programs() == 0
