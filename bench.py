@@ -18,8 +18,13 @@ With N > 1 (one rank per GPU, RCCL) inference runs as independent replicas (it d
 "weak") and the three train steps run data-parallel with the flat-gradient all-reduce, so every --gpus N run exercises the
 collective path; launched without torchrun, `--gpus N` re-executes itself under torch.distributed.run.
 
-roofline: C2 from per-launch HIP-event timings of the plan (engine.profile()); train steps from a launch census of one step
-x per-shape HIP-event timings (fasterseg_amd/census.py).  cpu_baseline: the CPU oracle (oracle/, fixture-pinned port of the
+Every train workload is gated like C2: the loss of the FIRST step of the stepper that is about to be timed is compared with the CPU
+oracle on the same weights / batch / RNG seeds (`parity` inside each workload; a miss aborts), and carries an fp32 leg
+(`ms_per_step_fp32`: the reference's arithmetic) beside the bf16 number.
+roofline: one more frame / step issued eagerly with every kernel launch timed by its own start/stop HIP event pair on the launch
+stream (hipExtLaunchKernelGGL; fasterseg_amd/census.py, csrc/census.hip): achieved = algorithmic FLOPs of ALL launches of the dominant
+kernel family / the sum of their measured durations - the figures tools/roofline_from_profile.py recomputes from the rocprofv3
+tables under profiles/.  cpu_baseline: the CPU oracle (oracle/, fixture-pinned port of the
 reference modules on torch-CPU kernels) on a bounded sample of the same workload, on this host's cores.
 A step count whose timed region would be shorter than --min-seconds is raised (reported as `steps`; `steps_requested` keeps
 the flag).
@@ -57,6 +62,7 @@ def parse():
     ap.add_argument("--min-seconds", type=float, default=0.5, help="minimum length of every timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the fp32 re-run of every train workload")
     ap.add_argument("--no-class-map", action="store_true", help="skip the class-map (evaluator) variant of the C2 engine")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU budget of each cpu_baseline sample")
     ap.add_argument("--dump-plan", default=None, help="write the per-launch table of the C2 plan (json) here")
@@ -227,10 +233,18 @@ def run_student_infer(args, world, rank, backend):
                             "the network); this run is the bilinear train/ network",
     }
     if rank == 0 and not args.no_roofline:
-        rows = eng.profile()
+        # in-frame: every launch of the plan timed by its own HIP event pair while whole frames are issued in plan order (what
+        # rocprofv3's kernel trace of a frame shows); isolated: each launch replayed 20x alone, cache-warm (the round-1/2 figure)
+        rows = eng.profile_in_frame()
         roof, families, total_ms = roofline_from_profile(rows, args.dtype)
+        iso_roof, iso_fam, iso_ms = roofline_from_profile(eng.profile(), args.dtype)
+        roof["method"] = ("in-frame: 20 frames issued launch by launch in plan order on one stream, every kernel timed by its own start/stop "
+                          "HIP event pair (hipExtLaunchKernelGGL); achieved = sum alg FLOPs / sum durations of the family's launches")
+        roof["isolated"] = {"achieved": iso_fam[roof["kernel"]]["TFLOPs"], "frac": round(iso_fam[roof["kernel"]]["TFLOPs"] / PEAK_TFLOPS[args.dtype], 4),
+                            "note": "each launch replayed 20x back to back from its own hipGraph (operands L2-warm): upper bound, not the in-frame rate"}
         line["roofline"] = roof
         line["kernel_families"] = families
+        line["kernel_families_isolated"] = iso_fam
         line["sum_kernel_ms"] = round(total_ms, 4)
         flops_roof = eng.total_flops / (PEAK_TFLOPS[args.dtype] * 1e12)
         bytes_roof = eng.total_bytes / (PEAK_HBM_GBS * 1e9)
@@ -267,11 +281,6 @@ def run_student_infer(args, world, rank, backend):
 
 
 # ---- train workloads ---------------------------------------------------------------------------------------------------
-def _census_roofline(args, entries):
-    from fasterseg_amd import census
-    return census.roofline(entries, args.dtype, PEAK_TFLOPS[args.dtype], PEAK_HBM_GBS)
-
-
 def _train_line(args, world, backend, name, batch, elapsed, steps, warmup, extra):
     ips = world * batch * steps / elapsed
     line = {"value": round(ips, 4), "unit": "images/s", "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3),
@@ -281,14 +290,77 @@ def _train_line(args, world, backend, name, batch, elapsed, steps, warmup, extra
     return line
 
 
+PARITY_BARS = {"bf16": 2e-2, "fp32": 2e-3}      # relative error of the first step's loss vs the CPU oracle (tests/test_train_parity_gpu.py)
+
+
+def _parity(what, got, want, dtype_name, extra=None):
+    rel = abs(got - want) / max(abs(want), 1e-12)
+    out = {"vs": what, "loss": got, "oracle_loss": want, "rel_err": rel, "bar": "rel_err <= %g (%s)" % (PARITY_BARS[dtype_name], dtype_name),
+           "pass": bool(rel <= PARITY_BARS[dtype_name])}
+    if extra:
+        out.update(extra)
+    if not out["pass"]:
+        raise SystemExit("bench.py: train-step loss does not match the CPU oracle: %s" % json.dumps(out))
+    return out
+
+
+def _timed_census(args, world, rank, step_fn, extra_entries=()):
+    """ONE more step, issued eagerly with every kernel launch timed by its own HIP event pair (census level 2).  Every rank runs it
+    (the step contains the gradient all-reduce), rank 0 reports."""
+    from fasterseg_amd import census
+    with census.recording(level=2) as rec:
+        step_fn()
+        torch.cuda.synchronize()
+    if rank != 0:
+        return None
+    roof, families, kernels = census.roofline_timed(rec, args.dtype, PEAK_TFLOPS[args.dtype], PEAK_HBM_GBS, extra_entries)
+    return {"roofline": roof, "kernel_families": families, "kernels_in_step": kernels}
+
+
+def _fp32_leg(args, world, make_stepper, run_of, batch):
+    """The same step in the reference's arithmetic (fp32 storage, exact-fp32 MFMA): a same-precision number beside the bf16 one."""
+    if args.dtype == "fp32" or args.no_fp32_leg:
+        return {}
+    torch.cuda.empty_cache()
+    stepper = make_stepper(torch.float32)
+    run = run_of(stepper)
+    elapsed, steps = timed_region(run, max(3, args.train_steps // 2), 2, world, args.min_seconds)
+    del stepper
+    torch.cuda.empty_cache()
+    return {"ms_per_step_fp32": round(elapsed / steps * 1e3, 3), "value_fp32": round(world * batch * steps / elapsed, 4),
+            "fp32_steps": steps, "fp32_note": PRECISION["fp32"] + " - the reference trains in fp32 (search/train_search.py:215-251, train/train.py:219-271)"}
+
+
 def run_student_train(args, world, rank, backend):
-    from fasterseg_amd import census, train_step
-    from oracle import ref_ops
+    from fasterseg_amd import train_step
+    from oracle import ref_loss, ref_ops
     from oracle.seeded import resolve_aliases
     batch, H, W = 12, 512, 1024
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    stepper = train_step.StudentDistillStep(batch, H, W, teacher_engine_dtype=dt, compute_dtype=dt)
+    make = lambda d: train_step.StudentDistillStep(batch, H, W, teacher_engine_dtype=d, compute_dtype=d)
+    stepper = make(dt)
     imgs, target = train_step.synthetic_batch(batch, H, W, rank, "cuda")
+    with open(os.path.join(ROOT, "tests", "golden", "arch_1.json")) as f:      # decoded structures (test fixtures): only the oracle reads them
+        meta_s = json.load(f)["train_21"]
+    with open(os.path.join(ROOT, "tests", "golden", "arch_0.json")) as f:
+        meta_t = json.load(f)["train_21"]
+    snap = lambda net, meta: resolve_aliases({k: v.detach().cpu().clone() for k, v in net.state_dict().items()}, meta)
+    ps, pt = snap(stepper.student, meta_s), snap(stepper.teacher, meta_t)          # the weights the first step sees
+    # ---- parity gate: the FIRST step's loss (the stepper that is about to be timed, teacher engine included) vs the CPU oracle on a
+    # slice of the same batch with the same weights.  OHEM's min_kept is per batch (train/train.py:62), so the device side evaluates
+    # the same slice through the same modules and criteria (eager teacher) - and the full-batch first step must agree with it too.
+    first = float(stepper.step(imgs, target))
+    parity = None
+    if rank == 0:
+        nb = 2
+        xi, ti = imgs[:nb], target[:nb]
+        got = stepper.loss_only(xi, ti)
+        with torch.no_grad():
+            t_logits = ref_ops.derived_forward(pt, meta_t, xi.cpu(), training=False)
+            p8, p16, p32 = ref_ops.derived_forward(dict(ps), meta_s, xi.cpu(), training=True)
+            want = float(ref_loss.student_step_loss(p8, p16, p32, t_logits, ti.cpu(), min_kept=nb * H * W // 16))
+        parity = _parity("oracle.ref_ops.derived_forward (teacher eval + student train mode) + oracle.ref_loss.student_step_loss on %d images of the "
+                         "batch, weights of step 0" % nb, got, want, args.dtype, {"first_step_loss_full_batch": first})
     loss = [None]
 
     def run():
@@ -296,38 +368,32 @@ def run_student_train(args, world, rank, backend):
     elapsed, steps = timed_region(run, args.train_steps, args.train_warmup, world, args.min_seconds)
     name = ("C4 student KL-distillation train step (BASELINE configs[3]): %d x 3x%dx%d per GPU, teacher arch_0 eval (engine) + student arch_1 "
             "train (3 heads), OHEM-CE + KLDiv, SGD" % (batch, H, W))
-    line = _train_line(args, world, backend, name, batch, elapsed, steps, args.train_warmup, {"final_loss": float(loss[0])})
-    if rank == 0 and not args.no_roofline:
-        with census.recording() as rec:
-            stepper.step(imgs, target)
-        torch.cuda.synchronize()
-        entries = rec.entries + (stepper.teacher_engine.census_entries() if stepper.teacher_engine is not None else [])
-        line["roofline"], line["kernel_families"] = _census_roofline(args, entries)
+    line = _train_line(args, world, backend, name, batch, elapsed, steps, args.train_warmup, {"final_loss": float(loss[0]), "parity": parity})
+    if not args.no_roofline:
+        extra = []
+        if rank == 0 and stepper.teacher_engine is not None:
+            extra = stepper.teacher_engine.census_entries(stepper.teacher_engine.profile_in_frame(frames=3, warm=1))
+        timed = _timed_census(args, world, rank, lambda: stepper.step(imgs, target), extra)
+        if timed:
+            line.update(timed)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # the same step on the CPU oracle, on a 2-image sample (teacher eval forward + student train forward/backward)
         nb = 2
-        with open(os.path.join(ROOT, "tests", "golden", "arch_1.json")) as f:
-            meta_s = json.load(f)["train_21"]
-        with open(os.path.join(ROOT, "tests", "golden", "arch_0.json")) as f:
-            meta_t = json.load(f)["train_21"]
-        ps = resolve_aliases({k: v.detach().cpu().clone() for k, v in stepper.student.state_dict().items()}, meta_s)
-        pt = resolve_aliases({k: v.detach().cpu().clone() for k, v in stepper.teacher.state_dict().items()}, meta_t)
         for k, v in ps.items():
             if v.is_floating_point() and not k.endswith(("running_mean", "running_var")):
                 v.requires_grad_(True)
         xi, ti = imgs[:nb].cpu(), target[:nb].cpu()
-        crit = torch.nn.CrossEntropyLoss(ignore_index=255)
 
         def cpu_step():
             with torch.no_grad():
                 t_logits = ref_ops.derived_forward(pt, meta_t, xi, training=False)
             p8, p16, p32 = ref_ops.derived_forward(ps, meta_s, xi, training=True)
-            l_ = crit(p8, ti) + 0.2 * crit(p16, ti) + 0.2 * crit(p32, ti)
-            l_ = l_ + torch.nn.functional.kl_div(torch.log_softmax(p8, 1), torch.softmax(t_logits, 1), reduction="mean")
-            l_.backward()
+            ref_loss.student_step_loss(p8, p16, p32, t_logits, ti, min_kept=nb * H * W // 16).backward()
         line["cpu_baseline"] = _time_cpu(cpu_step, nb, args.cpu_seconds,
-                                         "%d images of 3x%dx%d: teacher eval forward + student train forward/backward through oracle/ref_ops "
-                                         "(plain CE in place of OHEM selection)" % (nb, H, W))
+                                         "%d images of 3x%dx%d: teacher eval forward + student train forward/backward through oracle/ref_ops, "
+                                         "OHEM-CE + KLDiv through oracle/ref_loss" % (nb, H, W))
+    del stepper
+    line.update(_fp32_leg(args, world, make, lambda st: (lambda: st.step(imgs, target)), batch))
     return line
 
 
@@ -362,22 +428,52 @@ def _time_cpu_inner(fn, images, budget_s, what, cores):
 
 
 def run_supernet(args, world, rank, backend, pretrain):
-    from fasterseg_amd import census, latency_lookup_table, train_step
+    import numpy as np
+    from fasterseg_amd import latency_lookup_table, train_step
     from oracle import ref_supernet
     batch = 3 if pretrain else 2
     H, W = (256, 512) if pretrain else (224, 448)
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     lut = None if pretrain else latency_lookup_table.load_shipped("bf16")
-    stepper = train_step.SupernetStep(pretrain=pretrain, lut=lut, compute_dtype=dt)
+    make = lambda d: train_step.SupernetStep(pretrain=pretrain, lut=lut, compute_dtype=d)
+    stepper = make(dt)
     g = torch.Generator().manual_seed(2000 + rank)
 
-    def make():
+    def make_batch():
         imgs = torch.randn(batch, 3, H, W, generator=g).cuda()
         tgt = torch.randint(0, 19, (batch, H // 8, W // 8), generator=g)
         tgt[torch.rand(batch, H // 8, W // 8, generator=g) < 0.05] = 255
         return imgs, tgt.cuda()
-    imgs, target = make()
-    imgs_s, target_s = make()
+    imgs, target = make_batch()
+    imgs_s, target_s = make_batch()
+    cfg = dict(layers=train_step.SearchConfig.layers, width_mult_list=train_step.SearchConfig.width_mult_list,
+               prun_modes=train_step.SearchConfig.prun_modes, stem_head_width=train_step.SearchConfig.stem_head_width)
+    params = {k: v.detach().cpu().clone() for k, v in stepper.model.state_dict().items()}       # the weights the first step sees
+    # ---- parity gate: the FIRST step of the stepper that is about to be timed (graph capture, programs, pair batching and all) vs the
+    # CPU oracle's `_loss` on the same batch, same weights, same host-RNG seeds (np.random widths / torch.rand Gumbel noise).  Pretrain:
+    # the weight step's loss.  Search: the architecture step's `_loss` on the search batch (it runs first, on the initial weights and
+    # architecture parameters; the latency penalty is reported separately).
+    SEED = 4242
+    np.random.seed(SEED)
+    torch.manual_seed(SEED)
+    first_w, first_a = stepper.step(imgs, target, imgs_s, target_s)
+    parity = None
+    if rank == 0:
+        np.random.seed(SEED)
+        torch.manual_seed(SEED)
+        threads = torch.get_num_threads()
+        torch.set_num_threads(min(32, threads))
+        try:
+            with torch.no_grad():
+                xi, ti = (imgs, target) if pretrain else (imgs_s, target_s)
+                want = float(ref_supernet.loss(params, cfg, xi.cpu(), ti.cpu(), pretrain))
+        finally:
+            torch.set_num_threads(threads)
+        got = float(first_w) if pretrain else float(stepper.last_arch_ce)
+        parity = _parity("oracle.ref_supernet.loss (`_loss` of search/model_search.py:478-505, 4 passes) on the full batch, weights and RNG "
+                         "seeds of step 0%s" % ("" if pretrain else "; architecture step's loss without the latency penalty"), got, want, args.dtype)
+    np.random.seed(SEED + 1)
+    torch.manual_seed(SEED + 1)
     out = [None, None]
 
     def run():
@@ -390,17 +486,14 @@ def run_supernet(args, world, rank, backend, pretrain):
         name = "C5 architecture-search step (BASELINE configs[4]): arch update (Architect.step, Adam) + weight update, %d x 3x%dx%d per GPU for " \
                "each, F12.L16; latency table = shipped MI355X table (667 hipEvent-timed entries, fasterseg_amd/latency_lookup_table.py)" % (batch, H, W)
     line = _train_line(args, world, backend, name, batch, elapsed, steps, args.train_warmup,
-                       {"final_loss": float(out[0]), "arch_loss": None if out[1] is None else float(out[1]),
-                        "eager_passes_per_phase": sum(1 for s_ in stepper._specs() if not stepper._is_static(s_))})
-    if rank == 0 and not args.no_roofline:
-        with census.recording() as rec:
-            stepper.step(imgs, target, imgs_s, target_s, force_eager=True)
-        torch.cuda.synchronize()
-        line["roofline"], line["kernel_families"] = _census_roofline(args, rec.entries)
+                       {"final_loss": float(out[0]), "arch_loss": None if out[1] is None else float(out[1]), "parity": parity,
+                        "eager_passes_per_phase": sum(1 for s_ in stepper._specs() if not stepper._is_static(s_)),
+                        "execution": stepper.describe()})
+    if not args.no_roofline:
+        timed = _timed_census(args, world, rank, lambda: stepper.step(imgs, target, imgs_s, target_s, force_eager=True))
+        if timed:
+            line.update(timed)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cfg = dict(layers=train_step.SearchConfig.layers, width_mult_list=train_step.SearchConfig.width_mult_list,
-                   prun_modes=train_step.SearchConfig.prun_modes, stem_head_width=train_step.SearchConfig.stem_head_width)
-        params = {k: v.detach().cpu().clone() for k, v in stepper.model.state_dict().items()}
         for k, v in params.items():
             if v.is_floating_point() and not k.endswith(("running_mean", "running_var")):
                 v.requires_grad_(True)
@@ -415,6 +508,8 @@ def run_supernet(args, world, rank, backend, pretrain):
                                          "kernels, fixture-pinned)" % (H, W, "`_loss(pretrain)` forward+backward" if pretrain else
                                                                        "`_loss` forward+backward of the arch step and of the weight step"),
                                          threads=16)
+    del stepper
+    line.update(_fp32_leg(args, world, make, lambda st: (lambda: st.step(imgs, target, imgs_s, target_s)), batch))
     return line
 
 
@@ -424,7 +519,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
     world, rank, backend = dist_setup(args)
     c2 = run_student_infer(args, world, rank, backend)
-    workloads = {"C2_student_infer": {k: c2[k] for k in ("value", "unit", "ms_per_step", "steps", "dtype", "roofline", "cpu_baseline") if k in c2}}
+    workloads = {"C2_student_infer": {k: c2[k] for k in ("value", "unit", "ms_per_step", "steps", "dtype", "parity", "roofline", "cpu_baseline") if k in c2}}
     runners = {"c3": ("C3_supernet_pretrain", lambda: run_supernet(args, world, rank, backend, True)),
                "c4": ("C4_student_train", lambda: run_student_train(args, world, rank, backend)),
                "c5": ("C5_supernet_search", lambda: run_supernet(args, world, rank, backend, False))}

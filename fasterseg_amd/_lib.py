@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfasterseg_hip.so")
 
-EXPECTED_ABI = 202          # FS_ABI_VERSION of include/fasterseg_hip.h these bindings were written against
+EXPECTED_ABI = 203          # FS_ABI_VERSION of include/fasterseg_hip.h these bindings were written against
 FS_F32, FS_BF16 = 0, 1
 FS_CONV_RELU, FS_CONV_TRANSPOSED, FS_CONV_ACCUM = 1, 2, 4
 
@@ -35,7 +35,11 @@ class ResizeDesc(ctypes.Structure):
 
 
 class CensusEntry(ctypes.Structure):
-    _fields_ = [("family", c_int), ("desc", ConvDesc), ("count", c_ll)]
+    _fields_ = [("family", c_int), ("desc", ConvDesc), ("count", c_ll), ("ms", ctypes.c_double)]
+
+
+class KernelTime(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 56), ("count", c_ll), ("ms", ctypes.c_double)]
 
 
 class SgdTensor(ctypes.Structure):
@@ -120,6 +124,9 @@ _SPECIAL = {
     "fs_zoom_cell_supported": ([ctypes.POINTER(ZoomDesc)], c_int),
     "fs_census_enable": ([c_int], None),
     "fs_census_read": ([c_vp, c_int], c_int),
+    "fs_census_read_kernels": ([c_vp, c_int], c_int),
+    "fs_census_tag": ([c_int], None),
+    "fs_census_read_tags": ([c_int, c_vp, c_vp], c_int),
     "fs_event_create": ([], c_vp),
     "fs_event_destroy": ([c_vp], None),
 }

@@ -37,6 +37,7 @@ class Architect(object):
         for optimizer in self.optimizers:
             optimizer.zero_grad()
         loss, loss_latency = self._backward_step(input_valid, target_valid)
+        self.last_loss = loss.detach()                # `_loss` alone, before the latency penalty
         loss.backward()
         if not (isinstance(loss_latency, (int, float)) and loss_latency == 0):
             loss_latency.backward()

@@ -1,12 +1,14 @@
-"""Launch census + per-shape timing: what a train step's dominant kernel achieves against its roofline.
+"""Launch census + in-step kernel timing: what a train step's dominant kernel achieves against its roofline.
 
 The train steps replay most of their launches from hipGraphs, where individual kernels cannot be bracketed by events.  So
-the measurement is split: (1) the C library counts every convolution launch by geometry while one step is issued (launches
-recorded during a capture are counted once = per replay); (2) each counted geometry is then run alone on the device,
-`reps` times back to back from a small hipGraph bracketed by HIP events on the launch stream (same method as
-InferenceEngine.profile()); (3) achieved = sum(count x algorithmic FLOPs) / sum(count x measured duration).
-profiles/*_kernel_stats.csv (rocprofv3 --kernel-trace --stats of the same bench command) hold the in-step average durations
-of the same kernels for cross-checking.
+bench.py issues ONE more step eagerly (same kernels, one stream) with the C library's census at level 2: every kernel launch
+carries a start/stop HIP event pair (hipExtLaunchKernelGGL - the dispatch's own begin/end timestamps, the quantity
+rocprofv3's kernel trace reports) and the library accumulates launches and device time per kernel name and per convolution
+geometry.  achieved = sum(algorithmic FLOPs of ALL launches of the family) / sum(their measured durations): nothing is
+sampled, extrapolated or replayed warm (`roofline_timed`).  profiles/*_kernel_stats.csv (rocprofv3 --kernel-trace of the same
+step, tools/prof_step.sh) hold the same table for cross-checking; tools/roofline_from_profile.py recomputes the fractions
+from them.  The round-2 method (each geometry replayed alone, cache-warm, from a small hipGraph: `roofline`) is kept as the
+"isolated" figure.
 """
 import contextlib
 import ctypes
@@ -15,24 +17,28 @@ import torch
 
 from . import _lib
 from . import kernels as K
-from ._lib import FS_CONV_TRANSPOSED, CensusEntry, ConvDesc, call
+from ._lib import FS_CONV_TRANSPOSED, CensusEntry, ConvDesc, KernelTime, call
 
 IGEMM, HALO, WGRAD, STATS = 0, 1, 2, 0x100
 FAMILY_NAMES = {IGEMM: "conv_igemm (fwd + dgrad)", HALO: "conv3x3_halo", WGRAD: "conv_wgrad"}
 
 
 @contextlib.contextmanager
-def recording():
-    """with recording() as rec: <issue one step>  ->  rec.entries = [(family, ConvDesc, count)]"""
+def recording(level=1):
+    """with recording() as rec: <issue one step>  ->  rec.entries = [(family, ConvDesc, count, ms)], rec.kernels = {name: (count, ms)}
+    level 2 times every launch (ms is 0 at level 1)."""
     lib = _lib.lib()
 
     class _Rec:
         entries = []
+        kernels = {}
     rec = _Rec()
-    lib.fs_census_enable(1)
+    lib.fs_census_enable(level)
     try:
         yield rec
     finally:
+        if level > 1:
+            torch.cuda.synchronize()
         lib.fs_census_enable(0)
         n = lib.fs_census_read(None, 0)
         buf = (CensusEntry * max(n, 1))()
@@ -41,8 +47,12 @@ def recording():
         for i in range(n):
             d = ConvDesc()
             ctypes.memmove(ctypes.byref(d), ctypes.byref(buf[i].desc), ctypes.sizeof(ConvDesc))
-            out.append((int(buf[i].family), d, int(buf[i].count)))
+            out.append((int(buf[i].family), d, int(buf[i].count), float(buf[i].ms)))
         rec.entries = out
+        nk = lib.fs_census_read_kernels(None, 0)
+        kb = (KernelTime * max(nk, 1))()
+        nk = min(nk, lib.fs_census_read_kernels(ctypes.cast(kb, ctypes.c_void_p), nk))
+        rec.kernels = {kb[i].name.decode(): (int(kb[i].count), float(kb[i].ms)) for i in range(nk)}
 
 
 def conv_flops(d):
@@ -111,6 +121,7 @@ def roofline(entries, dtype_name, peak_tflops, peak_hbm_gbs=8000.0, max_shapes=1
     Shapes are timed in descending order of their share of the step's FLOPs until `coverage` of all FLOPs (or max_shapes) is
     reached; the remainder is reported as un-timed (`flops_coverage`), never extrapolated."""
     fams = {}
+    entries = [e[:3] for e in entries]
     order = sorted(entries, key=lambda e: -conv_flops(e[1]) * e[2])
     total_flops = sum(conv_flops(d) * c for _, d, c in order) or 1.0
     kept, acc = [], 0.0
@@ -142,3 +153,37 @@ def roofline(entries, dtype_name, peak_tflops, peak_hbm_gbs=8000.0, max_shapes=1
     families = {FAMILY_NAMES[k]: {"ms_per_step": round(v["ms"], 3), "launches": v["launches"], "shapes": v["shapes"],
                                   "TFLOPs": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in fams.items()}
     return roof, families
+
+
+def roofline_timed(rec, dtype_name, peak_tflops, peak_hbm_gbs=8000.0, extra_entries=()):
+    """`roofline` object + family table from a level-2 recording of one step: EVERY launch of every convolution family with
+    its own measured duration.  extra_entries: (family, desc, count, ms) of launches that ran outside the recording (the frozen
+    teacher's engine plan, timed by InferenceEngine.profile_in_frame)."""
+    fams = {}
+    for family, d, count, ms in list(rec.entries) + list(extra_entries):
+        f = fams.setdefault(family & 0xff, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0, shapes=0))
+        f["ms"] += ms
+        f["flops"] += conv_flops(d) * count
+        f["bytes"] += conv_bytes(d) * count
+        f["launches"] += count
+        f["shapes"] += 1
+    fams = {k: v for k, v in fams.items() if v["ms"] > 0}
+    if not fams:
+        return None, {}, {}
+    kernel_ms = sum(ms for _, ms in rec.kernels.values()) + sum(e[3] for e in extra_entries)
+    dom_id, dom = max(fams.items(), key=lambda kv: kv[1]["ms"])
+    ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+    roof = {"kernel": FAMILY_NAMES[dom_id], "bound": "mfma", "achieved": round(ach, 2), "peak": peak_tflops, "unit": "TFLOP/s",
+            "frac": round(ach / peak_tflops, 5), "launches_per_step": dom["launches"], "distinct_shapes": dom["shapes"],
+            "avg_launch_us": round(dom["ms"] / dom["launches"] * 1e3, 3), "share_of_kernel_time": round(dom["ms"] / max(kernel_ms, 1e-9), 4),
+            "alg_flops_per_launch": dom["flops"] / dom["launches"], "alg_bytes_per_launch": dom["bytes"] / dom["launches"],
+            "achieved_GBps": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9, 1), "traffic": None, "flops_coverage": 1.0,
+            "method": "one eager step at census level 2: every launch of the family timed by its own start/stop HIP event pair "
+                      "(hipExtLaunchKernelGGL) on the launch stream; achieved = sum FLOPs / sum durations of ALL launches"}
+    families = {FAMILY_NAMES[k]: {"ms_per_step": round(v["ms"], 3), "launches": v["launches"], "shapes": v["shapes"],
+                                  "avg_us": round(v["ms"] / v["launches"] * 1e3, 2),
+                                  "TFLOPs": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                                  "frac_of_mfma_peak": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / peak_tflops, 5)} for k, v in fams.items()}
+    kernels = {name: {"launches": c, "ms_per_step": round(ms, 3), "avg_us": round(ms / max(c, 1) * 1e3, 2)}
+               for name, (c, ms) in sorted(rec.kernels.items(), key=lambda kv: -kv[1][1])}
+    return roof, families, kernels

@@ -540,7 +540,7 @@ extern "C" fs_status fs_bn_group_fwd(void* stream, long long pixels, int C, int 
     hipStream_t st = (hipStream_t)stream;
     if (bn_small_ok(pixels, groups)) {
 #define FS_BN_SMALL_FWD(T, G)                                                                                                     \
-    hipLaunchKernelGGL((bn_small_fwd_kernel<T, G>), dim3(cv), dim3(BNS_THREADS), 0, st, pixels, C, (T*)z, z_cs, partials, splits, gamma, \
+    FS_LAUNCH((bn_small_fwd_kernel<T, G>), dim3(cv), dim3(BNS_THREADS), 0, st, pixels, C, (T*)z, z_cs, partials, splits, gamma, \
                        beta, eps, momentum, running_mean, running_var, num_batches_tracked, saved, (T*)y, y_cs, relu)
         if (dtype == FS_F32) { if (groups == 1) FS_BN_SMALL_FWD(float, 1); else FS_BN_SMALL_FWD(float, 2); }
         else { if (groups == 1) FS_BN_SMALL_FWD(bf16_t, 1); else FS_BN_SMALL_FWD(bf16_t, 2); }
@@ -548,10 +548,10 @@ extern "C" fs_status fs_bn_group_fwd(void* stream, long long pixels, int C, int 
         return check_launch("fs_bn_group_fwd");
     }
     if (dtype == FS_F32)
-        hipLaunchKernelGGL((bn_group_fwd_kernel<float>), dim3(cv), dim3(bnc_threads(pixels / groups)), 0, st, pixels, C, groups, (float*)z, z_cs, partials, splits,
+        FS_LAUNCH((bn_group_fwd_kernel<float>), dim3(cv), dim3(bnc_threads(pixels / groups)), 0, st, pixels, C, groups, (float*)z, z_cs, partials, splits,
                            gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, saved, (float*)y, y_cs, relu);
     else
-        hipLaunchKernelGGL((bn_group_fwd_kernel<bf16_t>), dim3(cv), dim3(bnc_threads(pixels / groups)), 0, st, pixels, C, groups, (bf16_t*)z, z_cs, partials, splits,
+        FS_LAUNCH((bn_group_fwd_kernel<bf16_t>), dim3(cv), dim3(bnc_threads(pixels / groups)), 0, st, pixels, C, groups, (bf16_t*)z, z_cs, partials, splits,
                            gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, saved, (bf16_t*)y, y_cs, relu);
     return check_launch("fs_bn_group_fwd");
 }
@@ -571,7 +571,7 @@ extern "C" fs_status fs_bn_group_bwd(void* stream, long long pixels, int C, int 
     hipStream_t st = (hipStream_t)stream;
     if (bn_small_ok(pixels, groups)) {
 #define FS_BN_SMALL_BWD(T, G)                                                                                                      \
-    hipLaunchKernelGGL((bn_small_bwd_kernel<T, G>), dim3(cv), dim3(BNS_THREADS), 0, st, pixels, C, (const T*)z, z_cs, (const T*)dy, dy_cs, \
+    FS_LAUNCH((bn_small_bwd_kernel<T, G>), dim3(cv), dim3(BNS_THREADS), 0, st, pixels, C, (const T*)z, z_cs, (const T*)dy, dy_cs, \
                        (const T*)y_out, y_cs, saved, gamma, relu, (T*)dz, dz_cs, red, dgamma_acc, dbeta_acc)
         if (dtype == FS_F32) { if (groups == 1) FS_BN_SMALL_BWD(float, 1); else FS_BN_SMALL_BWD(float, 2); }
         else { if (groups == 1) FS_BN_SMALL_BWD(bf16_t, 1); else FS_BN_SMALL_BWD(bf16_t, 2); }
@@ -579,10 +579,10 @@ extern "C" fs_status fs_bn_group_bwd(void* stream, long long pixels, int C, int 
         return check_launch("fs_bn_group_bwd");
     }
     if (dtype == FS_F32)
-        hipLaunchKernelGGL((bn_group_bwd_kernel<float>), dim3(cv), dim3(bnc_threads(pixels / groups)), 0, st, pixels, C, groups, (const float*)z, z_cs,
+        FS_LAUNCH((bn_group_bwd_kernel<float>), dim3(cv), dim3(bnc_threads(pixels / groups)), 0, st, pixels, C, groups, (const float*)z, z_cs,
                            (const float*)dy, dy_cs, (const float*)y_out, y_cs, saved, gamma, relu, (float*)dz, dz_cs, red, dgamma_acc, dbeta_acc);
     else
-        hipLaunchKernelGGL((bn_group_bwd_kernel<bf16_t>), dim3(cv), dim3(bnc_threads(pixels / groups)), 0, st, pixels, C, groups, (const bf16_t*)z, z_cs,
+        FS_LAUNCH((bn_group_bwd_kernel<bf16_t>), dim3(cv), dim3(bnc_threads(pixels / groups)), 0, st, pixels, C, groups, (const bf16_t*)z, z_cs,
                            (const bf16_t*)dy, dy_cs, (const bf16_t*)y_out, y_cs, saved, gamma, relu, (bf16_t*)dz, dz_cs, red, dgamma_acc, dbeta_acc);
     return check_launch("fs_bn_group_bwd");
 }

@@ -1,6 +1,7 @@
 // Shared device/host helpers for libfasterseg_hip (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
@@ -33,12 +34,25 @@ inline fs_status check_launch(const char* what) {
     return FS_OK;
 }
 
-// launch census (api.cpp): one branch per conv launch when disabled
+// launch census (census.hip).  g_census_on: 0 off, 1 count conv launches by geometry, 2 count AND time every kernel launch:
+// FS_LAUNCH then goes through hipExtLaunchKernelGGL with a start/stop event pair, i.e. the dispatch's own begin/end timestamps
+// (what rocprofv3's kernel trace reports), on the stream the kernel is launched on.
 extern int g_census_on;
-void census_conv(int family, const fs_conv_desc* d);
-#define FS_CENSUS(family, d)                                  \
-    do {                                                      \
-        if (fs::g_census_on) fs::census_conv((family), (d));  \
+struct CensusScope {          // every FS_LAUNCH issued while the scope lives is attributed to this (family, geometry) entry
+    bool live;
+    CensusScope(int family, const fs_conv_desc* d);
+    ~CensusScope();
+};
+bool census_events(const char* kernel, hipStream_t stream, hipEvent_t* start, hipEvent_t* stop);
+#define FS_CENSUS(family, d) fs::CensusScope fs_census_scope_((family), (d))
+#define FS_LAUNCH(kernel, grid, block, shmem, stream, ...)                                                      \
+    do {                                                                                                         \
+        hipEvent_t fs_e0_, fs_e1_;                                                                               \
+        if (fs::g_census_on > 1 && fs::census_events(#kernel, (stream), &fs_e0_, &fs_e1_)) {                    \
+            hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, fs_e0_, fs_e1_, 0, __VA_ARGS__);           \
+        } else {                                                                                                 \
+            hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                                 \
+        }                                                                                                        \
     } while (0)
 
 // fs_conv2d_fwd_ws without its split-K reduction launch: when the kernel splits K across blocks the partial slabs stay in

@@ -296,7 +296,7 @@ static void launch_halo(hipStream_t st, HaloArgs& a) {
     a.tiles_y = (a.Ho + TH - 1) / TH;
     a.tiles_n = (a.Cout + BN - 1) / BN;
     const long long blocks = (long long)a.N * a.tiles_y * a.tiles_x * a.tiles_n;
-    hipLaunchKernelGGL((conv3x3_halo_kernel<T, WAVES_M, WAVES_N, WM_T, WN_T, STRIDE>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    FS_LAUNCH((conv3x3_halo_kernel<T, WAVES_M, WAVES_N, WM_T, WN_T, STRIDE>), dim3((unsigned)blocks), dim3(256), 0, st, a);
 }
 
 // Output-channel tile: 32, 64 or 128 per block (always 8 x 16 pixels).  `force` (FS_CONV_TILE_* in fs_conv_desc.flags) picks one;
@@ -342,10 +342,10 @@ extern "C" fs_status fs_pack_weight_frag(void* stream, const float* w, long long
     long long g = (total + 255) / 256;
     if (g > 8192) g = 8192;
     if (dtype == FS_F32)
-        hipLaunchKernelGGL((pack_weight_frag_kernel<float>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, w, o_stride, i_stride,
+        FS_LAUNCH((pack_weight_frag_kernel<float>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, w, o_stride, i_stride,
                            Cout, Cin, nchunks, total, (float*)out);
     else
-        hipLaunchKernelGGL((pack_weight_frag_kernel<bf16_t>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, w, o_stride, i_stride,
+        FS_LAUNCH((pack_weight_frag_kernel<bf16_t>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, w, o_stride, i_stride,
                            Cout, Cin, nchunks, total, (bf16_t*)out);
     return check_launch("fs_pack_weight_frag");
 }

@@ -502,7 +502,7 @@ static void launch_cfg(hipStream_t st, ConvArgs& a, float* ws = nullptr, long lo
     }
     if (slices > 1) {
         a.ws = ws;
-        hipLaunchKernelGGL((conv_igemm_kernel<T, WAVES_M, WAVES_N, WAVES_K, WM_T, WN_T, KSUB, VRES>),
+        FS_LAUNCH((conv_igemm_kernel<T, WAVES_M, WAVES_N, WAVES_K, WM_T, WN_T, KSUB, VRES>),
                            dim3((unsigned)(tiles_m * a.tiles_n), 1, (unsigned)slices), dim3(256), 0, st, a);
         if (t_defer_reduce) {
             t_slices = slices;
@@ -512,13 +512,13 @@ static void launch_cfg(hipStream_t st, ConvArgs& a, float* ws = nullptr, long lo
         const int rpb = 256 / cv;
         int rows = ((a.M + 511) / 512 + rpb - 1) / rpb * rpb;        // ~512 blocks, whole row groups per block
         if (rows < rpb) rows = rpb;
-        hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)((a.M + rows - 1) / rows)), dim3(256), 0, st, ws, slices, a.M,
+        FS_LAUNCH((splitk_reduce_kernel<T>), dim3((unsigned)((a.M + rows - 1) / rows)), dim3(256), 0, st, ws, slices, a.M,
                            a.Cout, a.scale, a.shift, (a.flags & FS_CONV_RELU) ? 1 : 0, (T*)a.y, a.y_cs, a.stats, rows);
         return;
     }
     a.ws = nullptr;
     a.k_slice = 0;
-    hipLaunchKernelGGL((conv_igemm_kernel<T, WAVES_M, WAVES_N, WAVES_K, WM_T, WN_T, KSUB, VRES>),
+    FS_LAUNCH((conv_igemm_kernel<T, WAVES_M, WAVES_N, WAVES_K, WM_T, WN_T, KSUB, VRES>),
                        dim3((unsigned)(tiles_m * a.tiles_n)), dim3(256), 0, st, a);
 }
 

@@ -498,7 +498,7 @@ extern "C" fs_status fs_pack_weight(void* stream, const float* w, long long o_st
     FS_REQUIRE(Cout > 0 && Cin > 0 && R > 0 && S > 0, FS_ERR_INVALID, "fs_pack_weight: bad shape");
     FS_REQUIRE(dtype == FS_F32 || dtype == FS_BF16, FS_ERR_INVALID, "fs_pack_weight: bad dtype");
     const long long total = (long long)Cout * Cin * R * S;
-    DT_DISPATCH(dtype, hipLaunchKernelGGL((pack_weight_kernel<T>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, w,
+    DT_DISPATCH(dtype, FS_LAUNCH((pack_weight_kernel<T>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, w,
                                           o_stride, i_stride, Cout, Cin, R, S, tflip, (T*)out);)
     return check_launch("fs_pack_weight");
 }
@@ -507,7 +507,7 @@ extern "C" fs_status fs_unpack_weight_grad(void* stream, const float* dw, int Co
                                            long long o_stride, long long i_stride, int accumulate) {
     FS_REQUIRE(dw && out, FS_ERR_INVALID, "fs_unpack_weight_grad: null pointer");
     const long long total = (long long)Cout * Cin * R * S;
-    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dw, Cout, Cin, R, S, out,
+    FS_LAUNCH(unpack_wgrad_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dw, Cout, Cin, R, S, out,
                        o_stride, i_stride, accumulate);
     return check_launch("fs_unpack_weight_grad");
 }
@@ -517,7 +517,7 @@ extern "C" fs_status fs_nchw_to_nhwc(void* stream, int N, int C, int H, int W, c
     FS_REQUIRE(x && y && N > 0 && C > 0 && H > 0 && W > 0, FS_ERR_INVALID, "fs_nchw_to_nhwc: bad argument");
     FS_REQUIRE(c_pad >= C && y_cs >= c_pad, FS_ERR_INVALID, "fs_nchw_to_nhwc: need C <= c_pad <= y_cs");
     dim3 grid((H * W + 63) / 64, N);
-    DT_DISPATCH(dtype, hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, C, H * W, x, (T*)y,
+    DT_DISPATCH(dtype, FS_LAUNCH((nchw_to_nhwc_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, C, H * W, x, (T*)y,
                                           y_cs, c_pad);)
     return check_launch("fs_nchw_to_nhwc");
 }
@@ -525,7 +525,7 @@ extern "C" fs_status fs_nchw_to_nhwc(void* stream, int N, int C, int H, int W, c
 extern "C" fs_status fs_nhwc_to_nchw(void* stream, int N, int C, int H, int W, const void* x, int x_cs, int dtype, float* y) {
     FS_REQUIRE(x && y && N > 0 && C > 0 && H > 0 && W > 0 && x_cs >= C, FS_ERR_INVALID, "fs_nhwc_to_nchw: bad argument");
     dim3 grid((H * W + 63) / 64, N);
-    DT_DISPATCH(dtype, hipLaunchKernelGGL((nhwc_to_nchw_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, C, H * W,
+    DT_DISPATCH(dtype, FS_LAUNCH((nhwc_to_nchw_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, C, H * W,
                                           (const T*)x, x_cs, y);)
     return check_launch("fs_nhwc_to_nchw");
 }
@@ -536,7 +536,7 @@ extern "C" fs_status fs_copy_channels(void* stream, long long pixels, int C, con
     if ((s = check_slice("fs_copy_channels", x, x_cs, C, dtype)) != FS_OK) return s;
     if ((s = check_slice("fs_copy_channels", y, y_cs, C, dtype)) != FS_OK) return s;
     const int cv = C / vec_elems(dtype);
-    DT_DISPATCH(dtype, hipLaunchKernelGGL((ew_kernel<T, EW_COPY>), dim3(grid_for(pixels * cv)), dim3(256), 0, (hipStream_t)stream,
+    DT_DISPATCH(dtype, FS_LAUNCH((ew_kernel<T, EW_COPY>), dim3(grid_for(pixels * cv)), dim3(256), 0, (hipStream_t)stream,
                                           pixels, cv, (const T*)x, x_cs, (T*)y, y_cs, nullptr, nullptr, 0);)
     return check_launch("fs_copy_channels");
 }
@@ -548,7 +548,7 @@ extern "C" fs_status fs_affine_act(void* stream, long long pixels, int C, const 
     if ((s = check_slice("fs_affine_act", y, y_cs, C, dtype)) != FS_OK) return s;
     FS_REQUIRE(scale && shift, FS_ERR_INVALID, "fs_affine_act: null scale/shift");
     const int cv = C / vec_elems(dtype);
-    DT_DISPATCH(dtype, hipLaunchKernelGGL((ew_kernel<T, EW_AFFINE>), dim3(grid_for(pixels * cv)), dim3(256), 0,
+    DT_DISPATCH(dtype, FS_LAUNCH((ew_kernel<T, EW_AFFINE>), dim3(grid_for(pixels * cv)), dim3(256), 0,
                                           (hipStream_t)stream, pixels, cv, (const T*)x, x_cs, (T*)y, y_cs, scale, shift, relu);)
     return check_launch("fs_affine_act");
 }
@@ -561,10 +561,10 @@ extern "C" fs_status fs_axpy_channels(void* stream, long long pixels, int C, con
     FS_REQUIRE(alpha, FS_ERR_INVALID, "fs_axpy_channels: null alpha");
     const int cv = C / vec_elems(dtype);
     if (accumulate) {
-        DT_DISPATCH(dtype, hipLaunchKernelGGL((ew_kernel<T, EW_AXPY_ACC>), dim3(grid_for(pixels * cv)), dim3(256), 0,
+        DT_DISPATCH(dtype, FS_LAUNCH((ew_kernel<T, EW_AXPY_ACC>), dim3(grid_for(pixels * cv)), dim3(256), 0,
                                               (hipStream_t)stream, pixels, cv, (const T*)x, x_cs, (T*)y, y_cs, alpha, nullptr, 0);)
     } else {
-        DT_DISPATCH(dtype, hipLaunchKernelGGL((ew_kernel<T, EW_AXPY>), dim3(grid_for(pixels * cv)), dim3(256), 0,
+        DT_DISPATCH(dtype, FS_LAUNCH((ew_kernel<T, EW_AXPY>), dim3(grid_for(pixels * cv)), dim3(256), 0,
                                               (hipStream_t)stream, pixels, cv, (const T*)x, x_cs, (T*)y, y_cs, alpha, nullptr, 0);)
     }
     return check_launch("fs_axpy_channels");
@@ -592,7 +592,7 @@ extern "C" fs_status fs_channel_stats_g(void* stream, long long pixels, int C, i
     long long ppb;
     const long long mg = pixels / groups;
     const int blocks = reduce_blocks(mg, 256 / cv, &ppb);
-    DT_DISPATCH(dtype, hipLaunchKernelGGL((chan_reduce_kernel<T, 0>), dim3(blocks, groups), dim3(256), 0, (hipStream_t)stream, pixels, C,
+    DT_DISPATCH(dtype, FS_LAUNCH((chan_reduce_kernel<T, 0>), dim3(blocks, groups), dim3(256), 0, (hipStream_t)stream, pixels, C,
                                           (const T*)x, x_cs, (const T*)nullptr, 0, (const T*)nullptr, 0, nullptr, nullptr, 0,
                                           stats, ppb, mg, 0);)
     return check_launch("fs_channel_stats");
@@ -606,7 +606,7 @@ extern "C" fs_status fs_bn_finalize(void* stream, int C, long long count, const 
                                     const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                                     float* mean, float* invstd, float* scale, float* shift, long long* num_batches_tracked) {
     FS_REQUIRE(stats && C > 0 && count > 0, FS_ERR_INVALID, "fs_bn_finalize: bad argument");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, C, (float)count, stats, gamma,
+    FS_LAUNCH(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, C, (float)count, stats, gamma,
                        beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift, num_batches_tracked);
     return check_launch("fs_bn_finalize");
 }
@@ -627,7 +627,7 @@ extern "C" fs_status fs_bn_bwd_reduce_g(void* stream, long long pixels, int C, i
     long long ppb;
     const long long mg = pixels / groups;
     const int blocks = reduce_blocks(mg, 256 / cv, &ppb);
-    DT_DISPATCH(dtype, hipLaunchKernelGGL((chan_reduce_kernel<T, 1>), dim3(blocks, groups), dim3(256), 0, (hipStream_t)stream, pixels, C,
+    DT_DISPATCH(dtype, FS_LAUNCH((chan_reduce_kernel<T, 1>), dim3(blocks, groups), dim3(256), 0, (hipStream_t)stream, pixels, C,
                                           (const T*)x, x_cs, (const T*)dy, dy_cs, (const T*)y_out, y_cs, mean, invstd, relu, red,
                                           ppb, mg, saved_stride);)
     return check_launch("fs_bn_bwd_reduce");
@@ -652,7 +652,7 @@ extern "C" fs_status fs_bn_bwd_apply_g(void* stream, long long pixels, int C, in
     FS_REQUIRE(mean && invstd && gamma && red && count > 0, FS_ERR_INVALID, "fs_bn_bwd_apply: bad argument");
     FS_REQUIRE(groups >= 1 && pixels % groups == 0, FS_ERR_INVALID, "fs_bn_bwd_apply: %lld pixels in %d groups", pixels, groups);
     const int cv = C / vec_elems(dtype);
-    DT_DISPATCH(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(grid_for(pixels * cv)), dim3(256), 0, (hipStream_t)stream,
+    DT_DISPATCH(dtype, FS_LAUNCH((bn_bwd_apply_kernel<T>), dim3(grid_for(pixels * cv)), dim3(256), 0, (hipStream_t)stream,
                                           pixels, cv, (const T*)x, x_cs, (const T*)dy, dy_cs, (const T*)y_out, y_cs, mean, invstd,
                                           gamma, red, 1.0f / (float)count, relu, (T*)dx, dx_cs, dgamma_acc, dbeta_acc, groups,
                                           saved_stride, red_total);)
@@ -674,7 +674,7 @@ extern "C" fs_status fs_dot(void* stream, long long pixels, int C, const void* x
     if ((s = check_slice("fs_dot", y, y_cs, C, dtype)) != FS_OK) return s;
     FS_REQUIRE(out, FS_ERR_INVALID, "fs_dot: null out");
     const int cv = C / vec_elems(dtype);
-    DT_DISPATCH(dtype, hipLaunchKernelGGL((dot_kernel<T>), dim3(grid_for(pixels * cv, 256, 1024)), dim3(256), 0,
+    DT_DISPATCH(dtype, FS_LAUNCH((dot_kernel<T>), dim3(grid_for(pixels * cv, 256, 1024)), dim3(256), 0,
                                           (hipStream_t)stream, pixels, cv, (const T*)x, x_cs, (const T*)y, y_cs, out);)
     return check_launch("fs_dot");
 }
@@ -702,7 +702,7 @@ extern "C" fs_status fs_weighted_sum(void* stream, long long pixels, int C, int 
     if ((s = check_slice("fs_weighted_sum", out, out_cs, C, dtype)) != FS_OK) return s;
     FS_REQUIRE(coef, FS_ERR_INVALID, "fs_weighted_sum: null coefficients");
     const int cv = C / vec_elems(dtype);
-    DT_DISPATCH(dtype, hipLaunchKernelGGL((wsum_kernel<T>), dim3(grid_for(pixels * cv)), dim3(256), 0, (hipStream_t)stream, pixels,
+    DT_DISPATCH(dtype, FS_LAUNCH((wsum_kernel<T>), dim3(grid_for(pixels * cv)), dim3(256), 0, (hipStream_t)stream, pixels,
                                           cv, a, coef, (T*)out, out_cs);)
     return check_launch("fs_weighted_sum");
 }
@@ -715,7 +715,7 @@ extern "C" fs_status fs_weighted_sum_bwd(void* stream, long long pixels, int C, 
     if ((s = check_slice("fs_weighted_sum_bwd", dy, dy_cs, C, dtype)) != FS_OK) return s;
     FS_REQUIRE(coef, FS_ERR_INVALID, "fs_weighted_sum_bwd: null coefficients");
     const int cv = C / vec_elems(dtype);
-    DT_DISPATCH(dtype, hipLaunchKernelGGL((wsum_bwd_kernel<T>), dim3(grid_for(pixels * cv)), dim3(256), 0, (hipStream_t)stream,
+    DT_DISPATCH(dtype, FS_LAUNCH((wsum_bwd_kernel<T>), dim3(grid_for(pixels * cv)), dim3(256), 0, (hipStream_t)stream,
                                           pixels, cv, (const T*)dy, dy_cs, coef, a);)
     return check_launch("fs_weighted_sum_bwd");
 }
@@ -728,7 +728,7 @@ extern "C" fs_status fs_weighted_sum_dots(void* stream, long long pixels, int C,
     if ((s = check_slice("fs_weighted_sum_dots", dy, dy_cs, C, dtype)) != FS_OK) return s;
     FS_REQUIRE(out, FS_ERR_INVALID, "fs_weighted_sum_dots: null out");
     const int cv = C / vec_elems(dtype);
-    DT_DISPATCH(dtype, hipLaunchKernelGGL((wsum_dot_kernel<T>), dim3(grid_for(pixels * cv, 256, 1024)), dim3(256), 0,
+    DT_DISPATCH(dtype, FS_LAUNCH((wsum_dot_kernel<T>), dim3(grid_for(pixels * cv, 256, 1024)), dim3(256), 0,
                                           (hipStream_t)stream, pixels, cv, (const T*)dy, dy_cs, a, out);)
     return check_launch("fs_weighted_sum_dots");
 }
@@ -743,7 +743,7 @@ extern "C" fs_status fs_bn_train_apply_g(void* stream, long long pixels, int C, 
     FS_REQUIRE(stats && saved && pixels > 0, FS_ERR_INVALID, "fs_bn_train_apply: bad argument");
     FS_REQUIRE(groups >= 1 && pixels % groups == 0, FS_ERR_INVALID, "fs_bn_train_apply: %lld pixels in %d groups", pixels, groups);
     const int cv = C / vec_elems(dtype);
-    DT_DISPATCH(dtype, hipLaunchKernelGGL((bn_train_apply_kernel<T>), dim3(grid_for(pixels * cv)), dim3(256), 0, (hipStream_t)stream,
+    DT_DISPATCH(dtype, FS_LAUNCH((bn_train_apply_kernel<T>), dim3(grid_for(pixels * cv)), dim3(256), 0, (hipStream_t)stream,
                                           pixels, cv, (const T*)x, x_cs, stats, (float)(pixels / groups), gamma, beta, eps, momentum,
                                           running_mean, running_var, num_batches_tracked, saved, (T*)y, y_cs, relu, groups);)
     return check_launch("fs_bn_train_apply");

@@ -170,15 +170,16 @@ extern "C" fs_status fs_bilinear_argmax(void* stream, const fs_resize_desc* d, c
     const float rh = d->Ho > 1 ? (float)(d->Hi - 1) / (float)(d->Ho - 1) : 0.f;
     const float rw = d->Wo > 1 ? (float)(d->Wi - 1) / (float)(d->Wo - 1) : 0.f;
     hipStream_t st = (hipStream_t)stream;
-    if (d->Wo == 8 * d->Wi && d->Wi >= 2 && d->C <= 20 && (reinterpret_cast<uintptr_t>(classes) & 7) == 0) {      // the x8 logits up-sample
+    // the x8 logits up-sample; the kernel loads 20 channels of every source pixel, so the channel stride must cover them
+    if (d->Wo == 8 * d->Wi && d->Wi >= 2 && d->C <= 20 && d->x_cs >= 20 && (reinterpret_cast<uintptr_t>(classes) & 7) == 0) {
         const long long total8 = (long long)d->N * d->Ho * (d->Wo / 8);
         long long g8 = (total8 + 255) / 256;
         if (g8 > 16384) g8 = 16384;
         if (d->dtype == FS_F32)
-            hipLaunchKernelGGL((bilinear_argmax8_kernel<float, 5>), dim3((unsigned)g8), dim3(256), 0, st, d->N, d->Hi, d->Wi, d->Ho, d->Wo, d->C,
+            FS_LAUNCH((bilinear_argmax8_kernel<float, 5>), dim3((unsigned)g8), dim3(256), 0, st, d->N, d->Hi, d->Wi, d->Ho, d->Wo, d->C,
                                rh, rw, (const float*)x, d->x_cs, classes);
         else
-            hipLaunchKernelGGL((bilinear_argmax8_kernel<bf16_t, 5>), dim3((unsigned)g8), dim3(256), 0, st, d->N, d->Hi, d->Wi, d->Ho, d->Wo, d->C,
+            FS_LAUNCH((bilinear_argmax8_kernel<bf16_t, 5>), dim3((unsigned)g8), dim3(256), 0, st, d->N, d->Hi, d->Wi, d->Ho, d->Wo, d->C,
                                rh, rw, (const bf16_t*)x, d->x_cs, classes);
         return check_launch("fs_bilinear_argmax");
     }
@@ -186,10 +187,10 @@ extern "C" fs_status fs_bilinear_argmax(void* stream, const fs_resize_desc* d, c
     long long g = (total + 255) / 256;
     if (g > 16384) g = 16384;
     if (d->dtype == FS_F32)
-        hipLaunchKernelGGL((bilinear_argmax_kernel<float>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, d->N, d->Hi, d->Wi, d->Ho,
+        FS_LAUNCH((bilinear_argmax_kernel<float>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, d->N, d->Hi, d->Wi, d->Ho,
                            d->Wo, d->C, rh, rw, (const float*)x, d->x_cs, classes);
     else
-        hipLaunchKernelGGL((bilinear_argmax_kernel<bf16_t>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, d->N, d->Hi, d->Wi,
+        FS_LAUNCH((bilinear_argmax_kernel<bf16_t>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, d->N, d->Hi, d->Wi,
                            d->Ho, d->Wo, d->C, rh, rw, (const bf16_t*)x, d->x_cs, classes);
     return check_launch("fs_bilinear_argmax");
 }
@@ -207,10 +208,10 @@ extern "C" fs_status fs_hist_info(void* stream, const unsigned char* pred, const
     const size_t lds = (size_t)(n_cl * n_cl + 2) * sizeof(unsigned int);
     hipStream_t st = (hipStream_t)stream;
     if (gt_bytes == 1)
-        hipLaunchKernelGGL((hist_info_kernel<unsigned char>), dim3((unsigned)g), dim3(256), lds, st, pred, (const unsigned char*)gt, n, n_cl, hist, counts);
+        FS_LAUNCH((hist_info_kernel<unsigned char>), dim3((unsigned)g), dim3(256), lds, st, pred, (const unsigned char*)gt, n, n_cl, hist, counts);
     else if (gt_bytes == 4)
-        hipLaunchKernelGGL((hist_info_kernel<int>), dim3((unsigned)g), dim3(256), lds, st, pred, (const int*)gt, n, n_cl, hist, counts);
+        FS_LAUNCH((hist_info_kernel<int>), dim3((unsigned)g), dim3(256), lds, st, pred, (const int*)gt, n, n_cl, hist, counts);
     else
-        hipLaunchKernelGGL((hist_info_kernel<long long>), dim3((unsigned)g), dim3(256), lds, st, pred, (const long long*)gt, n, n_cl, hist, counts);
+        FS_LAUNCH((hist_info_kernel<long long>), dim3((unsigned)g), dim3(256), lds, st, pred, (const long long*)gt, n, n_cl, hist, counts);
     return check_launch("fs_hist_info");
 }

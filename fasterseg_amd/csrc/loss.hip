@@ -108,7 +108,7 @@ extern "C" fs_status fs_kl_distill_fwd(void* stream, const float* student, const
     const long long P = B * HW;
     long long blocks = (P + 255) / 256;
     if (blocks > 65536) blocks = 65536;
-    hipLaunchKernelGGL(kl_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, student, teacher, C, HW, P, kl, lse_s,
+    FS_LAUNCH(kl_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, student, teacher, C, HW, P, kl, lse_s,
                        lse_t);
     return check_launch("fs_kl_distill_fwd");
 }
@@ -120,7 +120,7 @@ extern "C" fs_status fs_kl_distill_bwd(void* stream, const float* student, const
     const long long P = B * HW;
     long long blocks = (P + 255) / 256;
     if (blocks > 65536) blocks = 65536;
-    hipLaunchKernelGGL(kl_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, student, teacher, lse_s, lse_t, scale,
+    FS_LAUNCH(kl_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, student, teacher, lse_s, lse_t, scale,
                        C, HW, P, d_student);
     return check_launch("fs_kl_distill_bwd");
 }
@@ -131,7 +131,7 @@ extern "C" fs_status fs_ohem_ce_fwd(void* stream, const float* logits, const lon
     const long long P = B * HW;
     long long blocks = (P + 255) / 256;
     if (blocks > 65536) blocks = 65536;
-    hipLaunchKernelGGL(ohem_ce_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, logits, target, C, HW, P, ignore,
+    FS_LAUNCH(ohem_ce_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, logits, target, C, HW, P, ignore,
                        true_prob, nll, lse);
     return check_launch("fs_ohem_ce_fwd");
 }
@@ -144,7 +144,7 @@ extern "C" fs_status fs_ohem_ce_bwd(void* stream, const float* logits, const lon
     const long long P = B * HW;
     long long blocks = (P + 255) / 256;
     if (blocks > 65536) blocks = 65536;
-    hipLaunchKernelGGL(ohem_ce_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, logits, target, lse, kept, scale,
+    FS_LAUNCH(ohem_ce_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, logits, target, lse, kept, scale,
                        C, HW, P, dlogits);
     return check_launch("fs_ohem_ce_bwd");
 }

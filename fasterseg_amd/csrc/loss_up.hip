@@ -316,10 +316,10 @@ extern "C" fs_status fs_ohem_ce_up_fwd(void* stream, const fs_logits_desc* d, co
     const long long P = (long long)g.N * g.H * g.W;
     hipStream_t st = (hipStream_t)stream;
     if (d->dtype == FS_F32)
-        hipLaunchKernelGGL((ohem_up_fwd_kernel<float>), dim3(pixel_blocks(P)), dim3(256), 0, st, (const float*)logits_lo, target, g, ignore,
+        FS_LAUNCH((ohem_up_fwd_kernel<float>), dim3(pixel_blocks(P)), dim3(256), 0, st, (const float*)logits_lo, target, g, ignore,
                            true_prob, nll, lse);
     else
-        hipLaunchKernelGGL((ohem_up_fwd_kernel<bf16_t>), dim3(pixel_blocks(P)), dim3(256), 0, st, (const bf16_t*)logits_lo, target, g, ignore,
+        FS_LAUNCH((ohem_up_fwd_kernel<bf16_t>), dim3(pixel_blocks(P)), dim3(256), 0, st, (const bf16_t*)logits_lo, target, g, ignore,
                            true_prob, nll, lse);
     return check_launch("fs_ohem_ce_up_fwd");
 }
@@ -337,12 +337,12 @@ static void launch_up_bwd(hipStream_t st, const UpGeom& g, const void* s_lo, con
     const long long cells = (long long)g.N * g.h * g.w;
     const double area = ((double)g.H / g.h) * ((double)g.W / g.w);
     if (area <= 100.0)           // x8 heads: cells of 8-9 x 8-9 pixels, one wave each
-        hipLaunchKernelGGL((up_bwd_cells_kernel<TS, TT, OHEM, 1>), dim3((unsigned)((cells + 3) / 4)), dim3(256), 0, st, (const TS*)s_lo, g,
+        FS_LAUNCH((up_bwd_cells_kernel<TS, TT, OHEM, 1>), dim3((unsigned)((cells + 3) / 4)), dim3(256), 0, st, (const TS*)s_lo, g,
                            (const TT*)t_lo, gt, lse_s, lse_t, target, kept, ws);
     else                         // x16 / x32: 17 x 17 / 33 x 33 pixels over a block
-        hipLaunchKernelGGL((up_bwd_cells_kernel<TS, TT, OHEM, 4>), dim3((unsigned)cells), dim3(256), 0, st, (const TS*)s_lo, g,
+        FS_LAUNCH((up_bwd_cells_kernel<TS, TT, OHEM, 4>), dim3((unsigned)cells), dim3(256), 0, st, (const TS*)s_lo, g,
                            (const TT*)t_lo, gt, lse_s, lse_t, target, kept, ws);
-    hipLaunchKernelGGL((up_bwd_gather_kernel<TS>), dim3(pixel_blocks(cells * g.cs)), dim3(256), 0, st, ws, g, scale, (TS*)dlo);
+    FS_LAUNCH((up_bwd_gather_kernel<TS>), dim3(pixel_blocks(cells * g.cs)), dim3(256), 0, st, ws, g, scale, (TS*)dlo);
 }
 
 extern "C" fs_status fs_ohem_ce_up_bwd(void* stream, const fs_logits_desc* d, const void* logits_lo, const long long* target,
@@ -371,7 +371,7 @@ extern "C" fs_status fs_kl_distill_up_fwd(void* stream, const fs_logits_desc* ds
     const long long P = (long long)gs.N * gs.H * gs.W;
     const dim3 grid(pixel_blocks(P));
     hipStream_t st = (hipStream_t)stream;
-#define FS_KL_FWD(TS, TT) hipLaunchKernelGGL((kl_up_fwd_kernel<TS, TT>), grid, dim3(256), 0, st, (const TS*)student_lo, gs, (const TT*)teacher_lo, gt, kl, lse_s, lse_t)
+#define FS_KL_FWD(TS, TT) FS_LAUNCH((kl_up_fwd_kernel<TS, TT>), grid, dim3(256), 0, st, (const TS*)student_lo, gs, (const TT*)teacher_lo, gt, kl, lse_s, lse_t)
     if (ds->dtype == FS_F32 && dt->dtype == FS_F32) FS_KL_FWD(float, float);
     else if (ds->dtype == FS_F32) FS_KL_FWD(float, bf16_t);
     else if (dt->dtype == FS_F32) FS_KL_FWD(bf16_t, float);

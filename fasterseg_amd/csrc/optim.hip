@@ -125,10 +125,10 @@ extern "C" fs_status fs_sgd_momentum_multi(void* stream, const fs_sgd_tensor* te
     FS_REQUIRE(pack_only || (grads && momentum_buf), FS_ERR_INVALID, "fs_sgd_momentum_multi: null gradient / momentum buffer");
     FS_REQUIRE(pack_dtype == FS_F32 || pack_dtype == FS_BF16, FS_ERR_INVALID, "fs_sgd_momentum_multi: bad pack dtype %d", pack_dtype);
     if (pack_dtype == FS_F32)
-        hipLaunchKernelGGL((sgd_multi_kernel<float>), dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, tensors, chunks, touched,
+        FS_LAUNCH((sgd_multi_kernel<float>), dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, tensors, chunks, touched,
                            grads, momentum_buf, grad_scale, lr, momentum, weight_decay, pack_only);
     else
-        hipLaunchKernelGGL((sgd_multi_kernel<bf16_t>), dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, tensors, chunks, touched,
+        FS_LAUNCH((sgd_multi_kernel<bf16_t>), dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, tensors, chunks, touched,
                            grads, momentum_buf, grad_scale, lr, momentum, weight_decay, pack_only);
     return check_launch("fs_sgd_momentum_multi");
 }

@@ -375,10 +375,10 @@ extern "C" fs_status fs_bilinear_fwd(void* stream, const fs_resize_desc* d, cons
         const int cv = d->C / vec_elems(d->dtype);
         const long long total = (long long)d->N * d->Ho * d->Wo * cv;
         if (d->dtype == FS_F32)
-            hipLaunchKernelGGL((bilinear_fwd_kernel<float>), dim3(grid_for(total)), dim3(256), 0, st, d->N, d->Hi, d->Wi, d->Ho,
+            FS_LAUNCH((bilinear_fwd_kernel<float>), dim3(grid_for(total)), dim3(256), 0, st, d->N, d->Hi, d->Wi, d->Ho,
                                d->Wo, cv, rh, rw, (const float*)x, d->x_cs, (float*)y, d->y_cs, d->relu);
         else
-            hipLaunchKernelGGL((bilinear_fwd_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, st, d->N, d->Hi, d->Wi, d->Ho,
+            FS_LAUNCH((bilinear_fwd_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, st, d->N, d->Hi, d->Wi, d->Ho,
                                d->Wo, cv, rh, rw, (const bf16_t*)x, d->x_cs, (bf16_t*)y, d->y_cs, d->relu);
     } else {
         const bool out_f32 = (d->out_nchw == 1) || d->dtype == FS_F32;
@@ -386,25 +386,25 @@ extern "C" fs_status fs_bilinear_fwd(void* stream, const fs_resize_desc* d, cons
             const long long total = (long long)d->N * ((d->C + 3) / 4) * d->Ho * (d->Wo / 4);
             const dim3 g(grid_for(total));
             if (d->dtype == FS_F32)
-                hipLaunchKernelGGL((bilinear_fwd_nchw_kernel<float, float>), g, dim3(256), 0, st, d->N, d->Hi, d->Wi, d->Ho, d->Wo,
+                FS_LAUNCH((bilinear_fwd_nchw_kernel<float, float>), g, dim3(256), 0, st, d->N, d->Hi, d->Wi, d->Ho, d->Wo,
                                    d->C, rh, rw, (const float*)x, d->x_cs, (float*)y);
             else if (out_f32)
-                hipLaunchKernelGGL((bilinear_fwd_nchw_kernel<bf16_t, float>), g, dim3(256), 0, st, d->N, d->Hi, d->Wi, d->Ho, d->Wo,
+                FS_LAUNCH((bilinear_fwd_nchw_kernel<bf16_t, float>), g, dim3(256), 0, st, d->N, d->Hi, d->Wi, d->Ho, d->Wo,
                                    d->C, rh, rw, (const bf16_t*)x, d->x_cs, (float*)y);
             else
-                hipLaunchKernelGGL((bilinear_fwd_nchw_kernel<bf16_t, bf16_t>), g, dim3(256), 0, st, d->N, d->Hi, d->Wi, d->Ho,
+                FS_LAUNCH((bilinear_fwd_nchw_kernel<bf16_t, bf16_t>), g, dim3(256), 0, st, d->N, d->Hi, d->Wi, d->Ho,
                                    d->Wo, d->C, rh, rw, (const bf16_t*)x, d->x_cs, (bf16_t*)y);
         } else {
             const long long total = (long long)d->N * d->C * d->Ho * d->Wo;
             const dim3 g(grid_for(total));
             if (d->dtype == FS_F32)
-                hipLaunchKernelGGL((bilinear_fwd_nchw_scalar_kernel<float, float>), g, dim3(256), 0, st, d->N, d->Hi, d->Wi, d->Ho,
+                FS_LAUNCH((bilinear_fwd_nchw_scalar_kernel<float, float>), g, dim3(256), 0, st, d->N, d->Hi, d->Wi, d->Ho,
                                    d->Wo, d->C, rh, rw, (const float*)x, d->x_cs, (float*)y);
             else if (out_f32)
-                hipLaunchKernelGGL((bilinear_fwd_nchw_scalar_kernel<bf16_t, float>), g, dim3(256), 0, st, d->N, d->Hi, d->Wi, d->Ho,
+                FS_LAUNCH((bilinear_fwd_nchw_scalar_kernel<bf16_t, float>), g, dim3(256), 0, st, d->N, d->Hi, d->Wi, d->Ho,
                                    d->Wo, d->C, rh, rw, (const bf16_t*)x, d->x_cs, (float*)y);
             else
-                hipLaunchKernelGGL((bilinear_fwd_nchw_scalar_kernel<bf16_t, bf16_t>), g, dim3(256), 0, st, d->N, d->Hi, d->Wi,
+                FS_LAUNCH((bilinear_fwd_nchw_scalar_kernel<bf16_t, bf16_t>), g, dim3(256), 0, st, d->N, d->Hi, d->Wi,
                                    d->Ho, d->Wo, d->C, rh, rw, (const bf16_t*)x, d->x_cs, (bf16_t*)y);
         }
     }
@@ -419,13 +419,13 @@ extern "C" fs_status fs_bilinear_bwd_nchw(void* stream, const fs_resize_desc* d,
     const float rh = host_scale(d->Hi, d->Ho), rw = host_scale(d->Wi, d->Wo);
     hipStream_t st = (hipStream_t)stream;
     const long long rows = (long long)d->N * d->C * d->Ho;
-    hipLaunchKernelGGL(bilinear_bwd_nchw_w_kernel, dim3(grid_for(rows * d->Wi)), dim3(256), 0, st, rows, d->Wi, d->Wo, rw, dy, workspace);
+    FS_LAUNCH(bilinear_bwd_nchw_w_kernel, dim3(grid_for(rows * d->Wi)), dim3(256), 0, st, rows, d->Wi, d->Wo, rw, dy, workspace);
     const long long total = (long long)d->N * d->C * d->Hi * d->Wi;
     if (d->dtype == FS_F32)
-        hipLaunchKernelGGL((bilinear_bwd_nchw_h_kernel<float>), dim3(grid_for(total)), dim3(256), 0, st, d->N, d->C, d->Hi, d->Wi, d->Ho,
+        FS_LAUNCH((bilinear_bwd_nchw_h_kernel<float>), dim3(grid_for(total)), dim3(256), 0, st, d->N, d->C, d->Hi, d->Wi, d->Ho,
                            rh, workspace, (float*)dx, d->x_cs);
     else
-        hipLaunchKernelGGL((bilinear_bwd_nchw_h_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, st, d->N, d->C, d->Hi, d->Wi,
+        FS_LAUNCH((bilinear_bwd_nchw_h_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, st, d->N, d->C, d->Hi, d->Wi,
                            d->Ho, rh, workspace, (bf16_t*)dx, d->x_cs);
     return check_launch("fs_bilinear_bwd_nchw");
 }
@@ -441,21 +441,21 @@ extern "C" fs_status fs_bilinear_bwd(void* stream, const fs_resize_desc* d, cons
         const int cv = d->C / vec_elems(d->dtype);
         const long long total = (long long)d->N * d->Hi * d->Wi * cv;
         if (d->dtype == FS_F32)
-            hipLaunchKernelGGL((bilinear_bwd_kernel<float>), dim3(grid_for(total)), dim3(256), 0, st, d->N, d->Hi, d->Wi, d->Ho,
+            FS_LAUNCH((bilinear_bwd_kernel<float>), dim3(grid_for(total)), dim3(256), 0, st, d->N, d->Hi, d->Wi, d->Ho,
                                d->Wo, cv, rh, rw, (const float*)dy, d->y_cs, (const float*)y_out, d->y_cs, d->relu, (float*)dx,
                                d->x_cs);
         else
-            hipLaunchKernelGGL((bilinear_bwd_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, st, d->N, d->Hi, d->Wi, d->Ho,
+            FS_LAUNCH((bilinear_bwd_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, st, d->N, d->Hi, d->Wi, d->Ho,
                                d->Wo, cv, rh, rw, (const bf16_t*)dy, d->y_cs, (const bf16_t*)y_out, d->y_cs, d->relu, (bf16_t*)dx,
                                d->x_cs);
     } else {
         FS_REQUIRE(d->out_nchw == 1 || d->dtype == FS_F32, FS_ERR_UNSUPPORTED, "fs_bilinear_bwd: NCHW gradient must be fp32");
         const long long total = (long long)d->N * d->Hi * d->Wi * d->C;
         if (d->dtype == FS_F32)
-            hipLaunchKernelGGL((bilinear_bwd_nchw_kernel<float>), dim3(grid_for(total)), dim3(256), 0, st, d->N, d->Hi, d->Wi,
+            FS_LAUNCH((bilinear_bwd_nchw_kernel<float>), dim3(grid_for(total)), dim3(256), 0, st, d->N, d->Hi, d->Wi,
                                d->Ho, d->Wo, d->C, rh, rw, (const float*)dy, (float*)dx, d->x_cs);
         else
-            hipLaunchKernelGGL((bilinear_bwd_nchw_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, st, d->N, d->Hi, d->Wi,
+            FS_LAUNCH((bilinear_bwd_nchw_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, st, d->N, d->Hi, d->Wi,
                                d->Ho, d->Wo, d->C, rh, rw, (const float*)dy, (bf16_t*)dx, d->x_cs);
     }
     return check_launch("fs_bilinear_bwd");

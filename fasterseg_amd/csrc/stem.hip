@@ -287,15 +287,15 @@ extern "C" fs_status fs_conv_stem_fwd(void* stream, int N, int H, int W, int Cou
     if (W % 4 == 0 && aligned16(x) && N <= 65535) {          // LDS-tiled kernels: coalesced 16-byte image loads
         dim3 tiles((unsigned)((Wo + S_TW - 1) / S_TW), (unsigned)((Ho + S_TH - 1) / S_TH), (unsigned)N);
         if (dtype == FS_BF16 && Cout <= 64 && Cout % 8 == 0 && g_stem_mfma) {      // matrix-core form (split-bf16 operands)
-            hipLaunchKernelGGL(stem_mfma_kernel, tiles, dim3(256), 0, (hipStream_t)stream, H, W, Ho, Wo, Cout, x, w, scale, shift,
+            FS_LAUNCH(stem_mfma_kernel, tiles, dim3(256), 0, (hipStream_t)stream, H, W, Ho, Wo, Cout, x, w, scale, shift,
                                (bf16_t*)y, y_cs, relu);
             return check_launch("fs_conv_stem_fwd");
         }
         if (dtype == FS_F32)
-            hipLaunchKernelGGL((stem_lds_kernel<float>), tiles, dim3(256), 0, (hipStream_t)stream, H, W, Ho, Wo, Cout, x, w, scale,
+            FS_LAUNCH((stem_lds_kernel<float>), tiles, dim3(256), 0, (hipStream_t)stream, H, W, Ho, Wo, Cout, x, w, scale,
                                shift, (float*)y, y_cs, relu);
         else
-            hipLaunchKernelGGL((stem_lds_kernel<bf16_t>), tiles, dim3(256), 0, (hipStream_t)stream, H, W, Ho, Wo, Cout, x, w, scale,
+            FS_LAUNCH((stem_lds_kernel<bf16_t>), tiles, dim3(256), 0, (hipStream_t)stream, H, W, Ho, Wo, Cout, x, w, scale,
                                shift, (bf16_t*)y, y_cs, relu);
         return check_launch("fs_conv_stem_fwd");
     }
@@ -304,10 +304,10 @@ extern "C" fs_status fs_conv_stem_fwd(void* stream, int N, int H, int W, int Cou
     if (gx > 32768) gx = 32768;
     dim3 grid((unsigned)gx, (Cout + 15) / 16);
     if (dtype == FS_F32)
-        hipLaunchKernelGGL((stem_conv_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, N, H, W, Ho, Wo, Cout, x, w, scale,
+        FS_LAUNCH((stem_conv_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, N, H, W, Ho, Wo, Cout, x, w, scale,
                            shift, (float*)y, y_cs, relu);
     else
-        hipLaunchKernelGGL((stem_conv_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, N, H, W, Ho, Wo, Cout, x, w, scale,
+        FS_LAUNCH((stem_conv_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, N, H, W, Ho, Wo, Cout, x, w, scale,
                            shift, (bf16_t*)y, y_cs, relu);
     return check_launch("fs_conv_stem_fwd");
 }

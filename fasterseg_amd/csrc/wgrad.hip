@@ -210,7 +210,7 @@ static fs_status wgrad_impl(void* stream, const fs_conv_desc* d, const void* x, 
     a.slab = slab;
     dim3 grid((unsigned)((M + slab - 1) / slab), (unsigned)(tiles_co * a.tiles_ci), (unsigned)taps);
     FS_CENSUS(FS_CENSUS_WGRAD, d);
-    if (d->dtype == FS_F32) hipLaunchKernelGGL((wgrad_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((wgrad_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    if (d->dtype == FS_F32) FS_LAUNCH((wgrad_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    else FS_LAUNCH((wgrad_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("fs_conv2d_wgrad");
 }

@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256) void zoom_cell_kernel(ZoomArgs p) {
 
 template <typename T, int NT> static void launch_zoom(hipStream_t st, const ZoomArgs& a) {
     const long long blocks = (long long)a.N * a.tiles_y * a.tiles_x;
-    hipLaunchKernelGGL((zoom_cell_kernel<T, NT>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    FS_LAUNCH((zoom_cell_kernel<T, NT>), dim3((unsigned)blocks), dim3(256), 0, st, a);
 }
 
 static inline float zoom_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }

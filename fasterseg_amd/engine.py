@@ -100,13 +100,20 @@ class InferenceEngine:
         # tuned on an idle device can be replayed under a profiler, whose counters perturb the timings it would otherwise tune on)
         self._plan_path = os.environ.get("FS_ENGINE_PLAN")
         self._plan_in, self._plan_out = None, {"convs": [], "cells": []}
-        if self._plan_path:
-            self._plan_path = "%s.%s.%s" % (self._plan_path, output, "bf16" if dtype == torch.bfloat16 else "fp32")
-            if os.path.exists(self._plan_path):
-                import json
-                with open(self._plan_path) as f:
-                    self._plan_in = json.load(f)
         self._trace(net)
+        if self._plan_path:
+            # a plan is replayed by position, so it is only valid for the network and input it was tuned on: its file name and
+            # its "signature" field carry a hash of (input shape, traced op kinds and output shapes); a mismatch re-tunes
+            import hashlib
+            import json
+            sig = hashlib.sha1(repr((tuple(self.input_shape), [(op["kind"], tuple(op["out"].shape)) for op in self.ops])).encode()).hexdigest()[:12]
+            self._plan_out["signature"] = sig
+            self._plan_path = "%s.%s.%s.%s" % (self._plan_path, output, "bf16" if dtype == torch.bfloat16 else "fp32", sig)
+            if os.path.exists(self._plan_path):
+                with open(self._plan_path) as f:
+                    plan = json.load(f)
+                if plan.get("signature") == sig:
+                    self._plan_in = plan
         self._fuse_cells()
         self._fuse_resizes()
         self._assign_buffers()
@@ -939,10 +946,44 @@ class InferenceEngine:
         self.input.copy_(x)
         return self.run()
 
-    def census_entries(self):
-        """The plan's convolution launches as (family, descriptor, count) tuples in fasterseg_amd.census form."""
+    def census_entries(self, timed_rows=None):
+        """The plan's convolution launches as (family, descriptor, count, ms) tuples in fasterseg_amd.census form; ms from
+        `timed_rows` = profile_in_frame() when given."""
         fam = {"fs_conv2d_fwd_ws": 0, "fs_conv2d_fwd": 0, "fs_conv3x3_s1_fwd": 1}
-        return [(fam[c["fn"]], c["desc"], 1) for c in self.calls if c["fn"] in fam]
+        return [(fam[c["fn"]], c["desc"], 1, timed_rows[i]["ms"] if timed_rows else 0.0) for i, c in enumerate(self.calls) if c["fn"] in fam]
+
+    def profile_in_frame(self, frames=20, warm=3):
+        """Device time of every launch of the plan IN THE FRAME: `frames` whole forwards are issued launch by launch on one
+        stream (plan order) with the library's census at level 2, i.e. every kernel carries its own start/stop HIP event pair
+        (hipExtLaunchKernelGGL: the dispatch's begin -> end interval, what rocprofv3's kernel trace reports).  Each launch sees
+        the cache state the preceding launches of the frame left - not its own operands from 20 warm replays (profile()).
+        Returns [dict(label, family, ms, flops, bytes, launches)] in plan order, ms = mean per frame."""
+        from . import _lib
+        lib = _lib.lib()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        n = len(self.calls)
+        with torch.cuda.stream(side):
+            st = ctypes.c_void_p(side.cuda_stream)
+            for _ in range(warm):
+                self._launch_all_on(st)
+            side.synchronize()
+            lib.fs_census_enable(2)
+            try:
+                for _ in range(frames):
+                    for i, c in enumerate(self.calls):
+                        lib.fs_census_tag(i)
+                        call(c["fn"], st, *c["args"])
+                lib.fs_census_tag(-1)
+                side.synchronize()
+            finally:
+                lib.fs_census_enable(0)
+            counts = (ctypes.c_longlong * n)()
+            ms = (ctypes.c_double * n)()
+            lib.fs_census_read_tags(n, ctypes.cast(counts, ctypes.c_void_p), ctypes.cast(ms, ctypes.c_void_p))
+        torch.cuda.current_stream().wait_stream(side)
+        return [dict(label=c["label"], family=c["family"], ms=ms[i] / frames, flops=c["flops"], bytes=c["bytes"],
+                     launches=counts[i] / frames) for i, c in enumerate(self.calls)]
 
     def profile(self, repeats=20, rounds=3):
         """Device time of every launch of the plan, measured with HIP events on the launch stream.

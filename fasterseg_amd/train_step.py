@@ -50,23 +50,46 @@ class StudentDistillStep:
                 return self.teacher.forward_lowres(imgs)
             return self.teacher(imgs)
 
-    def step(self, imgs, target):
+    def _loss(self, imgs, target, t_logits, ohem):
         from . import functional as FN
         from .losses import distill_kl_lowres, ohem_ce_lowres
-        self.sync.prepare()
-        t_logits = self.teacher_logits(imgs)
         FN.set_compute_dtype(self.compute_dtype)
         try:
             p8, p16, p32 = self.student.forward_lowres(imgs) if self.fused_loss else self.student(imgs)
         finally:
             FN.set_compute_dtype(torch.float32)
         if self.fused_loss:      # train/train.py:254-260 with the x8 / x16 / x32 up-samples evaluated inside the criteria
-            loss = (ohem_ce_lowres(self.ohem, p8, target) + self.lamb * ohem_ce_lowres(self.ohem, p16, target)
-                    + self.lamb * ohem_ce_lowres(self.ohem, p32, target))
-            loss = loss + distill_kl_lowres(p8, t_logits, self.size)
-        else:
-            loss = self.ohem(p8, target) + self.lamb * self.ohem(p16, target) + self.lamb * self.ohem(p32, target)
-            loss = loss + distill_kl(p8, t_logits)
+            loss = (ohem_ce_lowres(ohem, p8, target) + self.lamb * ohem_ce_lowres(ohem, p16, target)
+                    + self.lamb * ohem_ce_lowres(ohem, p32, target))
+            return loss + distill_kl_lowres(p8, t_logits, self.size)
+        loss = ohem(p8, target) + self.lamb * ohem(p16, target) + self.lamb * ohem(p32, target)
+        return loss + distill_kl(p8, t_logits)
+
+    def loss_only(self, imgs, target):
+        """The step's loss on any number of images (train/train.py:246-262) through the same modules, criteria and compute dtype,
+        without backward / update: the frozen teacher runs through its modules (the engine's plan is fixed to the step's batch), OHEM's
+        min_kept follows the images given (train/train.py:62).  BatchNorm running statistics are put back afterwards.  Used by
+        bench.py's parity gate against the CPU oracle."""
+        from . import functional as FN
+        buffers = list(self.student.buffers())
+        saved = [b_.clone() for b_ in buffers]
+        ohem = ProbOhemCrossEntropy2d(ignore_label=255, thresh=0.7, min_kept=int(imgs.shape[0] * self.size[0] * self.size[1] // 16),
+                                      use_weight=False)
+        with torch.no_grad():
+            FN.set_compute_dtype(self.compute_dtype)
+            try:
+                t_logits = self.teacher.forward_lowres(imgs) if self.fused_loss else self.teacher(imgs)
+            finally:
+                FN.set_compute_dtype(torch.float32)
+            loss = float(self._loss(imgs, target, t_logits, ohem))
+            for b_, s_ in zip(buffers, saved):
+                b_.copy_(s_)
+        return loss
+
+    def step(self, imgs, target):
+        self.sync.prepare()
+        t_logits = self.teacher_logits(imgs)
+        loss = self._loss(imgs, target, t_logits, self.ohem)
         loss.backward()
         self.sync.sync()
         self.optimizer.step()
@@ -97,7 +120,7 @@ class SupernetStep:
     same sub-network."""
 
     def __init__(self, pretrain=True, cfg=SearchConfig, seed=12345, device="cuda", lut=None, use_graphs=None,
-                 compute_dtype=torch.float32):
+                 compute_dtype=torch.float32, gc_freeze=None):
         import os
         self.compute_dtype = compute_dtype
         self.use_graphs = bool(int(os.environ.get("FS_SUPERNET_GRAPHS", "1"))) if use_graphs is None else use_graphs
@@ -135,6 +158,8 @@ class SupernetStep:
         np.random.seed(seed)
         torch.manual_seed(seed)
         self._prewarmed = not bool(int(os.environ.get("FS_PREWARM_PROGRAMS", "1")))
+        self.gc_freeze = bool(int(os.environ.get("FS_GC_FREEZE", "1"))) if gc_freeze is None else bool(gc_freeze)
+        self.last_arch_ce = None
         self.architect = None
         if not pretrain:
             if lut is not None:
@@ -299,6 +324,7 @@ class SupernetStep:
             K.zero_pool.reset(imgs.device)
             try:
                 loss_arch = self._phase_loss("a", imgs_search, target_search)
+                self.last_arch_ce = loss_arch                 # `_loss` of the architecture step, before the latency penalty
                 loss_latency = self.architect._latency_loss()
                 if torch.is_tensor(loss_latency):
                     loss_latency.backward()
@@ -344,9 +370,18 @@ class SupernetStep:
                     K.zero_pool.stop()
         self._set_phase("w")
         self.programs_prewarmed = built
-        gc.collect()
-        gc.freeze()
+        # process-wide side effect, so it is the application's choice: FS_GC_FREEZE=0 (or freeze=False) leaves the collector alone
+        if self.gc_freeze:
+            gc.collect()
+            gc.freeze()
         return built
+
+    def describe(self):
+        """How the passes of a step are executed (bench.py prints it)."""
+        specs = self._specs()
+        return {"passes_per_phase": len(specs), "graphed": sum(1 for s_ in specs if self._is_static(s_)) if self.use_graphs else 0,
+                "eager": sum(1 for s_ in specs if not (self.use_graphs and self._is_static(s_))),
+                "programs_prewarmed": getattr(self, "programs_prewarmed", 0), "gc_frozen": bool(self.gc_freeze and self._prewarmed)}
 
     def _step_eager(self, imgs, target, imgs_search=None, target_search=None):
         loss_arch = None
@@ -359,9 +394,12 @@ class SupernetStep:
             self._set_phase("a")
             try:
                 loss_arch = self.architect.step(imgs, target, imgs_search, target_search)
+                self.last_arch_ce = self.architect.last_loss
             finally:
                 self._set_phase("w")
-        self.sync.prepare(passes=1)           # `_loss` sums its four forwards: ONE backward over all of them
+        # `_loss` sums its four forwards and ONE backward runs over all of them - but a weight shared by the four forwards is
+        # written by four wgrad launches, and the sink's hook fires on the first: buckets must not go out before sync()
+        self.sync.prepare(passes=len(self._specs()))
         loss = self.model._loss(imgs, target, self.pretrain)
         loss.backward()
         self.sync.sync()

@@ -76,7 +76,7 @@ typedef struct fs_resize_desc {
 const char* fs_last_error(void);
 /* ABI revision of this header; fs_version() returns the one the library was built from.  Bindings check both this and
  * fs_struct_size() when they load the library (fasterseg_amd/_lib.py) - a stale .so must not be used silently. */
-#define FS_ABI_VERSION 202
+#define FS_ABI_VERSION 203
 int fs_version(void);
 int fs_struct_size(int which);   /* 0 fs_conv_desc, 1 fs_resize_desc, 2 fs_zoom_desc, 3 fs_sgd_tensor, 4 fs_logits_desc; -1 otherwise */
 /* test hook: force the tile configuration of fs_conv2d_fwd (0..6; -1 = heuristic).  Not for production use. */
@@ -362,10 +362,13 @@ fs_status fs_bilinear_argmax(void* stream, const fs_resize_desc* d, const void* 
 fs_status fs_hist_info(void* stream, const unsigned char* pred, const void* gt, int gt_bytes, long long n, int n_cl,
                        unsigned long long* hist, unsigned long long* counts);
 
-/* --- launch census (measurement support) ------------------------------------------------------------ */
-/* While enabled, every convolution launched through this ABI is counted by geometry (family + descriptor); launches
- * issued during hipGraph capture are counted once, i.e. per replay.  bench.py times each counted shape alone with HIP
- * events and reports the step's dominant kernel against its roofline (DESIGN.md "What the numbers are computed from"). */
+/* --- launch census + in-step kernel timing (measurement support) ----------------------------------- */
+/* Level 1: every convolution launched through this ABI is counted by geometry (family + descriptor); launches issued during
+ * hipGraph capture are counted once, i.e. per replay.  Level 2: additionally every kernel this library launches (outside a
+ * capture) carries a start/stop HIP event pair (hipExtLaunchKernelGGL): its elapsed time is the dispatch's own begin -> end
+ * interval on the launch stream, accumulated per kernel name and per conv geometry.  bench.py issues ONE step / frame eagerly
+ * at level 2 and reports the dominant kernel against its roofline from {launches, algorithmic FLOPs, measured time} of ALL its
+ * launches (DESIGN.md "What the numbers are computed from"); profiles/ holds rocprofv3's table of the same command. */
 #define FS_CENSUS_CONV_IGEMM 0      /* fs_conv2d_fwd[_ws]: forward and data-gradient convolutions; +FS_CENSUS_STATS with BN partials */
 #define FS_CENSUS_CONV_HALO  1      /* fs_conv3x3_s1_fwd */
 #define FS_CENSUS_WGRAD      2      /* fs_conv2d_wgrad[_strided] */
@@ -374,9 +377,18 @@ typedef struct fs_census_entry {
     int family;
     fs_conv_desc desc;
     long long count;
+    double ms;                      /* level 2: summed device time of the entry's launches (incl. their split-K reductions) */
 } fs_census_entry;
-void fs_census_enable(int on);                                   /* 1: clear and start counting, 0: stop */
+typedef struct fs_kernel_time {
+    char name[56];                  /* kernel function name without template arguments */
+    long long count;
+    double ms;
+} fs_kernel_time;
+void fs_census_enable(int level);                                /* 1 / 2: clear and start, 0: stop (waits for timed launches) */
 int fs_census_read(fs_census_entry* out, int max_entries);      /* fills up to max_entries, returns the number of distinct shapes */
+int fs_census_read_kernels(fs_kernel_time* out, int max_entries);   /* level 2: per-kernel launch counts and summed device time */
+void fs_census_tag(int tag);                                     /* level 2: launches issued from now on also accumulate under `tag` (>= 0; -1: none) */
+int fs_census_read_tags(int n_tags, long long* counts, double* ms);  /* launches and summed device time of tags 0..n_tags-1 */
 
 /* --- loss head fused with the logits up-sample --------------------------------------- */
 /* The same two criteria computed straight from the LOW-resolution NHWC logits of a head: the bilinear (align_corners=True)

@@ -421,6 +421,75 @@ def gen_supernet():
         json.dump(meta, f)
 
 
+# 7b. the FULL-SIZE supernet of the benchmarked steps: F12.L16 (search/config_search.py:81-84) at the C3 map size (256x512:
+#     32x64 ... 8x16, zoomed 4x8) and at the C5 map size (224x448: 28x56 / 14x28 / 7x14, zoomed 3x7 - odd sizes through H//2),
+#     one image, fp64: loss, the set of parameters that receive gradients, gradient norms of a sample of them, a few gradients.
+L16_CFG = dict(num_classes=19, layers=16, Fch=12, width_mult_list=WML, prun_modes=['max', 'arch_ratio'],
+               stem_head_width=[(1, 1), (8. / 12, 8. / 12)])
+L16_CASES = (("pretrain", (1, 3, 256, 512)), ("search", (1, 3, 224, 448)))
+L16_GRADS = ("alpha_0_0", "alpha_1_1", "beta_1_1", "beta_1_2", "ratio_1_0", "ratio_1_2", "cells.1.0._op._ops.3.conv1.weight",
+             "cells.9.1.downsample._ops.0.conv2.weight", "cells.13.2._op._ops.4.bn2.bn.4.weight", "cells.15.2._op._ops.2.conv1.weight",
+             "cells.7.1._op._ops.1.conv1.weight", "stem.0.0.conv.0.weight", "head02.0.conv_1x1.bias", "refine32.0.1.conv.0.weight")
+
+
+def l16_sampled(key):
+    """Which parameters have their gradient norm in the fixture (all 40 k would be 2.5 MB of names): 1 in 16 by name hash, plus
+    every parameter outside the cells."""
+    import zlib
+    return (not key.startswith("cells.")) or zlib.crc32(key.encode()) % 16 == 0
+
+
+def gen_supernet_l16():
+    import hashlib
+    store, meta = {}, {}
+    with ref_loader.reference("search"):
+        import model_search
+        real_cuda = torch.Tensor.cuda
+        torch.Tensor.cuda = lambda self, *a, **k: self
+        try:
+            crit = torch.nn.CrossEntropyLoss(ignore_index=255)
+            net = model_search.Network_Multi_Path(criterion=crit, **L16_CFG)
+            sd = seeded_state(net.state_dict(), 778)
+            for k in list(sd):
+                if k.split("_")[0] in ("alpha", "beta", "ratio"):
+                    sd[k] = sd[k] * 5.0
+            net.load_state_dict(sd)
+            net = net.to(torch.float64).train()
+            meta["num_params"] = int(sum(p.numel() for p in net.parameters()))
+            for mode, shape in L16_CASES:
+                x = seeded_input(shape, 41).to(torch.float64)
+                g = torch.Generator().manual_seed(42)
+                target = torch.randint(0, 19, (shape[0], shape[2] // 8, shape[3] // 8), generator=g)
+                target[torch.rand(target.shape, generator=g) < 0.05] = 255
+                store[mode + "/target"] = _np(target)
+                net.load_state_dict({k: v.to(torch.float64) if v.is_floating_point() else v for k, v in sd.items()})   # BN buffers back
+                net.zero_grad()
+                np.random.seed(5)
+                torch.manual_seed(6)
+                net.arch_idx = 0
+                loss = net._loss(x, target, mode == "pretrain")
+                loss.backward()
+                store[mode + "/loss"] = np.array([float(loss.detach())])
+                named = dict(net.named_parameters())
+                with_grad = sorted(k for k, p in named.items() if p.grad is not None)
+                is_arch = lambda k: k.split("_")[0] in ("alpha", "beta", "ratio")
+                weights = [k for k in with_grad if not is_arch(k)]
+                meta[mode] = {"shape": list(shape), "params_with_grad": len(with_grad),
+                              "params_with_grad_sha1": hashlib.sha1("\n".join(with_grad).encode()).hexdigest(),
+                              "weights_with_grad": len(weights),
+                              "weights_with_grad_sha1": hashlib.sha1("\n".join(weights).encode()).hexdigest(),
+                              "gradnorms": {k: float(named[k].grad.norm()) for k in with_grad if l16_sampled(k)}}
+                for k in L16_GRADS:
+                    if named[k].grad is not None:
+                        _put(store, "%s/g/%s" % (mode, k), named[k].grad.float())
+                print("supernet L16", mode, shape, float(loss.detach()), "params with grad:", len(with_grad), "norms kept:", len(meta[mode]["gradnorms"]))
+        finally:
+            torch.Tensor.cuda = real_cuda
+    np.savez_compressed(os.path.join(GOLD, "supernet_l16.npz"), **store)
+    with open(os.path.join(GOLD, "supernet_l16_meta.json"), "w") as f:
+        json.dump(meta, f)
+
+
 # 8. evaluation metrics (tools/seg_opr/metric.py is pure numpy and imports unmodified)
 def gen_eval():
     import importlib.util
@@ -445,9 +514,9 @@ def gen_eval():
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(max(1, os.cpu_count() or 1))
-    which = sys.argv[1:] or ["arch", "decode", "ops", "nets", "lut", "loss", "supernet", "eval"]
+    which = sys.argv[1:] or ["arch", "decode", "ops", "nets", "lut", "loss", "supernet", "supernet_l16", "eval"]
     for w in which:
-        {"arch": gen_arch, "decode": gen_decode_cases, "ops": gen_ops, "nets": gen_nets, "lut": gen_lut, "loss": gen_loss, "supernet": gen_supernet, "eval": gen_eval}[w]()
+        {"arch": gen_arch, "decode": gen_decode_cases, "ops": gen_ops, "nets": gen_nets, "lut": gen_lut, "loss": gen_loss, "supernet": gen_supernet, "supernet_l16": gen_supernet_l16, "eval": gen_eval}[w]()
 
 
 if __name__ == "__main__":

@@ -123,11 +123,14 @@ def test_engine_plan_file_reproduces_the_tuned_plan(tmp_path, monkeypatch):
     with torch.no_grad():
         a = engine.InferenceEngine(net, shape, dtype=torch.bfloat16)
         ga = a(x.cuda()).clone()
-        assert os.path.exists(str(tmp_path / "plan.json") + ".logits.bf16")
+        assert a._plan_path.startswith(str(tmp_path / "plan.json") + ".logits.bf16.") and os.path.exists(a._plan_path)
         b = engine.InferenceEngine(net, shape, dtype=torch.bfloat16)
         gb = b(x.cuda()).clone()
+        # a plan is positional: another input shape (or network) has another signature and tunes afresh instead of replaying it
+        c = engine.InferenceEngine(net, (1, 3, 128, 256), dtype=torch.bfloat16)
         torch.cuda.synchronize()
     assert b._plan_in is not None and a._plan_in is None
+    assert c._plan_in is None and c._plan_path != a._plan_path
     assert sorted(c["label"] + c["fn"] for c in a.calls) == sorted(c["label"] + c["fn"] for c in b.calls)
     assert [t[4] for t in a.autotuned] == [t[4] for t in b.autotuned]
     assert torch.equal(ga, gb)

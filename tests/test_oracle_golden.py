@@ -88,3 +88,17 @@ def test_oracle_student_train_step():
         if k.startswith("arch1_train/g/"):
             pname = k[len("arch1_train/g/"):].split("@")[0]
             assert_close_golden(params[pname].grad, store, "arch1_train/g/" + pname, 5e-3, 5e-3)
+
+
+def test_oracle_ohem_matches_reference():
+    """oracle/ref_loss.ohem_ce (the criterion of bench.py's C4 parity gate / cpu_baseline) vs the reference's ProbOhemCrossEntropy2d."""
+    from oracle import ref_loss
+    store = load_npz("loss.npz")
+    for i in range(4):
+        pred = torch.tensor(store["ohem%d/pred" % i]).requires_grad_(True)
+        target = torch.tensor(store["ohem%d/target" % i])
+        thresh, min_kept = store["ohem%d/cfg" % i]
+        loss = ref_loss.ohem_ce(pred, target, 255, float(thresh), int(min_kept))
+        loss.backward()
+        assert abs(float(loss.detach()) - float(store["ohem%d/loss" % i][0])) < 1e-6, i
+        np.testing.assert_allclose(pred.grad.numpy(), store["ohem%d/grad" % i], atol=1e-6)

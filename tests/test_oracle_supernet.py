@@ -54,3 +54,29 @@ def test_oracle_supernet_losses_and_gradients_match_reference():
                 got = params[pname].grad.reshape(-1)[::step].numpy()
                 denom = float(np.abs(want_g).max()) + 1e-12
                 assert float(np.abs(got - want_g.reshape(-1)).max()) <= 2e-3 * denom, (mode, pname)
+
+
+def test_oracle_supernet_l16_search_loss_matches_reference():
+    """The oracle at the benchmarked depth and map size (F12.L16, 1x3x224x448: 7x14 maps zoomed to 3x7 through H//2) against the
+    fixture the unmodified reference produced in fp64 - this is the checker bench.py's C3 / C5 parity gates and cpu_baseline use."""
+    from fasterseg_amd import model_search
+    store = load_npz("supernet_l16.npz")
+    meta = load_json("supernet_l16_meta.json")
+    cfg = dict(CFG, layers=16)
+    net = model_search.Network_Multi_Path(19, 16, None, 12, WML, ['max', 'arch_ratio'], [(1, 1), (8. / 12, 8. / 12)])
+    assert sum(p.numel() for p in net.parameters()) == meta["num_params"]
+    sd = seeded_state(net.state_dict(), 778)
+    del net
+    params = {}
+    for k, v in sd.items():
+        if k.split("_")[0] in ("alpha", "beta", "ratio"):
+            v = v * 5.0
+        params[k] = v.double() if v.is_floating_point() else v
+    x = seeded_input(tuple(meta["search"]["shape"]), 41).double()
+    target = torch.tensor(store["search/target"])
+    np.random.seed(5)
+    torch.manual_seed(6)
+    with torch.no_grad():
+        loss = ref_supernet.loss(params, cfg, x, target, False)
+    want = float(store["search/loss"][0])
+    assert abs(float(loss) - want) <= 1e-6 * abs(want), (float(loss), want)

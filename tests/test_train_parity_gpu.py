@@ -1,0 +1,219 @@
+"""Parity of the train paths bench.py times, at the benchmarked size and in the benchmarked dtype.
+
+* F12.L16 supernet (search/config_search.py:81-84) `_loss` forward + backward at the C3 map size (1x3x256x512, pretrain passes)
+  and the C5 map size (1x3x224x448, search passes: 28x56 / 14x28 / 7x14 maps and the zoomed 3x7 ones) against fixtures the
+  UNMODIFIED reference produced in fp64 (tests/golden/supernet_l16*, oracle/make_golden.py gen_supernet_l16) - through the bare
+  modules (fp32) and through train_step.SupernetStep exactly as bench.py builds it (hipGraph replay of the fixed-width passes,
+  MixedOp launch programs, pair batching, flat-gradient sink), fp32 AND bf16.
+* the student's train step (3 heads) in bf16 against the reference's fp64 fixture (tests/golden/nets.npz arch1_train64).
+
+Bars.  fp32 (exact-fp32 MFMA, fp32 storage): loss 2e-3 relative, gradient norms 5e-2 (batch-statistics BN on maps of a few
+dozen pixels: a last-bit change of a mean can flip a ReLU-mask element).  bf16 (bf16 storage of every activation, bf16 MFMA
+operands, fp32 accumulation / statistics / master weights / parameter gradients): every stored activation is rounded to 8
+mantissa bits (relative 2^-9 = 0.2 %, 0.4 % through a BN rescale); a random walk through the ~60 conv / BN / resample stages of
+a forward + backward gives a few per cent per gradient tensor, so loss <= 2e-2 relative, per-tensor gradient cosine >= 0.99
+and relative L2 <= 0.15, gradient norms within 15 % (<= 2 % of the sampled tensors may miss: tensors of tiny norm behind 3x7
+maps).  Measured values are written to gpurun_out/parity_metrics.json when that directory exists.
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.seeded import seeded_input, seeded_state
+from tests._util import golden_get, load_json, load_npz
+
+pytestmark = pytest.mark.gpu
+WML = [4. / 12, 6. / 12, 8. / 12, 10. / 12, 1.]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CASES = {"pretrain": (1, 3, 256, 512), "search": (1, 3, 224, 448)}
+
+
+def _record(name, metrics):
+    out = os.path.join(ROOT, "gpurun_out")
+    if not os.path.isdir(out):
+        return
+    path = os.path.join(out, "parity_metrics.json")
+    try:
+        with open(path) as f:
+            data = json.load(f)
+    except Exception:
+        data = {}
+    data[name] = metrics
+    with open(path, "w") as f:
+        json.dump(data, f, indent=1)
+
+
+def _l16_state(net):
+    sd = seeded_state(net.state_dict(), 778)
+    for k in list(sd):
+        if k.split("_")[0] in ("alpha", "beta", "ratio"):
+            sd[k] = sd[k] * 5.0
+    return sd
+
+
+def _batch(mode):
+    shape = CASES[mode]
+    store = load_npz("supernet_l16.npz")
+    return seeded_input(shape, 41).cuda(), torch.tensor(store[mode + "/target"]).cuda()
+
+
+def _cos_rel(got, store, key):
+    want, step = golden_get(store, key)
+    g = got.detach().float().cpu().numpy().reshape(-1)[::step].astype(np.float64)
+    w = want.reshape(-1).astype(np.float64)
+    cos = float((g * w).sum() / (np.sqrt((g * g).sum() * (w * w).sum()) + 1e-300))
+    rel = float(np.sqrt(((g - w) ** 2).sum()) / (np.sqrt((w * w).sum()) + 1e-300))
+    return cos, rel
+
+
+def _check(name, loss, params, mode, dtype, weights_only):
+    store = load_npz("supernet_l16.npz")
+    meta = load_json("supernet_l16_meta.json")[mode]
+    bf16 = dtype == torch.bfloat16
+    want = float(store[mode + "/loss"][0])
+    loss_rel = abs(loss - want) / abs(want)
+    is_arch = lambda k: k.split("_")[0] in ("alpha", "beta", "ratio")
+    got_names = sorted(k for k, p in params.items() if p.grad is not None and not (weights_only and is_arch(k)))
+    tag = "weights_with_grad" if weights_only else "params_with_grad"
+    norm_bar = 0.15 if bf16 else 5e-2
+    bad, worst = [], 0.0
+    sampled = {k: w for k, w in meta["gradnorms"].items() if not (weights_only and is_arch(k))}
+    for k, w in sampled.items():
+        g = float(params[k].grad.float().norm())
+        err = abs(g - w) / (w + 1e-12)
+        worst = max(worst, err)
+        if abs(g - w) > norm_bar * w + 1e-6:
+            bad.append((k, g, w))
+    cos_min, rel_max, per = 1.0, 0.0, {}
+    for key in store:
+        if key.startswith(mode + "/g/"):
+            pname = key[len(mode + "/g/"):].split("@")[0]
+            if params[pname].grad is None:
+                continue
+            cos, rel = _cos_rel(params[pname].grad, store, mode + "/g/" + pname)
+            per[pname] = (round(cos, 5), round(rel, 5))
+            cos_min, rel_max = min(cos_min, cos), max(rel_max, rel)
+    _record(name, dict(loss=loss, want=want, loss_rel=loss_rel, n_with_grad=len(got_names), norms_checked=len(sampled), norms_missed=len(bad),
+                       worst_norm_err=worst, cos_min=cos_min, rel_l2_max=rel_max, per_tensor=per))
+    assert loss_rel <= (2e-2 if bf16 else 2e-3), (loss, want)
+    assert len(got_names) == meta[tag] and hashlib.sha1("\n".join(got_names).encode()).hexdigest() == meta[tag + "_sha1"], \
+        "a different set of parameters received gradients (%d vs %d)" % (len(got_names), meta[tag])
+    assert len(bad) <= (len(sampled) // 50 if bf16 else len(sampled) // 100), bad[:8]
+    assert cos_min >= (0.99 if bf16 else 0.999) and rel_max <= (0.15 if bf16 else 5e-2), per
+
+
+@pytest.mark.parametrize("mode", ["pretrain", "search"])
+def test_l16_supernet_modules_fp32(mode):
+    """The bare modules (per-module autograd path, architecture parameters differentiated too) at full depth / real map sizes."""
+    from fasterseg_amd import model_search
+    net = model_search.Network_Multi_Path(19, 16, torch.nn.CrossEntropyLoss(ignore_index=255), 12, WML, ['max', 'arch_ratio'],
+                                          [(1, 1), (8. / 12, 8. / 12)])
+    net.load_state_dict(_l16_state(net))
+    net = net.cuda().train()
+    x, target = _batch(mode)
+    np.random.seed(5)
+    torch.manual_seed(6)
+    net.arch_idx = 0
+    loss = net._loss(x, target, mode == "pretrain")
+    loss.backward()
+    _check("l16_modules_fp32_" + mode, float(loss.detach()), dict(net.named_parameters()), mode, torch.float32, weights_only=False)
+
+
+class _FrozenLR:
+    """train_step.SearchConfig with lr = 0: the step runs its optimizer kernel but leaves the weights where the fixture has them."""
+    lr = 0.0
+    momentum = 0.9
+    weight_decay = 5e-4
+    grad_clip = 5
+    arch_learning_rate = 3e-4
+    layers = 16
+    Fch = 12
+    width_mult_list = WML
+    prun_modes = ['max', 'arch_ratio']
+    stem_head_width = [(1, 1), (8. / 12, 8. / 12)]
+    latency_weight = [0, 1e-2]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("mode", ["pretrain", "search"])
+def test_l16_supernet_step_as_benchmarked(mode, dtype):
+    """train_step.SupernetStep as bench.py runs it (graphs + programs + pair batching + flat-gradient sink, compute dtype), one
+    weight step of `_loss` on the fixture's weights and batch: loss and gradients vs the reference's fp64 run."""
+    from fasterseg_amd.train_step import SupernetStep
+    st = SupernetStep(pretrain=(mode == "pretrain"), cfg=_FrozenLR, compute_dtype=dtype)
+    st.architect = None                                   # the fixture is `_loss` of the weight step (train_search.py:246-250)
+    st.model.load_state_dict({k: v.cuda() for k, v in _l16_state(st.model).items()})
+    st.optimizer.refresh_packs()
+    x, target = _batch(mode)
+    np.random.seed(5)
+    torch.manual_seed(6)
+    st.model.arch_idx = 0
+    loss, _ = st.step(x, target)
+    torch.cuda.synchronize()
+    assert st.graphs, "the fixed-width passes were not captured"
+    _check("l16_step_%s_%s" % ("bf16" if dtype == torch.bfloat16 else "fp32", mode), float(loss), dict(st.model.named_parameters()), mode,
+           dtype, weights_only=True)
+
+
+def test_l16_supernet_step_is_reproducible_in_loss():
+    """Two fresh builds of the bf16 pretrain step on the same weights / batch / seeds give the same loss to 1e-3 relative (the
+    remaining run-to-run differences are float atomics in BN statistics of maps > 512 px and in the weight-gradient slabs)."""
+    from fasterseg_amd.train_step import SupernetStep
+    out = []
+    for _ in range(2):
+        st = SupernetStep(pretrain=True, cfg=_FrozenLR, compute_dtype=torch.bfloat16)
+        st.model.load_state_dict({k: v.cuda() for k, v in _l16_state(st.model).items()})
+        st.optimizer.refresh_packs()
+        x, target = _batch("pretrain")
+        np.random.seed(5)
+        torch.manual_seed(6)
+        out.append(float(st.step(x, target)[0]))
+        del st
+        torch.cuda.empty_cache()
+    assert abs(out[0] - out[1]) <= 1e-3 * abs(out[0]), out
+
+
+def test_student_train_step_bf16_vs_fp64_fixture():
+    """The student's train-mode forward + backward (3 heads) with bf16 compute against the reference's fp64 run of the same step
+    (fixture arch1_train64) - the arithmetic bench.py's C4 workload runs."""
+    from fasterseg_amd import functional as FN
+    from tests.test_ops_gpu import build_net
+    store = load_npz("nets.npz")
+    net = build_net(1, [2, 1], True)
+    x = seeded_input((2, 3, 128, 256), 6).cuda().requires_grad_(True)
+    FN.set_compute_dtype(torch.bfloat16)
+    try:
+        p8, p16, p32 = net(x)
+        loss = (p8 * seeded_input(tuple(p8.shape), 7).cuda()).sum() + 0.2 * (p16 * seeded_input(tuple(p16.shape), 8).cuda()).sum() \
+            + 0.2 * (p32 * seeded_input(tuple(p32.shape), 9).cuda()).sum()
+        loss.backward()
+    finally:
+        FN.set_compute_dtype(torch.float32)
+    metrics = {}
+    for name, p in (("p8", p8), ("p16", p16), ("p32", p32)):
+        want, _ = golden_get(store, "arch1_train64/%s_sub" % name)
+        got = p[:, :, ::4, ::4].detach().float().cpu().numpy()
+        metrics[name + "_rel_to_max"] = float(np.abs(got - want).max() / np.abs(want).max())
+        metrics[name + "_rel_l2"] = float(np.sqrt(((got - want) ** 2).sum() / (want ** 2).sum()))
+    params = dict(net.named_parameters())
+    norms = load_json("arch1_train64_gradnorms.json")
+    assert set(norms) == {k for k, p in params.items() if p.grad is not None}, "same set of parameters receives gradients"
+    errs = {k: abs(float(params[k].grad.norm()) - w) / (w + 1e-12) for k, w in norms.items()}
+    metrics["worst_norm_err"] = max(errs.values())
+    metrics["norms_missed"] = sum(1 for e in errs.values() if e > 0.15)
+    cos_min, rel_max = 1.0, 0.0
+    for key in store:
+        if key.startswith("arch1_train64/g/"):
+            pname = key[len("arch1_train64/g/"):].split("@")[0]
+            cos, rel = _cos_rel(params[pname].grad, store, "arch1_train64/g/" + pname)
+            cos_min, rel_max = min(cos_min, cos), max(rel_max, rel)
+    cos, rel = _cos_rel(x.grad, store, "arch1_train64/gx")
+    metrics.update(cos_min=min(cos_min, cos), rel_l2_max=max(rel_max, rel), gx_rel_l2=rel)
+    _record("student_train_bf16", metrics)
+    assert all(metrics[n + "_rel_l2"] <= 3e-2 for n in ("p8", "p16", "p32")), metrics
+    assert metrics["norms_missed"] <= len(norms) // 50, sorted(errs.items(), key=lambda kv: -kv[1])[:8]
+    assert metrics["cos_min"] >= 0.99 and metrics["rel_l2_max"] <= 0.15, metrics
