@@ -10,16 +10,17 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfasterseg_hip.so")
 
-EXPECTED_ABI = 203          # FS_ABI_VERSION of include/fasterseg_hip.h these bindings were written against
+EXPECTED_ABI = 204          # FS_ABI_VERSION of include/fasterseg_hip.h these bindings were written against
 FS_F32, FS_BF16 = 0, 1
-FS_CONV_RELU, FS_CONV_TRANSPOSED, FS_CONV_ACCUM = 1, 2, 4
+FS_CONV_RELU, FS_CONV_TRANSPOSED, FS_CONV_ACCUM, FS_CONV_RELU_TAIL = 1, 2, 4, 8
 
 c_int, c_ll, c_float, c_vp = ctypes.c_int, ctypes.c_longlong, ctypes.c_float, ctypes.c_void_p
 
 
 class ConvDesc(ctypes.Structure):
     _fields_ = [(n, c_int) for n in ("N", "H", "W", "Cin", "Cout", "R", "S", "stride", "pad", "Ho", "Wo",
-                                     "x_cs", "y_cs", "dtype", "flags", "w_os", "w_ts", "vr_H", "vr_W", "vr_relu", "bn_groups")]
+                                     "x_cs", "y_cs", "dtype", "flags", "w_os", "w_ts", "vr_H", "vr_W", "vr_relu", "bn_groups",
+                                     "n_seg", "n_jump", "k_seg", "k_jump", "g_jump")]
 
 
 class ZoomDesc(ctypes.Structure):
@@ -54,6 +55,7 @@ SIGNATURES = {
     "fs_conv2d_fwd_ws": [c_vp, ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll],
     "fs_conv2d_wgrad": [c_vp, ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp],
     "fs_conv2d_wgrad_strided": [c_vp, ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_ll, c_ll, c_ll],
+    "fs_conv2d_wgrad_ws": [c_vp, ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_ll, c_ll, c_ll, c_vp, c_ll],
     "fs_pack_weight_frag": [c_vp, c_vp, c_ll, c_ll, c_int, c_int, c_int, c_vp],
     "fs_conv3x3_s1_fwd": [c_vp, ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "fs_zoom_cell_fwd": [c_vp, ctypes.POINTER(ZoomDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
@@ -122,6 +124,7 @@ _SPECIAL = {
     "fs_sgd_tensor_chunks": ([c_ll, c_int, c_int, c_int], c_ll),
     "fs_loss_up_workspace_bytes": ([ctypes.POINTER(LogitsDesc)], c_ll),
     "fs_zoom_cell_supported": ([ctypes.POINTER(ZoomDesc)], c_int),
+    "fs_workspace_counter_bytes": ([], c_ll),
     "fs_census_enable": ([c_int], None),
     "fs_census_read": ([c_vp, c_int], c_int),
     "fs_census_read_kernels": ([c_vp, c_int], c_int),

@@ -63,8 +63,10 @@ __global__ __launch_bounds__(BNC_THREADS) void bn_group_fwd_kernel(long long pix
     __shared__ float affine[2 * VEC];
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int c0 = blockIdx.x * VEC;
+    const int relu_arg = relu;
+    relu = relu_at(relu, c0) ? 1 : 0;          // per channel vector (see common.h)
     const long long mg = pixels / groups;
-    if (blockIdx.x == 0 && tid == 0 && num_batches_tracked) *num_batches_tracked += groups;
+    if (blockIdx.x == 0 && tid == 0) bump_batches_tracked(num_batches_tracked, relu_arg, groups);
     for (int g = 0; g < groups; ++g) {
         const long long base = (long long)g * mg;
         float s1[VEC], s2[VEC];
@@ -182,6 +184,8 @@ __global__ __launch_bounds__(BNC_THREADS) void bn_group_bwd_kernel(long long pix
     __shared__ float red[2 * BNC_MAX_WAVES * VEC];
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int c0 = blockIdx.x * VEC;
+    const int relu_arg = relu;
+    relu = relu_at(relu, c0) ? 1 : 0;          // per channel vector (see common.h)
     const long long mg = pixels / groups;
     float tot_b[VEC], tot_g[VEC], ga[VEC];
 #pragma unroll
@@ -305,8 +309,10 @@ __global__ __launch_bounds__(BNS_THREADS) void bn_small_fwd_kernel(long long pix
     __shared__ float affine[G * 2 * VEC];
     const int tid = threadIdx.x;
     const int c0 = blockIdx.x * VEC;
+    const int relu_arg = relu;
+    relu = relu_at(relu, c0) ? 1 : 0;          // per channel vector (see common.h)
     const int mg = (int)(pixels / G);
-    if (blockIdx.x == 0 && tid == 0 && num_batches_tracked) *num_batches_tracked += G;
+    if (blockIdx.x == 0 && tid == 0) bump_batches_tracked(num_batches_tracked, relu_arg, G);
     u32x4 raw[G][BNS_UNROLL];
     if (splits > 1) {                     // sum the split-K slabs of the producing conv; keep z for the backward
 #pragma unroll
@@ -423,6 +429,8 @@ __global__ __launch_bounds__(BNS_THREADS) void bn_small_bwd_kernel(long long pix
     __shared__ float red[G * 2 * VEC * BNS_WAVES];
     const int tid = threadIdx.x;
     const int c0 = blockIdx.x * VEC;
+    const int relu_arg = relu;
+    relu = relu_at(relu, c0) ? 1 : 0;          // per channel vector (see common.h)
     const int mg = (int)(pixels / G);
     u32x4 rz[G][BNS_UNROLL], rg[G][BNS_UNROLL], ro[G][BNS_UNROLL];
 #pragma unroll

@@ -60,6 +60,17 @@ bool census_events(const char* kernel, hipStream_t stream, hipEvent_t* start, hi
 fs_status conv_fwd_deferred(void* stream, const fs_conv_desc* d, const void* x, const void* w_packed, void* y, void* workspace,
                             long long workspace_bytes, int* slices);
 
+// `relu` argument of the BatchNorm kernels: bit 0 = apply ReLU, bits 8.. = the first channel it applies to (0: every channel);
+// forward kernels: bit 1 = num_batches_tracked points at TWO adjacent counters (the two BatchNorm modules of a fused pair).
+// A fused pair of conv->BN units whose first member has its ReLU after a later up-sample ('conv_downup', operations.py:271-276)
+// and whose second has it right after the BN ('conv_2x_downup'.bn1, :438-440) is one BN launch over both channel ranges.
+__host__ __device__ inline bool relu_at(int relu, int c) { return (relu & 1) && c >= (relu >> 8); }
+__device__ inline void bump_batches_tracked(long long* counters, int relu, int by) {
+    if (!counters) return;
+    counters[0] += by;
+    if (relu & 2) counters[1] += by;
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 inline int elem_size(int dtype) { return dtype == FS_BF16 ? 2 : 4; }
 inline int vec_elems(int dtype) { return 16 / elem_size(dtype); }

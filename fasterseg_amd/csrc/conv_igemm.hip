@@ -42,6 +42,8 @@ struct ConvArgs {
     int vr_relu;          //   ReLU applied to the resampled value (zoomed-conv up-sample, operations.py:275-276)
     float* ws;            // cross-block split-K: fp32 partial tiles [gridDim.z][M][Cout] (null = whole K in one block)
     int k_slice;          // K elements per gridDim.z slice (multiple of the config's BKT)
+    int n_seg, n_jump;    // two-segment filter bank: output channels >= n_seg read filter row (n + n_jump); n_seg = 0: one bank
+    int k_seg, k_jump;    // two-segment contraction: input channels >= k_seg of a tap are k_jump elements further; k_seg = 0: off
 };
 
 template <typename T> struct Mma;
@@ -139,7 +141,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     for (int ps = 0; ps < B_PASS; ++ps) {
         const int n = n0 + ps * B_RPP + b_row;
         b_ok[ps] = n < p.Cout;
-        b_ptr[ps] = p.w + ((long long)(b_ok[ps] ? n : 0) * p.w_os) * sizeof(T);
+        const int nrow = b_ok[ps] ? n + ((p.n_seg > 0 && n >= p.n_seg) ? p.n_jump : 0) : 0;
+        b_ptr[ps] = p.w + ((long long)nrow * p.w_os) * sizeof(T);
     }
     int bk[B_SUBS];
 #pragma unroll
@@ -195,7 +198,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
         for (int j = 0; j < B_SUBS; ++j) {
             const bool kvalid = bk[j] < k_hi;
             // a slice of a wider resident pack: taps are w_tgap elements further apart than Cin (0 for a dense pack)
-            const long long koff = bk[j] + (long long)__umulhi((unsigned)bk[j], p.cin_magic) * p.w_tgap;
+            const int brs = (int)__umulhi((unsigned)bk[j], p.cin_magic);
+            long long koff = bk[j] + (long long)brs * p.w_tgap;
+            if (p.k_seg > 0 && bk[j] - brs * p.Cin >= p.k_seg) koff += p.k_jump;
 #pragma unroll
             for (int ps = 0; ps < B_PASS; ++ps) {
                 const bool ok = kvalid && b_ok[ps];
@@ -623,6 +628,17 @@ extern "C" fs_status fs_conv2d_fwd_ws(void* stream, const fs_conv_desc* d, const
     a.flags = d->flags;
     a.tiles_n = 1;
     a.cin_magic = (unsigned)(((1ull << 32) + (unsigned)d->Cin - 1) / (unsigned)d->Cin);
+    a.n_seg = a.n_jump = a.k_seg = a.k_jump = 0;
+    if (d->n_seg > 0) {
+        FS_REQUIRE(d->n_seg < d->Cout && d->n_seg + d->n_jump >= 0, FS_ERR_INVALID, "fs_conv2d_fwd: bad filter segment (%d, %d) for Cout=%d",
+                   d->n_seg, d->n_jump, d->Cout);
+        a.n_seg = d->n_seg; a.n_jump = d->n_jump;
+    }
+    if (d->k_seg > 0) {
+        FS_REQUIRE(d->k_seg < d->Cin && d->k_seg % vec == 0 && d->k_jump % vec == 0, FS_ERR_INVALID,
+                   "fs_conv2d_fwd: contraction segment (%d, %d) must be multiples of %d inside Cin=%d", d->k_seg, d->k_jump, vec, d->Cin);
+        a.k_seg = d->k_seg; a.k_jump = d->k_jump;
+    }
     a.vr_H = a.vr_W = a.vr_relu = 0;
     a.vr_rh = a.vr_rw = 0.f;
     if (d->vr_H > 0 || d->vr_W > 0) {
@@ -636,14 +652,18 @@ extern "C" fs_status fs_conv2d_fwd_ws(void* stream, const fs_conv_desc* d, const
     if (d->w_os == 0 && d->w_ts == 0) {
         a.w_os = a.K; a.w_tgap = 0;
     } else {          // filter = leading block of a wider resident pack
-        FS_REQUIRE(d->w_ts >= d->Cin && d->w_os >= d->R * d->S * d->w_ts && d->w_ts % vec == 0 && d->w_os % vec == 0,
+        // (a two-segment contraction reads k_seg channels of a tap from the first array and Cin - k_seg from the second)
+        const int tap_need = d->k_seg > 0 ? (d->k_seg > d->Cin - d->k_seg ? d->k_seg : d->Cin - d->k_seg) : d->Cin;
+        FS_REQUIRE(d->w_ts >= tap_need && d->w_os >= d->R * d->S * d->w_ts && d->w_ts % vec == 0 && d->w_os % vec == 0,
                    FS_ERR_INVALID, "fs_conv2d_fwd: filter strides (%d,%d) invalid for Cin=%d", d->w_os, d->w_ts, d->Cin);
         a.w_os = d->w_os; a.w_tgap = d->w_ts - d->Cin;
     }
     // 16-byte epilogue stores need an aligned slice; otherwise every tile takes the element-wise path
     if (!(aligned16(y) && (d->y_cs % vec == 0))) a.flags |= CONV_SCALAR_STORE;
     FS_CENSUS(FS_CENSUS_CONV_IGEMM | (stats ? FS_CENSUS_STATS : 0), d);
-    if (d->dtype == FS_F32) dispatch<float>((hipStream_t)stream, a, g_force_cfg, (float*)workspace, workspace_bytes);
-    else dispatch<bf16_t>((hipStream_t)stream, a, g_force_cfg, (float*)workspace, workspace_bytes);
+    // the last FS_WS_COUNTER_BYTES of every workspace are the (zero) arrival counters of the deterministic reductions: not scratch
+    const long long ws_bytes = workspace_bytes > FS_WS_COUNTER_BYTES ? workspace_bytes - FS_WS_COUNTER_BYTES : 0;
+    if (d->dtype == FS_F32) dispatch<float>((hipStream_t)stream, a, g_force_cfg, (float*)workspace, ws_bytes);
+    else dispatch<bf16_t>((hipStream_t)stream, a, g_force_cfg, (float*)workspace, ws_bytes);
     return check_launch("fs_conv2d_fwd");
 }

@@ -165,7 +165,7 @@ __global__ void bn_train_apply_kernel(long long pixels, int cv, const T* __restr
     const int C = cv * VEC;
     const long long mg = pixels / groups;
     if (blockIdx.x == 0) {
-        if (threadIdx.x == 0 && num_batches_tracked) *num_batches_tracked += groups;
+        if (threadIdx.x == 0) bump_batches_tracked(num_batches_tracked, relu, groups);
         for (int c = threadIdx.x; c < C; c += blockDim.x) {
             for (int g_ = 0; g_ < groups; ++g_) {
                 const float* st = stats + (long long)g_ * 2 * C;
@@ -201,7 +201,7 @@ __global__ void bn_train_apply_kernel(long long pixels, int cv, const T* __restr
             const float is = 1.0f / sqrtf(var + eps);
             const float sc = (gamma ? gamma[c + i] : 1.f) * is;
             const float o = f[i] * sc + ((beta ? beta[c + i] : 0.f) - m * sc);
-            f[i] = relu ? fmaxf(o, 0.f) : o;
+            f[i] = relu_at(relu, c) ? fmaxf(o, 0.f) : o;
         }
         stg16(y + pix * y_cs + c, Elem<T>::pack(f));
     }
@@ -232,6 +232,7 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(long long pixels, int 
     const int col = tid % cv;
     const int row = tid / cv;
     const bool active = row < rpb;
+    relu = relu_at(relu, col * VEC) ? 1 : 0;
     float a0[VEC], a1[VEC], mu[VEC], is[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
@@ -313,7 +314,7 @@ __global__ void bn_bwd_apply_kernel(long long pixels, int cv, const T* __restric
         float f[VEC], g[VEC];
         Elem<T>::unpack(ldg16(x + pix * x_cs + c), f);
         Elem<T>::unpack(ldg16(dy + pix * dy_cs + c), g);
-        if (relu) {
+        if (relu_at(relu, c)) {
             float o[VEC];
             Elem<T>::unpack(ldg16(yo + pix * y_cs + c), o);
 #pragma unroll

@@ -146,8 +146,8 @@ extern "C" fs_status fs_exec_program_streams(void* const* streams, int n_streams
                                               I(20), P(21), L(22));
                 break;
             case FS_OP_WGRAD_STRIDED:
-                NEED(7);
-                st = fs_conv2d_wgrad_strided(stream, (const fs_conv_desc*)P(0), P(1), P(2), PF(3), L(4), L(5), L(6));
+                NEED(9);
+                st = fs_conv2d_wgrad_ws(stream, (const fs_conv_desc*)P(0), P(1), P(2), PF(3), L(4), L(5), L(6), P(7), L(8));
                 break;
             case FS_OP_CHANNEL_STATS:
                 NEED(6);

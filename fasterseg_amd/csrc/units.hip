@@ -14,6 +14,13 @@
 // GB/s, so beyond a few hundred pixels the two grid-wide passes win and stay.
 static const long long BN_COL_MAX_PIXELS = 512;
 
+// the BN kernels' `relu` argument of a conv unit (common.h relu_at): bit 0 = apply, bits 8.. = first channel
+static inline int unit_relu(const fs_conv_desc* d, bool forward = false) {
+    const int two = (forward && d->n_seg > 0) ? 2 : 0;      // a fused pair: two num_batches_tracked counters
+    if (!(d->flags & FS_CONV_RELU)) return two;
+    return 1 | two | (((d->flags & FS_CONV_RELU_TAIL) && d->n_seg > 0) ? (d->n_seg << 8) : 0);
+}
+
 // BatchNorm(+ReLU) of an existing map z, forward / backward, the launch sequence chosen by the map size (FactorizedReduce's BN
 // after its two 1x1 convs, operations.py:521-526, and the grouped large-map case of the conv units below).
 extern "C" fs_status fs_bn_act_train_fwd(void* stream, long long pixels, int C, int groups, void* z, int z_cs, const float* gamma,
@@ -58,7 +65,8 @@ extern "C" fs_status fs_conv_bn_act_train_fwd(void* stream, const fs_conv_desc* 
                                               long long workspace_bytes) {
     FS_REQUIRE(d && x && w_packed && stats && saved && z && y, FS_ERR_INVALID, "fs_conv_bn_act_train_fwd: null argument");
     fs_conv_desc c = *d;
-    c.flags &= ~FS_CONV_RELU;          // the conv writes the raw pre-normalisation map z
+    c.flags &= ~(FS_CONV_RELU | FS_CONV_RELU_TAIL);          // the conv writes the raw pre-normalisation map z
+    c.k_seg = c.k_jump = 0;            // (k_jump of a fused unit describes the rotated pack of its backward)
     const int C = d->Cout;
     const long long count = (long long)d->N * d->Ho * d->Wo;
     const int groups = d->bn_groups > 1 ? d->bn_groups : 1;
@@ -69,18 +77,18 @@ extern "C" fs_status fs_conv_bn_act_train_fwd(void* stream, const fs_conv_desc* 
         if (s != FS_OK) return s;
         return fs_bn_group_fwd(stream, count, C, groups, z, d->y_cs, slices > 1 ? (const float*)workspace : nullptr, slices, gamma, beta,
                                eps, momentum, running_mean, running_var, num_batches_tracked, saved, y, d->y_cs, d->dtype,
-                               (d->flags & FS_CONV_RELU) ? 1 : 0);
+                               unit_relu(d, true));
     }
     if (groups > 1) {              // the conv's fused statistics are per launch, not per group: one reduction launch more
         fs_status s = fs_conv2d_fwd_ws(stream, &c, x, w_packed, nullptr, nullptr, z, nullptr, workspace, workspace_bytes);
         if (s != FS_OK) return s;
         return fs_bn_act_train_fwd(stream, count, C, groups, z, d->y_cs, gamma, beta, eps, momentum, running_mean, running_var,
-                                   num_batches_tracked, stats, saved, y, d->y_cs, d->dtype, (d->flags & FS_CONV_RELU) ? 1 : 0);
+                                   num_batches_tracked, stats, saved, y, d->y_cs, d->dtype, unit_relu(d, true));
     }
     fs_status s = fs_conv2d_fwd_ws(stream, &c, x, w_packed, nullptr, nullptr, z, stats, workspace, workspace_bytes);   // (+ sum / sumsq)
     if (s != FS_OK) return s;
     return fs_bn_train_apply(stream, count, C, z, d->y_cs, stats, gamma, beta, eps, momentum, running_mean, running_var,
-                             num_batches_tracked, saved, y, d->y_cs, d->dtype, (d->flags & FS_CONV_RELU) ? 1 : 0);
+                             num_batches_tracked, saved, y, d->y_cs, d->dtype, unit_relu(d, true));
 }
 
 extern "C" fs_status fs_conv_bn_act_train_bwd(void* stream, const fs_conv_desc* d, const void* x, const void* w_flip,
@@ -90,7 +98,7 @@ extern "C" fs_status fs_conv_bn_act_train_bwd(void* stream, const fs_conv_desc* 
                                               long long t_stride, void* dx, int dx_cs, int wf_os, int wf_ts, void* workspace,
                                               long long workspace_bytes) {
     FS_REQUIRE(d && z && dy && saved && gamma && red && dz, FS_ERR_INVALID, "fs_conv_bn_act_train_bwd: null argument");
-    const int relu = (d->flags & FS_CONV_RELU) ? 1 : 0;
+    const int relu = unit_relu(d);
     FS_REQUIRE(!relu || y, FS_ERR_INVALID, "fs_conv_bn_act_train_bwd: ReLU unit needs its output y");
     const int C = d->Cout;
     const long long pixels = (long long)d->N * d->Ho * d->Wo;
@@ -114,7 +122,7 @@ extern "C" fs_status fs_conv_bn_act_train_bwd(void* stream, const fs_conv_desc* 
         fs_conv_desc w = *d;
         w.flags = 0;
         w.y_cs = C;
-        s = fs_conv2d_wgrad_strided(stream, &w, x, dz, dw, o_stride, i_stride, t_stride);
+        s = fs_conv2d_wgrad_ws(stream, &w, x, dz, dw, o_stride, i_stride, t_stride, workspace, workspace_bytes);
         if (s != FS_OK) return s;
     }
     if (dx) {
@@ -122,6 +130,10 @@ extern "C" fs_status fs_conv_bn_act_train_bwd(void* stream, const fs_conv_desc* 
         FS_REQUIRE(w_flip, FS_ERR_INVALID, "fs_conv_bn_act_train_bwd: data gradient needs the flipped filter pack");
         fs_conv_desc g = {};
         g.w_os = wf_os; g.w_ts = wf_ts;          // 0,0: dense flipped pack; else a block of a resident [Cin][R][S][Cout] pack
+        if (d->n_seg > 0) {                      // fused pair: the contraction runs over both rotated packs
+            g.k_seg = d->n_seg;
+            g.k_jump = d->k_jump;
+        }
         g.N = d->N; g.H = d->Ho; g.W = d->Wo; g.Cin = d->Cout;
         g.Cout = d->Cin; g.R = d->R; g.S = d->S;
         g.stride = 1; g.pad = d->R - 1 - d->pad;

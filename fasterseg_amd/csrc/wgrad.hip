@@ -24,6 +24,10 @@ struct WgradArgs {
     int tiles_ci;
     long long slab;   // pixels per block
     long long o_stride, i_stride, t_stride;   // o_stride > 0: accumulate straight into a strided gradient tensor (element strides of O, I and of the flattened R*S tap index)
+    int n_seg, g_jump;        // fused pair: gradient rows of output channels >= n_seg are g_jump rows further (n_seg = 0: off)
+    float* part;              // deterministic mode: [tile][slab][4 waves][16][64] fp32 partial tiles (null: fp32 atomics)
+    unsigned int* counters;   // [tile] arrival counters, zero on entry, left zero
+    int slabs;
 };
 
 constexpr int KC = 32;      // pixels per chunk
@@ -138,6 +142,31 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
             __syncthreads();
         }
     }
+    // Deterministic accumulation over the pixel slabs (p.part != null): every block stores its partial tile, the block that
+    // arrives LAST at the tile's counter (an integer atomic) sums the partials in slab order and adds the total to the gradient
+    // with plain loads / stores - the same bits whatever the block schedule, and no fp32 atomics (they were a third of this
+    // kernel).  Launches that touch one gradient tensor are ordered by their stream.
+    if (p.part != nullptr && p.slabs > 1) {
+        __shared__ int s_last;
+        const unsigned int tile = blockIdx.z * gridDim.y + blockIdx.y;
+        float* mine = p.part + ((long long)tile * p.slabs + blockIdx.x) * (BCH * BCH);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mine[(wave * 16 + r) * 64 + lane] = acc[r];
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) s_last = (atomicAdd(&p.counters[tile], 1u) == (unsigned int)(p.slabs - 1)) ? 1 : 0;
+        __syncthreads();
+        if (!s_last) return;
+        __threadfence();
+        const float* all = p.part + (long long)tile * p.slabs * (BCH * BCH);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int sl = 0; sl < p.slabs; ++sl) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += __builtin_nontemporal_load(all + (long long)sl * (BCH * BCH) + (wave * 16 + r) * 64 + lane);
+        }
+        if (tid == 0) p.counters[tile] = 0u;
+    }
     // D[i = co][j = ci]: col = lane&31 -> ci, row -> co
     const int ci = ci0 + wn * 32 + (lane & 31);
     if (ci < p.Cin) {
@@ -145,9 +174,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
         for (int r = 0; r < 16; ++r) {
             const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (co < p.Cout) {
-                float* dst = p.o_stride > 0 ? p.dw + co * p.o_stride + ci * p.i_stride + (tr * p.S + ts) * p.t_stride
-                                            : p.dw + (((long long)co * p.R + tr) * p.S + ts) * p.Cin + ci;
-                atomicAdd(dst, acc[r]);
+                const long long row = co + ((p.n_seg > 0 && co >= p.n_seg) ? p.g_jump : 0);
+                float* dst = p.o_stride > 0 ? p.dw + row * p.o_stride + ci * p.i_stride + (tr * p.S + ts) * p.t_stride
+                                            : p.dw + ((row * p.R + tr) * p.S + ts) * p.Cin + ci;
+                if (p.part != nullptr) *dst += acc[r];
+                else atomicAdd(dst, acc[r]);
             }
         }
     }
@@ -158,20 +189,29 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
 using namespace fs;
 
 static fs_status wgrad_impl(void* stream, const fs_conv_desc* d, const void* x, const void* dy, float* dw_packed, long long o_stride,
-                            long long i_stride, long long t_stride);
+                            long long i_stride, long long t_stride, void* workspace, long long workspace_bytes);
 
 extern "C" fs_status fs_conv2d_wgrad(void* stream, const fs_conv_desc* d, const void* x, const void* dy, float* dw_packed) {
-    return wgrad_impl(stream, d, x, dy, dw_packed, 0, 0, 0);
+    return wgrad_impl(stream, d, x, dy, dw_packed, 0, 0, 0, nullptr, 0);
 }
 
 extern "C" fs_status fs_conv2d_wgrad_strided(void* stream, const fs_conv_desc* d, const void* x, const void* dy, float* dw,
                                              long long o_stride, long long i_stride, long long t_stride) {
     FS_REQUIRE(o_stride > 0 && i_stride > 0 && t_stride > 0, FS_ERR_INVALID, "fs_conv2d_wgrad_strided: strides must be positive");
-    return wgrad_impl(stream, d, x, dy, dw, o_stride, i_stride, t_stride);
+    return wgrad_impl(stream, d, x, dy, dw, o_stride, i_stride, t_stride, nullptr, 0);
+}
+
+extern "C" long long fs_workspace_counter_bytes(void) { return FS_WS_COUNTER_BYTES; }
+
+extern "C" fs_status fs_conv2d_wgrad_ws(void* stream, const fs_conv_desc* d, const void* x, const void* dy, float* dw,
+                                        long long o_stride, long long i_stride, long long t_stride, void* workspace,
+                                        long long workspace_bytes) {
+    FS_REQUIRE(o_stride > 0 && i_stride > 0 && t_stride > 0, FS_ERR_INVALID, "fs_conv2d_wgrad_ws: strides must be positive");
+    return wgrad_impl(stream, d, x, dy, dw, o_stride, i_stride, t_stride, workspace, workspace_bytes);
 }
 
 static fs_status wgrad_impl(void* stream, const fs_conv_desc* d, const void* x, const void* dy, float* dw_packed, long long o_stride,
-                            long long i_stride, long long t_stride) {
+                            long long i_stride, long long t_stride, void* workspace, long long workspace_bytes) {
     FS_REQUIRE(d && x && dy && dw_packed, FS_ERR_INVALID, "fs_conv2d_wgrad: null argument");
     FS_REQUIRE(d->dtype == FS_F32 || d->dtype == FS_BF16, FS_ERR_INVALID, "fs_conv2d_wgrad: bad dtype");
     const int vec = vec_elems(d->dtype);
@@ -189,6 +229,8 @@ static fs_status wgrad_impl(void* stream, const fs_conv_desc* d, const void* x, 
     a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.R = d->R; a.S = d->S;
     a.stride = d->stride; a.pad = d->pad; a.Ho = d->Ho; a.Wo = d->Wo;
     a.x_cs = d->x_cs; a.dy_cs = d->y_cs;
+    a.n_seg = d->n_seg > 0 ? d->n_seg : 0;
+    a.g_jump = d->n_seg > 0 ? d->g_jump : 0;
     const long long M = (long long)d->N * d->Ho * d->Wo;
     a.M = (int)M; a.HoWo = d->Ho * d->Wo;
     const int tiles_co = (d->Cout + BCH - 1) / BCH;
@@ -207,8 +249,27 @@ static fs_status wgrad_impl(void* stream, const fs_conv_desc* d, const void* x, 
     if (slabs < 1) slabs = 1;
     long long slab = (M + slabs - 1) / slabs;
     slab = (slab + KC - 1) / KC * KC;
+    // deterministic slab reduction through the caller's workspace (partials in front, the zero-initialised arrival counters in its
+    // last FS_WS_COUNTER_BYTES); FS_WGRAD_ATOMICS=1, no workspace or too many tiles: fp32 atomics
+    static const bool force_atomics = [] { const char* e = getenv("FS_WGRAD_ATOMICS"); return e && atoi(e) > 0; }();
+    a.part = nullptr; a.counters = nullptr; a.slabs = 1;
+    if (workspace && !force_atomics && aligned16(workspace) && workspace_bytes > FS_WS_COUNTER_BYTES &&
+        other * (long long)sizeof(unsigned int) <= FS_WS_COUNTER_BYTES) {
+        const long long room = (workspace_bytes - FS_WS_COUNTER_BYTES) / ((long long)BCH * BCH * sizeof(float));   // partial tiles that fit
+        long long fit = room / other;
+        if (fit >= 1) {
+            if (slabs > fit) {
+                slabs = fit;
+                slab = (M + slabs - 1) / slabs;
+                slab = (slab + KC - 1) / KC * KC;
+            }
+            a.part = (float*)workspace;
+            a.counters = (unsigned int*)((char*)workspace + workspace_bytes - FS_WS_COUNTER_BYTES);
+        }
+    }
     a.slab = slab;
     dim3 grid((unsigned)((M + slab - 1) / slab), (unsigned)(tiles_co * a.tiles_ci), (unsigned)taps);
+    a.slabs = (int)grid.x;
     FS_CENSUS(FS_CENSUS_WGRAD, d);
     if (d->dtype == FS_F32) FS_LAUNCH((wgrad_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, a);
     else FS_LAUNCH((wgrad_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, a);

@@ -9,7 +9,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import FS_BF16, FS_CONV_RELU, FS_CONV_TRANSPOSED, FS_F32, ConvDesc, ResizeDesc, ZoomDesc, call
+from ._lib import FS_BF16, FS_CONV_RELU, FS_CONV_RELU_TAIL, FS_CONV_TRANSPOSED, FS_F32, ConvDesc, ResizeDesc, ZoomDesc, call
 
 _DT = {torch.float32: FS_F32, torch.bfloat16: FS_BF16}
 
@@ -189,6 +189,7 @@ def unpack_weight_grad(dw_packed, grad, cout, cin, accumulate=False):
 # convolution
 # ---------------------------------------------------------------------------------------------------
 WORKSPACE_BYTES = 16 << 20          # FS_CONV_WORKSPACE_BYTES
+WS_COUNTER_BYTES = 65536            # FS_WS_COUNTER_BYTES: the workspace's tail holds zero-initialised arrival counters
 _workspaces = {}
 
 
@@ -199,6 +200,7 @@ def stream_workspace(device):
     ws = _workspaces.get(raw)
     if ws is None:
         ws = _workspaces[raw] = torch.empty(WORKSPACE_BYTES, dtype=torch.uint8, device=device)
+        ws[-WS_COUNTER_BYTES:].zero_()         # arrival counters of the deterministic reductions: zero once, every kernel leaves them zero
     return ws.data_ptr(), WORKSPACE_BYTES
 
 
@@ -298,7 +300,8 @@ def conv2d_wgrad(x, dy, R, S, stride, pad, cout=None):
     cout = dy.shape[1] if cout is None else cout
     d = conv_desc(x.shape, x_cs, cout, R, S, stride, pad, dy_cs, x.dtype, 0, (dy.shape[2], dy.shape[3]))
     dw = torch.zeros((cout, R, S, Cin), dtype=torch.float32, device=x.device)
-    call("fs_conv2d_wgrad", _stream(), ctypes.byref(d), _p(x), _p(dy), _p(dw))
+    ws, ws_bytes = stream_workspace(x.device)       # deterministic slab reduction (fs_conv2d_wgrad alone would use fp32 atomics)
+    call("fs_conv2d_wgrad_ws", _stream(), ctypes.byref(d), _p(x), _p(dy), _p(dw), R * S * Cin, 1, Cin, ws, ws_bytes)
     return dw
 
 
@@ -312,7 +315,8 @@ def conv2d_wgrad_into(x, dy, R, S, stride, pad, grad, cout=None):
     cout = dy.shape[1] if cout is None else cout
     assert grad.dtype == torch.float32 and grad.stride(2) == S * grad.stride(3) and grad.shape[0] >= cout and grad.shape[1] >= Cin
     d = conv_desc(x.shape, x_cs, cout, R, S, stride, pad, dy_cs, x.dtype, 0, (dy.shape[2], dy.shape[3]))
-    call("fs_conv2d_wgrad_strided", _stream(), ctypes.byref(d), _p(x), _p(dy), _p(grad), grad.stride(0), grad.stride(1), grad.stride(3))
+    ws, ws_bytes = stream_workspace(x.device)       # slab partials + arrival counters: bit-reproducible, no fp32 atomics
+    call("fs_conv2d_wgrad_ws", _stream(), ctypes.byref(d), _p(x), _p(dy), _p(grad), grad.stride(0), grad.stride(1), grad.stride(3), ws, ws_bytes)
     return grad
 
 

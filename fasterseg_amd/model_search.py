@@ -125,13 +125,27 @@ def _eval(op, x, alpha, ratios, groups):
         return op(x, alpha, ratios)
 
 
+# Eager ("random" / Gumbel width) passes replay one launch program per MixedOp.  On ONE stream such a pass is bound by the serial
+# latency of ~4.4 k kernels of a few microseconds each (36 ms, as long as the much larger max-width pass takes from its graph), while
+# the host needs ~2 us to issue one: the MixedOps of a layer only depend on the previous layer, so their programs are issued
+# round-robin on a few side streams (fork after the previous layer, join before the beta merges) and autograd replays the same
+# fork / join in backward (a node's backward runs on the stream of its forward).  FS_EAGER_LANES=1 keeps one stream.
+_EAGER_LANES = int(os.environ.get("FS_EAGER_LANES", "6"))
+
+
 def _run_tasks(tasks):
     """tasks: [(mixed_op, x, alpha, ratios, bn_groups)] -> outputs.  While capturing, every primitive of every task runs on its own
-    stream; the alpha-weighted sums follow on the capturing stream after the join."""
-    if not (_LAYER_LANES > 1 and len(tasks) > 1 and tasks[0][1].is_cuda and torch.cuda.is_current_stream_capturing()):
+    stream; the alpha-weighted sums follow on the capturing stream after the join.  Eager training passes put whole MixedOp
+    programs on side streams."""
+    on_gpu = len(tasks) > 1 and tasks[0][1].is_cuda
+    capturing = on_gpu and torch.cuda.is_current_stream_capturing()
+    eager_lanes = (on_gpu and not capturing and _EAGER_LANES > 1 and _PROGRAMS and torch.is_grad_enabled() and tasks[0][0].training)
+    if not ((capturing and _LAYER_LANES > 1) or eager_lanes):
         return [_eval(op, x, alpha, ratios, g) for op, x, alpha, ratios, g in tasks]
     main = torch.cuda.current_stream()
     pool = layer_lanes(main)
+    if not capturing:
+        pool = pool[:_EAGER_LANES]
     used, slot, pending = [], 0, []
 
     def lane_for(k):
@@ -144,13 +158,17 @@ def _run_tasks(tasks):
         widths = [None, None]
         coef = op._coefficients(x, alpha, ratios, widths)  # also selects the widths of the five primitives
         prog = None
-        if _PROGRAMS and _CAPTURE_PROGRAMS and op.training and torch.is_grad_enabled():
+        if _PROGRAMS and (_CAPTURE_PROGRAMS or not capturing) and op.training and torch.is_grad_enabled():
             with FN.bn_groups(groups):
                 prog = op._program(FN.as_nhwc(x), coef, widths[0], widths[1])
         if prog is not None:          # the whole MixedOp (five primitives, their sum, and in backward the sum of the five input
             with torch.cuda.stream(lane_for(slot)):        # gradients) as one launch program on one lane
                 pending.append((FN.mixed_op_program(FN.as_nhwc(x), coef, prog), None))
             slot += 1
+            continue
+        if not capturing:             # no program (nothing to differentiate, gradients outside the sink): per-module path, in place
+            with FN.bn_groups(groups):
+                pending.append((FN.weighted_sum([prim(x) for prim in op._ops], coef), None))
             continue
         outs = []
         for prim in op._ops:

@@ -37,6 +37,9 @@ class FlatSGD:
         self.pack_dtype = pack_dtype
         packable = [i for i, p in enumerate(params) if pack_dtype is not None and p.dim() == 4 and p.shape[0] % 8 == 0
                     and p.shape[1] % 8 == 0 and p.shape[2] == p.shape[3] and p.shape[2] in (1, 3)]
+        # packs follow the layout of the flat gradient buffer: filters whose gradient slices are adjacent (the fusable pairs of a
+        # search MixedOp, fusion.flat_order) have adjacent packs too, so one two-segment descriptor addresses both
+        packable.sort(key=lambda i: sync.offsets[i])
         total = sum(params[i].numel() for i in packable)
         self.pack_fwd = torch.empty(total, dtype=pack_dtype, device=dev) if packable else None
         self.pack_flip = torch.empty(total, dtype=pack_dtype, device=dev) if packable else None

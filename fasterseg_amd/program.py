@@ -230,14 +230,14 @@ class _Lowering:
                self.param(b.running_var), self.param(b.num_batches_tracked), float(b.eps), momentum, stats, saved, z.ref, y.ref,
                Ref(WS, 0), K.WORKSPACE_BYTES)
 
-        def backward(dy, need_x):
+        def backward(dy, need_x, dx_into=None):
             bl = self.b
             red = bl.alloc(TMPB, (G + 1 if G > 1 else 1) * 2 * cout * 4, zero=True)
             dz = self.new(bl, TMPB, x.N, cout, Ho, Wo)
             wf, wf_os, wf_ts, dx = None, 0, 0, None
             if need_x:
                 wf, wf_os, wf_ts = self.filter(bl, TMPB, w, cout, cin, True)
-                dx = self.new(bl, TMPB, x.N, cin, x.H, x.W)
+                dx = dx_into if dx_into is not None else self.new(bl, TMPB, x.N, cin, x.H, x.W)
             if self.want_w:
                 g = self.grad_slot(w)
                 assert g.stride(2) == S * g.stride(3)
@@ -248,9 +248,111 @@ class _Lowering:
                 dw, acc = (NULL, 0, 0, 0), (NULL, NULL)
             bl.emit(OP_UNIT_BWD, _Desc(desc), x.ref, wf or NULL, z.ref, y.ref if relu else NULL, dy.ref, dy.cs, saved,
                     absolute(b.weight), red, acc[0], acc[1], dz.ref, dw[0], dw[1], dw[2], dw[3], dx.ref if need_x else NULL,
-                    cin, wf_os, wf_ts, Ref(WS, 0), K.WORKSPACE_BYTES)
+                    dx.cs if need_x else cin, wf_os, wf_ts, Ref(WS, 0), K.WORKSPACE_BYTES)
             return dx
         return y, backward
+
+    # -- two conv -> BN -> [ReLU] modules on the same input as ONE unit over their concatenated output channels --------------
+    def fused_unit(self, x, conv_a, bn_a, conv_b, bn_b, relu_a, relu_b):
+        """conv_a / conv_b: USConv2d of identical geometry reading x; bn_*: their USBatchNorm2d.  Output: one map with channels
+        [A | B].  Returns None when the pair's storage is not laid out as two segments of one array (fusion.colocate / flat_order
+        were not applied): the caller then lowers the primitives one by one."""
+        from . import functional as FN
+        from .fusion import adjacent
+        f = self.f
+        cout, cin = conv_a.active_channels()
+        if conv_b.active_channels() != (cout, cin) or x.C != cin or not (relu_b or not relu_a):
+            return None
+        ba, bb = bn_a.active(), bn_b.active()
+        wa, wb = conv_a.weight, conv_b.weight
+        O, I, R, S = wa.shape
+        taps = R * S
+        if tuple(wb.shape) != (O, I, R, S) or conv_a.stride != conv_b.stride or conv_a.padding != conv_b.padding:
+            return None
+        for t in (ba, bb):
+            if not (t.training and t.track_running_stats):
+                return None
+        momentum = 0.1 if ba.momentum is None else float(ba.momentum)
+        if (0.1 if bb.momentum is None else float(bb.momentum)) != momentum or float(ba.eps) != float(bb.eps) or ba.num_features != cout:
+            return None
+        if not (adjacent(ba.weight, bb.weight) and adjacent(ba.bias, bb.bias) and adjacent(ba.running_mean, bb.running_mean)
+                and adjacent(ba.running_var, bb.running_var) and adjacent(ba.num_batches_tracked, bb.num_batches_tracked)):
+            return None
+        g_jump = 0
+        if self.want_w:
+            ga, gb = wa.grad, wb.grad
+            if ga is None or gb is None or not adjacent(ga, gb, ga.numel() * 4) or ga.stride() != gb.stride():
+                return None
+            for pa, pb in ((ba.weight, bb.weight), (ba.bias, bb.bias)):
+                if pa.grad is None or pb.grad is None or not adjacent(pa.grad, pb.grad):
+                    return None
+            g_jump = O - cout
+        rpa, rpb = FN.resident_pack(wa, self.dtype), FN.resident_pack(wb, self.dtype)
+        resident = rpa is not None and rpb is not None and adjacent(rpa[0], rpb[0]) and adjacent(rpa[1], rpb[1])
+        stride, pad = conv_a.stride[0], conv_a.padding[0]
+        Ho, Wo = (x.H + 2 * pad - R) // stride + 1, (x.W + 2 * pad - S) // stride + 1
+        C2 = 2 * cout
+        G = self.groups
+        if resident:
+            for w in (wa, wb):
+                self.guard.append((w, w.data_ptr(), w._version))
+            wp, w_os, w_ts, n_jump = absolute(rpa[0]), taps * I, I, O - cout
+        else:       # dense scratch pack [A rows | B rows]
+            for w in (wa, wb):
+                assert w.stride(3) == 1 and w.stride(2) == S
+                self.guard.append((w, w.data_ptr(), None))
+            wp = f.alloc(TMPF, C2 * taps * cin * self.esize)
+            for k, w in enumerate((wa, wb)):
+                f.emit(OP_PACK_WEIGHT, absolute(w), w.stride(0), w.stride(1), cout, cin, R, S, self.dt, 0, wp + k * cout * taps * cin * self.esize)
+            w_os, w_ts, n_jump = 0, 0, 0
+        flags = 0
+        if relu_b:
+            flags = K.FS_CONV_RELU | (0 if relu_a else K.FS_CONV_RELU_TAIL)
+        k_jump = (I * taps * O - cout) if resident else (cin * taps * cout - cout)
+        desc = ConvDesc(x.N, x.H, x.W, cin, C2, R, S, stride, pad, Ho, Wo, x.cs, C2, self.dt, flags, w_os, w_ts, 0, 0, 0, G,
+                        cout, n_jump, 0, k_jump, g_jump)
+        stats = f.alloc(TMPF, G * 2 * C2 * 4, zero=True)
+        saved = f.alloc(SAVE, G * 4 * C2 * 4)
+        z = self.new(f, SAVE, x.N, C2, Ho, Wo)
+        y = self.new(f, SAVE, x.N, C2, Ho, Wo)
+        f.emit(OP_UNIT_FWD, _Desc(desc), x.ref, wp, self.param(ba.weight), self.param(ba.bias), self.param(ba.running_mean),
+               self.param(ba.running_var), self.param(ba.num_batches_tracked), float(ba.eps), momentum, stats, saved, z.ref, y.ref,
+               Ref(WS, 0), K.WORKSPACE_BYTES)
+        for t in (bb.weight, bb.bias, bb.running_mean, bb.running_var):
+            self.guard.append((t, t.data_ptr(), None))
+
+        def backward(dcat, need_x):
+            """dcat: gradient w.r.t. the [A | B] output (2 cout channels, any channel stride)."""
+            bl = self.b
+            red = bl.alloc(TMPB, (G + 1 if G > 1 else 1) * 2 * C2 * 4, zero=True)
+            dz = self.new(bl, TMPB, x.N, C2, Ho, Wo)
+            wf, wf_os, wf_ts, dx = None, 0, 0, None
+            if need_x:
+                if resident:
+                    wf, wf_os, wf_ts = absolute(rpa[1]), taps * O, O
+                else:       # dense rotated packs [cin][R][S][cout], A then B
+                    wf = bl.alloc(TMPB, 2 * cin * taps * cout * self.esize)
+                    for k, w in enumerate((wa, wb)):
+                        bl.emit(OP_PACK_WEIGHT, absolute(w), w.stride(0), w.stride(1), cout, cin, R, S, self.dt, 1,
+                                wf + k * cin * taps * cout * self.esize)
+                    wf_os, wf_ts = taps * cout, cout
+                dx = self.new(bl, TMPB, x.N, cin, x.H, x.W)
+            if self.want_w:
+                g = self.grad_slot(wa)
+                self.grad_slot(wb)
+                assert g.stride(2) == S * g.stride(3)
+                gg, gb_ = self.grad_slot(ba.weight), self.grad_slot(ba.bias)
+                self.grad_slot(bb.weight)
+                self.grad_slot(bb.bias)
+                dw = (absolute(g), g.stride(0), g.stride(1), g.stride(3))
+                acc = (absolute(gg), absolute(gb_))
+            else:
+                dw, acc = (NULL, 0, 0, 0), (NULL, NULL)
+            bl.emit(OP_UNIT_BWD, _Desc(desc), x.ref, wf or NULL, z.ref, y.ref if relu_b else NULL, dcat.ref, dcat.cs, saved,
+                    absolute(ba.weight), red, acc[0], acc[1], dz.ref, dw[0], dw[1], dw[2], dw[3], dx.ref if need_x else NULL,
+                    cin, wf_os, wf_ts, Ref(WS, 0), K.WORKSPACE_BYTES)
+            return dx
+        return y, backward, cout
 
     # -- bilinear resize (align_corners=True) --------------------------------------------------------
     def resize(self, x, Ho, Wo, relu):
@@ -258,13 +360,13 @@ class _Lowering:
         y = self.new(f, SAVE, x.N, x.C, Ho, Wo)
         f.emit(OP_BILINEAR_FWD, _Desc(ResizeDesc(x.N, x.H, x.W, Ho, Wo, x.C, x.cs, y.cs, self.dt, int(relu), 0)), x.ref, y.ref)
 
-        def backward(dy, need_x):
+        def backward(dy, need_x, dx_into=None):
             if not need_x:
                 return None
             bl = self.b
             if relu and dy.cs != y.cs:
                 raise NotImplementedError("strided gradient into a ReLU-fused resize")
-            dx = self.new(bl, TMPB, x.N, x.C, x.H, x.W)
+            dx = dx_into if dx_into is not None else self.new(bl, TMPB, x.N, x.C, x.H, x.W)
             bl.emit(OP_BILINEAR_BWD, _Desc(ResizeDesc(x.N, x.H, x.W, Ho, Wo, x.C, dx.cs, dy.cs, self.dt, int(relu), 0)), dy.ref,
                     y.ref if relu else NULL, dx.ref)
             return dx
@@ -309,7 +411,8 @@ class _Lowering:
                 dzk = dz.ref + k * half * self.esize
                 if self.want_w:
                     g = self.grad_slot(w)
-                    bl.emit(OP_WGRAD_STRIDED, _Desc(descs[k]), x.ref, dzk, absolute(g), g.stride(0), g.stride(1), g.stride(3))
+                    bl.emit(OP_WGRAD_STRIDED, _Desc(descs[k]), x.ref, dzk, absolute(g), g.stride(0), g.stride(1), g.stride(3), Ref(WS, 0),
+                            K.WORKSPACE_BYTES)
                 if need_x:
                     wf, wf_os, wf_ts = self.filter(bl, TMPB, w, half, cin, True)
                     gk = self.new(bl, TMPB, x.N, cin, x.H, x.W)
@@ -370,6 +473,74 @@ def _ones(device):
     return _one_vectors[key]
 
 
+# FS_FUSE_MIXEDOP=0 lowers every primitive on its own (the round-2 programs)
+import os
+_FUSE = bool(int(os.environ.get("FS_FUSE_MIXEDOP", "1")))
+
+
+def _lower_fused(lo, x, mixed, need_x):
+    """The five primitives with the first convs of ('conv', 'conv_2x') and of ('conv_downup', 'conv_2x_downup') as one unit each and
+    one shared down-sample (fusion.py).  Returns (outs, grads, run_backward) or None when the pairs' storage is not adjacent.
+    grads[k]: where the weighted sum's backward must write d out_k (a channel slice of a pair's gradient buffer where that saves a
+    copy); run_backward() emits the backward commands and returns the tensors whose sum is d x."""
+    from .fusion import pair_modules
+    from .operations import FactorizedReduce
+    ops = mixed._ops
+    pairs = pair_modules(mixed)
+    if len(pairs) != 2 or not isinstance(ops[0], FactorizedReduce):
+        return None
+    (conv, conv2x), (du, du2x) = pairs
+    if conv.ZOOM or not du.ZOOM or conv.NUM_CONVS != 1 or conv2x.NUM_CONVS != 2 or du.NUM_CONVS != 1 or du2x.NUM_CONVS != 2:
+        return None
+    mark_f, mark_b = (len(lo.f.words), dict((k, list(v)) for k, v in lo.f.sizes.items())), None
+    stride = conv.stride
+    upsample = stride == 1
+    y0, bw0 = lo.primitive(x, ops[0])
+    fa = lo.fused_unit(x, conv.conv1, conv.bn1, conv2x.conv1, conv2x.bn1, True, True)
+    if fa is None:
+        lo.f.words = lo.f.words[:mark_f[0]]
+        lo.f.sizes = mark_f[1]
+        return None
+    ya, bwa, c = fa
+    y3, bw3 = lo.unit(ya.channels(c, c), conv2x.conv2, conv2x.bn2, True)
+    xd, bw_down = lo.resize(x, x.H // 2, x.W // 2, False)
+    fb = lo.fused_unit(xd, du.conv1, du.bn1, du2x.conv1, du2x.bn1, not upsample, True)
+    if fb is None:
+        lo.f.words = lo.f.words[:mark_f[0]]
+        lo.f.sizes = mark_f[1]
+        return None
+    yb, bwb, cb = fb
+    assert cb == c
+    y4, bw4 = lo.unit(yb.channels(c, c), du2x.conv2, du2x.bn2, not upsample)
+    y2 = yb.channels(0, c)
+    bw_up2 = bw_up4 = None
+    if upsample:
+        y2, bw_up2 = lo.resize(y2, x.H, x.W, True)
+        y4, bw_up4 = lo.resize(y4, x.H, x.W, True)
+    outs = [y0, ya.channels(0, c), y2, y3, y4]
+    b = lo.b
+    o = outs[0]
+    dcat_a = lo.new(b, TMPB, ya.N, 2 * c, ya.H, ya.W)                 # d [conv out | conv_2x.conv1 out]
+    dcat_b = lo.new(b, TMPB, yb.N, 2 * c, yb.H, yb.W)                 # d [conv_downup.conv1 out | conv_2x_downup.conv1 out]
+    dense = lambda: lo.new(b, TMPB, o.N, o.C, o.H, o.W)
+    grads = [dense(), dcat_a.channels(0, c), dense() if upsample else dcat_b.channels(0, c), dense(), dense()]
+
+    def run_backward():
+        if upsample:
+            bw_up2(grads[2], True, dx_into=dcat_b.channels(0, c))
+            d4 = bw_up4(grads[4], True)
+        else:
+            d4 = grads[4]
+        bw4(d4, True, dx_into=dcat_b.channels(c, c))
+        dxd = bwb(dcat_b, need_x)
+        dx_down = bw_down(dxd, need_x) if need_x else None
+        bw3(grads[3], True, dx_into=dcat_a.channels(c, c))
+        dx_a = bwa(dcat_a, need_x)
+        dx_0 = bw0(grads[0], need_x)
+        return [dx_0, dx_a, dx_down]
+    return outs, grads, run_backward
+
+
 def lower_mixed_op(mixed, x_shape, x_cs, dtype, device, need_x, need_coef, want_w, sink, groups=1):
     """Programs for `mixed` (ratios already set through set_prun_ratio) on an (N, C, H, W) NHWC input with channel stride x_cs;
     `groups` > 1: the batch is that many inputs the BatchNorms normalise independently (functional.bn_groups)."""
@@ -377,11 +548,15 @@ def lower_mixed_op(mixed, x_shape, x_cs, dtype, device, need_x, need_coef, want_
     assert N % groups == 0
     lo = _Lowering(dtype, want_w, sink, groups)
     x = Buf(Ref(X, 0), N, C, H, W, x_cs, lo.esize)
+    fused = _lower_fused(lo, x, mixed, need_x) if (_FUSE and len(mixed._ops) == 5) else None
     outs, backs = [], []
-    for op in mixed._ops:
-        y, bw = lo.primitive(x, op)
-        outs.append(y)
-        backs.append(bw)
+    if fused is not None:
+        outs = fused[0]
+    else:
+        for op in mixed._ops:
+            y, bw = lo.primitive(x, op)
+            outs.append(y)
+            backs.append(bw)
     n = len(outs)
     y0 = outs[0]
     assert all((o.N, o.C, o.H, o.W) == (y0.N, y0.C, y0.H, y0.W) for o in outs)
@@ -393,11 +568,11 @@ def lower_mixed_op(mixed, x_shape, x_cs, dtype, device, need_x, need_coef, want_
     if need_coef:
         gcoef = b.alloc(TMPB, 4 * 8, zero=True)
         b.emit(OP_WSUM_DOTS, dy.pixels, dy.C, n, dy.ref, dy.cs, [o.ref for o in outs], [o.cs for o in outs], lo.dt, gcoef)
-    gys = [lo.new(b, TMPB, y0.N, y0.C, y0.H, y0.W) for _ in range(n)]
+    gys = fused[1] if fused is not None else [lo.new(b, TMPB, y0.N, y0.C, y0.H, y0.W) for _ in range(n)]
     b.emit(OP_WSUM_BWD, dy.pixels, dy.C, n, dy.ref, dy.cs, Ref(COEF, 0), [g.ref for g in gys], [g.cs for g in gys], lo.dt)
-    dxs = [backs[k](gys[k], need_x) for k in range(n)]
+    dxs = fused[2]() if fused is not None else [backs[k](gys[k], need_x) for k in range(n)]
     if need_x:
-        b.emit(OP_WSUM, x.pixels, C, n, [d.ref for d in dxs], [d.cs for d in dxs], absolute(_ones(device)), Ref(GX, 0), C, lo.dt)
+        b.emit(OP_WSUM, x.pixels, C, len(dxs), [d.ref for d in dxs], [d.cs for d in dxs], absolute(_ones(device)), Ref(GX, 0), C, lo.dt)
     gcoef_off = None
     if gcoef is not None:
         gcoef_off = gcoef.off             # the zero region starts the arena
@@ -406,4 +581,6 @@ def lower_mixed_op(mixed, x_shape, x_cs, dtype, device, need_x, need_coef, want_
         if id(p) not in seen:
             seen.add(id(p))
             touched.append(p)
-    return MixedOpProgram(lo.f, lo.b, (y0.N, y0.C, y0.H, y0.W), touched, need_x, need_coef, gcoef_off, lo.guard)
+    prog = MixedOpProgram(lo.f, lo.b, (y0.N, y0.C, y0.H, y0.W), touched, need_x, need_coef, gcoef_off, lo.guard)
+    prog.fused = fused is not None
+    return prog

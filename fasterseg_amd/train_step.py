@@ -138,6 +138,13 @@ class SupernetStep:
         broadcast_parameters(self.model)
         arch_ids = {id(p) for group in self.model._arch_parameters for p in group}
         self.weights = [p for p in self.model.parameters() if id(p) not in arch_ids]      # train_search.py:94-98
+        # horizontal fusion inside every MixedOp ('conv' + 'conv_2x' first convs as one GEMM, the two zoomed primitives sharing their
+        # down-sample and first conv): the pairs' BatchNorm state, gradient slices and resident packs become adjacent (fusion.py)
+        from . import fusion
+        self.fused_pairs = 0
+        if bool(int(os.environ.get("FS_FUSE_MIXEDOP", "1"))):
+            self.fused_pairs = fusion.colocate(self.model)
+            self.weights = fusion.flat_order(self.model, self.weights)
         # The weight step's backward also reaches alpha/beta/ratio in the reference, but those gradients are zeroed by
         # the architect before it ever reads them (architect.py: optimizer.zero_grad() first); they are not computed here.
         self.arch_params = [p for group in self.model._arch_parameters for p in group]
@@ -263,8 +270,12 @@ class SupernetStep:
         self._graph_arenas = []
         from . import model_search
         side = torch.cuda.Stream()
-        model_search.branch_lanes(side)           # MixedOp forks its five primitives onto these inside the capture
-        model_search.layer_lanes(side)            # ... and the MixedOps of a layer fork onto these
+        lanes = model_search.branch_lanes(side)   # MixedOp forks its five primitives onto these inside the capture
+        lanes = lanes + model_search.layer_lanes(side)            # ... and the MixedOps of a layer fork onto these
+        from . import kernels as K
+        for lane in [side] + lanes:               # every lane's conv workspace (scratch + zeroed arrival counters) exists before
+            with torch.cuda.stream(lane):         # the capture: an allocation inside it would put the counter fill into the graph
+                K.stream_workspace(self.static["w"][0].device)
         state = (self.model.arch_idx, self.model.prun_mode)
         for phase in self.static:
             self._set_phase(phase)
@@ -381,7 +392,8 @@ class SupernetStep:
         specs = self._specs()
         return {"passes_per_phase": len(specs), "graphed": sum(1 for s_ in specs if self._is_static(s_)) if self.use_graphs else 0,
                 "eager": sum(1 for s_ in specs if not (self.use_graphs and self._is_static(s_))),
-                "programs_prewarmed": getattr(self, "programs_prewarmed", 0), "gc_frozen": bool(self.gc_freeze and self._prewarmed)}
+                "programs_prewarmed": getattr(self, "programs_prewarmed", 0), "gc_frozen": bool(self.gc_freeze and self._prewarmed),
+                "fused_bn_banks": self.fused_pairs}
 
     def _step_eager(self, imgs, target, imgs_search=None, target_search=None):
         loss_arch = None

@@ -36,6 +36,7 @@ typedef enum { FS_F32 = 0, FS_BF16 = 1 } fs_dtype;
 #define FS_CONV_RELU        1   /* y = max(y, 0) after scale/shift            (nn.ReLU, operations.py:74,147) */
 #define FS_CONV_TRANSPOSED  2   /* gather for the data gradient of a stride-2 conv (conv2d backward-input)   */
 #define FS_CONV_ACCUM       4   /* y += result (fp32 only), used by split accumulations                       */
+#define FS_CONV_RELU_TAIL   8   /* fused train units with n_seg > 0: the ReLU of FS_CONV_RELU applies to output channels >= n_seg only */
 /* fs_conv3x3_s1_fwd only: output-channel tile per block instead of the heuristic (the engine times the candidates)   */
 #define FS_CONV_TILE_32     0x1000
 #define FS_CONV_TILE_64     0x2000
@@ -63,6 +64,17 @@ typedef struct fs_conv_desc {
                                updated group after group): ONE batched evaluation of a module on several inputs with the
                                arithmetic of separate evaluations (the from-down / from-keep pair of a supernet cell,
                                model_search.py:322-329).  0 or 1 = ordinary BatchNorm over the whole batch. */
+    int n_seg, n_jump;      /* two-segment filter bank (horizontal fusion of two convolutions that read the same input - 'conv' and
+                               'conv_2x'.conv1, 'conv_downup' and 'conv_2x_downup'.conv1 of a search MixedOp, model_search.py:64-78 -
+                               into ONE GEMM over their concatenated output channels): n_seg > 0 = output channels >= n_seg take
+                               filter row (channel + n_jump), i.e. the second bank starts n_seg + n_jump rows (of w_os elements)
+                               behind the first.  0 = one bank. */
+    int k_seg, k_jump;      /* the same along the contraction: input channels >= k_seg of every tap are read k_jump ELEMENTS further
+                               (the data gradient of a fused pair contracts over both rotated packs).  In the descriptor of a fused
+                               train unit (fs_conv_bn_act_train_fwd/bwd) k_jump is the jump of the rotated pack handed to the
+                               backward (k_seg is implied: n_seg). */
+    int g_jump;             /* fused train units: gradient rows of output channels >= n_seg are g_jump rows (of o_stride elements)
+                               further (the two filters' gradient slices are adjacent in the flat buffer) */
 } fs_conv_desc;
 
 typedef struct fs_resize_desc {
@@ -76,7 +88,7 @@ typedef struct fs_resize_desc {
 const char* fs_last_error(void);
 /* ABI revision of this header; fs_version() returns the one the library was built from.  Bindings check both this and
  * fs_struct_size() when they load the library (fasterseg_amd/_lib.py) - a stale .so must not be used silently. */
-#define FS_ABI_VERSION 203
+#define FS_ABI_VERSION 204
 int fs_version(void);
 int fs_struct_size(int which);   /* 0 fs_conv_desc, 1 fs_resize_desc, 2 fs_zoom_desc, 3 fs_sgd_tensor, 4 fs_logits_desc; -1 otherwise */
 /* test hook: force the tile configuration of fs_conv2d_fwd (0..6; -1 = heuristic).  Not for production use. */
@@ -152,6 +164,14 @@ fs_status fs_conv2d_wgrad(void* stream, const fs_conv_desc* d, const void* x, co
  * [O][R][S][I] (i_stride 1: coalesced atomics): no packed temporary, no unpack pass, no extra add. */
 fs_status fs_conv2d_wgrad_strided(void* stream, const fs_conv_desc* d, const void* x, const void* dy, float* dw,
                                   long long o_stride, long long i_stride, long long t_stride);
+/* The same with a caller workspace: the partial sums of the pixel slabs are stored there and added up in slab order by the block
+ * that arrives last (integer arrival counters), i.e. the result is bit-reproducible and no fp32 atomics are issued.  The LAST
+ * FS_WS_COUNTER_BYTES of the workspace hold the counters: zero before the first call, left zero by every call; launches sharing
+ * a workspace (or a gradient tensor) must be ordered (same stream).  workspace == NULL: the atomics of the entry points above. */
+#define FS_WS_COUNTER_BYTES 65536
+long long fs_workspace_counter_bytes(void);
+fs_status fs_conv2d_wgrad_ws(void* stream, const fs_conv_desc* d, const void* x, const void* dy, float* dw, long long o_stride,
+                             long long i_stride, long long t_stride, void* workspace, long long workspace_bytes);
 
 /* Stem convolution (model_seg.py:193): NCHW fp32 image (Cin=3) -> NHWC `dtype`, 3x3 stride 2 pad 1, fused
  * scale/shift/ReLU.  w_packed is [Cout][3][3][3] fp32. */

@@ -9,7 +9,7 @@ from fasterseg_amd import model_search, program
 from fasterseg_amd.parallel import FlatGradientSync
 
 NARGS = {program.OP_MEMSET: 2, program.OP_PACK_WEIGHT: 10, program.OP_CONV_FWD: 9, program.OP_UNIT_FWD: 16, program.OP_UNIT_BWD: 23,
-         program.OP_WGRAD_STRIDED: 7, program.OP_CHANNEL_STATS: 6, program.OP_BN_FINALIZE: 14, program.OP_AFFINE_ACT: 10,
+         program.OP_WGRAD_STRIDED: 9, program.OP_CHANNEL_STATS: 6, program.OP_BN_FINALIZE: 14, program.OP_AFFINE_ACT: 10,
          program.OP_BN_BWD_REDUCE: 13, program.OP_BN_BWD_APPLY: 19, program.OP_BILINEAR_FWD: 3, program.OP_BILINEAR_BWD: 4,
          program.OP_WSUM: 9, program.OP_WSUM_BWD: 9, program.OP_WSUM_DOTS: 9, program.OP_AXPY: 9, program.OP_BN_UNIT_FWD: 18,
          program.OP_BN_UNIT_BWD: 18}
@@ -89,6 +89,64 @@ def test_mixed_op_lowering_structure(stride, want_w):
             assert b_ops.count(program.OP_WGRAD_STRIDED) == 2
     else:
         assert prog.touched == []
+    assert prog.valid()
+
+
+@pytest.mark.parametrize("stride", [1, 2])
+@pytest.mark.parametrize("want_w", [False, True])
+def test_fused_mixed_op_lowering_structure(stride, want_w):
+    """With the pairs' storage made adjacent (fusion.colocate / flat_order) a MixedOp lowers to 5 conv->BN units instead of 7 (stride
+    1: skip, [conv | conv_2x.conv1], conv_2x.conv2, [conv_downup | conv_2x_downup.conv1], conv_2x_downup.conv2), ONE down-sample
+    instead of two, and the two fused units carry the two-segment descriptor fields; without adjacency the same call lowers unfused."""
+    import ctypes
+    from fasterseg_amd import fusion
+    from fasterseg_amd._lib import FS_CONV_RELU, FS_CONV_RELU_TAIL, ConvDesc
+    torch.manual_seed(0)
+    m = model_search.MixedOp(48, 48 * stride, stride=stride, width_mult_list=WIDTHS).train()
+    m.set_prun_ratio((8. / 12, 10. / 12))
+    for p in m.parameters():
+        p.requires_grad_(False)
+    plain = program.lower_mixed_op(m, (2, 32, 16, 24), 32, torch.float32, torch.device("cpu"), True, True, False, None)
+    assert not plain.fused
+    for p in m.parameters():
+        p.requires_grad_(True)
+    assert fusion.colocate(m) == 2 * len(WIDTHS)
+    sd = m.state_dict()
+    assert len(sd) == len({k: None for k in sd}) and all(sd[k].shape == v.shape for k, v in model_search.MixedOp(
+        48, 48 * stride, stride=stride, width_mult_list=WIDTHS).state_dict().items()), "state_dict keys / shapes unchanged"
+    sync = None
+    if want_w:
+        sync = FlatGradientSync(fusion.flat_order(m, m.parameters()))
+        sync.prepare()
+    else:
+        for p in m.parameters():
+            p.requires_grad_(False)
+    m.set_prun_ratio((8. / 12, 10. / 12))
+    prog = program.lower_mixed_op(m, (2, 32, 16, 24), 32, torch.float32, torch.device("cpu"), need_x=True, need_coef=not want_w,
+                                  want_w=want_w, sink=sync)
+    assert prog.fused
+    fwd = decode(prog.f_words, prog.f_n, {program.SAVE: prog.save_bytes, program.TMPF: prog.tmpf_bytes})
+    bwd = decode(prog.b_words, prog.b_n, {program.SAVE: prog.save_bytes, program.TMPB: prog.tmpb_bytes})
+    f_ops, b_ops = [c[0] for c in fwd], [c[0] for c in bwd]
+    units = 5 if stride == 1 else 4
+    assert f_ops.count(program.OP_UNIT_FWD) == units and b_ops.count(program.OP_UNIT_BWD) == units
+    assert f_ops.count(program.OP_BILINEAR_FWD) == (3 if stride == 1 else 1) and b_ops.count(program.OP_BILINEAR_BWD) == (3 if stride == 1 else 1)
+    assert b_ops[-1] == program.OP_WSUM and [a for op, a in bwd if op == program.OP_WSUM][-1][2] == (0, 3), "dx = sum of three tensors"
+    cout = int(48 * stride * 10 / 12)
+    blob = bytes(prog.f_blob)
+    seg = []
+    for op, args in fwd:
+        if op == program.OP_UNIT_FWD:
+            d = ConvDesc.from_buffer_copy(blob[args[0][1]:args[0][1] + ctypes.sizeof(ConvDesc)])
+            if d.n_seg:
+                seg.append(d)
+    assert len(seg) == 2 and all(d.Cout == 2 * cout and d.n_seg == cout and d.y_cs == 2 * cout for d in seg)
+    assert seg[0].flags & FS_CONV_RELU and not seg[0].flags & FS_CONV_RELU_TAIL          # conv | conv_2x.conv1: ReLU on both
+    # conv_downup's ReLU follows its up-sample (operations.py:271-276): at stride 1 only the conv_2x_downup half is rectified here
+    assert bool(seg[1].flags & FS_CONV_RELU_TAIL) == (stride == 1)
+    if want_w:
+        assert all(d.g_jump == 48 * stride - cout for d in seg)
+        assert len({id(p) for p in prog.touched}) == len(prog.touched) > 0 and all(sync.accepts(p) for p in prog.touched)
     assert prog.valid()
 
 

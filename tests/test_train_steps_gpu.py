@@ -112,10 +112,14 @@ WIDTHS = [4. / 12, 6. / 12, 8. / 12, 10. / 12, 1.]
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 @pytest.mark.parametrize("phase", ["w", "a"])
 @pytest.mark.parametrize("stride", [1, 2])
-def test_mixed_op_program_matches_module_path(stride, phase, dtype):
+@pytest.mark.parametrize("fused", [False, True], ids=["plain", "fused"])
+def test_mixed_op_program_matches_module_path(stride, phase, dtype, fused):
     """The launch program of a MixedOp (fs_exec_program) against the per-module autograd path on the same inputs: output,
-    dx, d alpha, every parameter gradient (through the flat buffer) and the BN running statistics."""
+    dx, d alpha, every parameter gradient (through the flat buffer) and the BN running statistics.  fused: the pairs' storage is
+    made adjacent (fusion.colocate / flat_order), so the program evaluates 'conv' + 'conv_2x'.conv1 and 'conv_downup' +
+    'conv_2x_downup'.conv1 as one two-segment conv -> BN unit each (and one shared down-sample) - the module path does not."""
     import copy
+    from fasterseg_amd import fusion
     from fasterseg_amd import kernels as K
     from fasterseg_amd import model_search
     from fasterseg_amd.parallel import FlatGradientSync
@@ -124,8 +128,10 @@ def test_mixed_op_program_matches_module_path(stride, phase, dtype):
     for p in m.parameters():
         if p.dim() == 1:
             p.data.uniform_(0.5, 1.5)
+    if fused:
+        assert fusion.colocate(m) == 2 * len(WIDTHS)
     state0 = copy.deepcopy(m.state_dict())
-    sync = FlatGradientSync(m.parameters())
+    sync = FlatGradientSync(fusion.flat_order(m, m.parameters()) if fused else m.parameters())
     x0 = K.to_nhwc(torch.randn(2, 32, 16, 24, device="cuda"), dtype)
     coef0 = torch.softmax(torch.randn(5, device="cuda"), 0)
     dy0 = K.to_nhwc(torch.randn(2, 40 * stride, 16 // stride, 24 // stride, device="cuda"), dtype)
@@ -143,6 +149,8 @@ def test_mixed_op_program_matches_module_path(stride, phase, dtype):
             coef = coef0.clone().requires_grad_(phase == "a")
             out = m(x, coef, (8. / 12, 10. / 12))
             assert (type(out.grad_fn).__name__ == "_MixedOpProgramBackward") == use_program
+            if use_program:
+                assert all(pr.fused == fused for pr in m.__dict__["_programs"].values()), "program fusion state"
             out.backward(dy0)
             rec = {"out": out.detach().float().clone(), "dx": x.grad.float().clone()}
             if phase == "a":
