@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfasterseg_hip.so")
 
-EXPECTED_ABI = 204          # FS_ABI_VERSION of include/fasterseg_hip.h these bindings were written against
+EXPECTED_ABI = 205          # FS_ABI_VERSION of include/fasterseg_hip.h these bindings were written against
 FS_F32, FS_BF16 = 0, 1
 FS_CONV_RELU, FS_CONV_TRANSPOSED, FS_CONV_ACCUM, FS_CONV_RELU_TAIL = 1, 2, 4, 8
 
@@ -71,6 +71,8 @@ SIGNATURES = {
     "fs_affine_act": [c_vp, c_ll, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int],
     "fs_channel_stats": [c_vp, c_ll, c_int, c_vp, c_int, c_int, c_vp],
     "fs_channel_stats_g": [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_int, c_vp],
+    "fs_channel_stats_ws": [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_int, c_vp, c_vp, c_ll],
+    "fs_bn_bwd_reduce_ws": [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_ll],
     "fs_bn_train_apply_g": [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_float, c_float, c_vp, c_vp, c_vp, c_vp, c_vp,
                             c_int, c_int, c_int],
     "fs_bn_bwd_reduce_g": [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp],
@@ -84,9 +86,9 @@ SIGNATURES = {
     "fs_bn_bwd_apply": [c_vp, c_ll, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_ll, c_int,
                         c_int, c_vp, c_int, c_vp, c_vp],
     "fs_bn_act_train_fwd": [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_float, c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
-                            c_int, c_int, c_int],
+                            c_int, c_int, c_int, c_vp, c_ll],
     "fs_bn_act_train_bwd": [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_vp,
-                            c_int, c_vp, c_vp],
+                            c_int, c_vp, c_vp, c_vp, c_ll],
     "fs_conv_bn_act_train_fwd": [c_vp, ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_float, c_float,
                                  c_vp, c_vp, c_vp, c_vp, c_vp, c_ll],
     "fs_conv_bn_act_train_bwd": [c_vp, ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp,

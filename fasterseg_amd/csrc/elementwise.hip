@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(long long pixels, int 
                                                           int y_cs, const float* __restrict__ mean,
                                                           const float* __restrict__ invstd, int relu,
                                                           float* __restrict__ out, long long pix_per_block, long long group_pixels,
-                                                          int saved_stride) {
+                                                          int saved_stride, float* __restrict__ part, unsigned int* counters) {
     constexpr int VEC = Elem<T>::VEC;
     __shared__ float red[2][256][VEC + 1];
     // blockIdx.y = group: its pixel range, its output slot (2C floats) and its saved (mean, invstd) block
@@ -267,13 +267,45 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(long long pixels, int 
     for (int i = 0; i < VEC; ++i) { red[0][tid][i] = a0[i]; red[1][tid][i] = a1[i]; }
     __syncthreads();
     // column sums: thread t < cv*VEC*2 reduces one (which, channel)
+    if (part == nullptr) {
+        for (int k = tid; k < 2 * C; k += 256) {
+            const int which = k / C, c = k - which * C;
+            const int cc = c / VEC, ci = c - cc * VEC;
+            float s = 0.f;
+            for (int r = 0; r < rpb; ++r) s += red[which][r * cv + cc][ci];
+            atomicAdd(out + which * C + c, s);
+        }
+        return;
+    }
+    // Deterministic form: the block's 2C column sums go to its slot of the workspace; the block that arrives LAST at the group's
+    // counter (integer atomic) adds the slots up in block order - eight interleaved row groups per column, combined in a fixed tree -
+    // and stores the totals.  Same bits whatever the block schedule; no float atomics.
+    __shared__ int s_last;
+    __shared__ float fin[8][33];
+    const int nb = gridDim.x;
+    float* mine = part + ((long long)blockIdx.y * nb + blockIdx.x) * 2 * C;
     for (int k = tid; k < 2 * C; k += 256) {
         const int which = k / C, c = k - which * C;
         const int cc = c / VEC, ci = c - cc * VEC;
         float s = 0.f;
         for (int r = 0; r < rpb; ++r) s += red[which][r * cv + cc][ci];
-        atomicAdd(out + which * C + c, s);
+        store_coherent(mine + k, s);
     }
+    if (!arrive_last(&counters[blockIdx.y], (unsigned int)nb, &s_last)) return;
+    const float* all = part + (long long)blockIdx.y * nb * 2 * C;
+    const int fc = tid & 31, rg = tid >> 5;
+    for (int k0 = 0; k0 < 2 * C; k0 += 32) {
+        const int k = k0 + fc;
+        float s = 0.f;
+        if (k < 2 * C)
+            for (int b = rg; b < nb; b += 8) s += load_coherent(all + (long long)b * 2 * C + k);
+        fin[rg][fc] = s;
+        __syncthreads();
+        if (rg == 0 && k < 2 * C)
+            out[k] = ((fin[0][fc] + fin[1][fc]) + (fin[2][fc] + fin[3][fc])) + ((fin[4][fc] + fin[5][fc]) + (fin[6][fc] + fin[7][fc]));
+        __syncthreads();
+    }
+    if (tid == 0) __hip_atomic_store(&counters[blockIdx.y], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <typename T>
@@ -582,8 +614,30 @@ static int reduce_blocks(long long pixels, int rpb, long long* ppb) {
     return (int)((pixels + per - 1) / per);
 }
 
-extern "C" fs_status fs_channel_stats_g(void* stream, long long pixels, int C, int groups, const void* x, int x_cs, int dtype,
-                                        float* stats) {
+// deterministic reductions: partial slots in front of the caller's workspace, arrival counters in its last FS_WS_COUNTER_BYTES
+// (zero before the first use, left zero).  Returns false (-> float atomics) when there is no room; `blocks` may be lowered to fit.
+static bool reduce_ws(void* workspace, long long workspace_bytes, int groups, int C, long long mg, int rpb, int* blocks, long long* ppb,
+                      float** part, unsigned int** counters) {
+    static const bool force_atomics = [] { const char* e = getenv("FS_BN_ATOMICS"); return e && atoi(e) > 0; }();
+    *part = nullptr; *counters = nullptr;
+    if (!workspace || force_atomics || !aligned16(workspace) || workspace_bytes <= FS_WS_COUNTER_BYTES) return false;
+    if ((long long)groups * (long long)sizeof(unsigned int) > FS_WS_COUNTER_BYTES) return false;
+    const long long room = (workspace_bytes - FS_WS_COUNTER_BYTES) / ((long long)sizeof(float) * 2 * C * groups);
+    if (room < 1) return false;
+    long long cap = room < 1024 ? room : 1024;          // the finishing block reads cap x 2C floats
+    if (*blocks > cap) {
+        long long per = (mg + cap - 1) / cap;
+        per = (per + rpb - 1) / rpb * rpb;
+        *ppb = per;
+        *blocks = (int)((mg + per - 1) / per);
+    }
+    *part = (float*)workspace;
+    *counters = (unsigned int*)((char*)workspace + workspace_bytes - FS_WS_COUNTER_BYTES);
+    return true;
+}
+
+extern "C" fs_status fs_channel_stats_ws(void* stream, long long pixels, int C, int groups, const void* x, int x_cs, int dtype,
+                                         float* stats, void* workspace, long long workspace_bytes) {
     fs_status s;
     if ((s = check_slice("fs_channel_stats", x, x_cs, C, dtype)) != FS_OK) return s;
     FS_REQUIRE(stats, FS_ERR_INVALID, "fs_channel_stats: null stats");
@@ -592,11 +646,18 @@ extern "C" fs_status fs_channel_stats_g(void* stream, long long pixels, int C, i
     FS_REQUIRE(cv <= 256, FS_ERR_UNSUPPORTED, "fs_channel_stats: C=%d too large", C);
     long long ppb;
     const long long mg = pixels / groups;
-    const int blocks = reduce_blocks(mg, 256 / cv, &ppb);
+    int blocks = reduce_blocks(mg, 256 / cv, &ppb);
+    float* part; unsigned int* counters;
+    reduce_ws(workspace, workspace_bytes, groups, C, mg, 256 / cv, &blocks, &ppb, &part, &counters);
     DT_DISPATCH(dtype, FS_LAUNCH((chan_reduce_kernel<T, 0>), dim3(blocks, groups), dim3(256), 0, (hipStream_t)stream, pixels, C,
                                           (const T*)x, x_cs, (const T*)nullptr, 0, (const T*)nullptr, 0, nullptr, nullptr, 0,
-                                          stats, ppb, mg, 0);)
+                                          stats, ppb, mg, 0, part, counters);)
     return check_launch("fs_channel_stats");
+}
+
+extern "C" fs_status fs_channel_stats_g(void* stream, long long pixels, int C, int groups, const void* x, int x_cs, int dtype,
+                                        float* stats) {
+    return fs_channel_stats_ws(stream, pixels, C, groups, x, x_cs, dtype, stats, nullptr, 0);
 }
 
 extern "C" fs_status fs_channel_stats(void* stream, long long pixels, int C, const void* x, int x_cs, int dtype, float* stats) {
@@ -614,9 +675,9 @@ extern "C" fs_status fs_bn_finalize(void* stream, int C, long long count, const 
 
 // Grouped forms (fs_conv_desc.bn_groups): `saved` = [groups][4][C] (mean, invstd, scale, shift per group), `red` = [groups][2][C]
 // partial reductions; fs_bn_bwd_apply_g also writes their sum over the groups to red_total[2][C] when given.
-extern "C" fs_status fs_bn_bwd_reduce_g(void* stream, long long pixels, int C, int groups, const void* x, int x_cs, const void* dy,
-                                        int dy_cs, const void* y_out, int y_cs, const float* mean, const float* invstd,
-                                        int saved_stride, int dtype, int relu, float* red) {
+extern "C" fs_status fs_bn_bwd_reduce_ws(void* stream, long long pixels, int C, int groups, const void* x, int x_cs, const void* dy,
+                                         int dy_cs, const void* y_out, int y_cs, const float* mean, const float* invstd,
+                                         int saved_stride, int dtype, int relu, float* red, void* workspace, long long workspace_bytes) {
     fs_status s;
     if ((s = check_slice("fs_bn_bwd_reduce", x, x_cs, C, dtype)) != FS_OK) return s;
     if ((s = check_slice("fs_bn_bwd_reduce", dy, dy_cs, C, dtype)) != FS_OK) return s;
@@ -627,11 +688,20 @@ extern "C" fs_status fs_bn_bwd_reduce_g(void* stream, long long pixels, int C, i
     FS_REQUIRE(cv <= 256, FS_ERR_UNSUPPORTED, "fs_bn_bwd_reduce: C=%d too large", C);
     long long ppb;
     const long long mg = pixels / groups;
-    const int blocks = reduce_blocks(mg, 256 / cv, &ppb);
+    int blocks = reduce_blocks(mg, 256 / cv, &ppb);
+    float* part; unsigned int* counters;
+    reduce_ws(workspace, workspace_bytes, groups, C, mg, 256 / cv, &blocks, &ppb, &part, &counters);
     DT_DISPATCH(dtype, FS_LAUNCH((chan_reduce_kernel<T, 1>), dim3(blocks, groups), dim3(256), 0, (hipStream_t)stream, pixels, C,
                                           (const T*)x, x_cs, (const T*)dy, dy_cs, (const T*)y_out, y_cs, mean, invstd, relu, red,
-                                          ppb, mg, saved_stride);)
+                                          ppb, mg, saved_stride, part, counters);)
     return check_launch("fs_bn_bwd_reduce");
+}
+
+extern "C" fs_status fs_bn_bwd_reduce_g(void* stream, long long pixels, int C, int groups, const void* x, int x_cs, const void* dy,
+                                        int dy_cs, const void* y_out, int y_cs, const float* mean, const float* invstd,
+                                        int saved_stride, int dtype, int relu, float* red) {
+    return fs_bn_bwd_reduce_ws(stream, pixels, C, groups, x, x_cs, dy, dy_cs, y_out, y_cs, mean, invstd, saved_stride, dtype, relu, red,
+                               nullptr, 0);
 }
 
 extern "C" fs_status fs_bn_bwd_reduce(void* stream, long long pixels, int C, const void* x, int x_cs, const void* dy, int dy_cs,

@@ -205,14 +205,14 @@ extern "C" fs_status fs_exec_program_streams(void* const* streams, int n_streams
                 st = fs_bilinear_argmax(stream, (const fs_resize_desc*)P(0), P(1), (unsigned char*)P(2));
                 break;
             case FS_OP_BN_UNIT_FWD:
-                NEED(18);
+                NEED(20);
                 st = fs_bn_act_train_fwd(stream, L(0), I(1), I(2), P(3), I(4), PF(5), PF(6), F(7), F(8), PF(9), PF(10), (long long*)P(11),
-                                         PF(12), PF(13), P(14), I(15), I(16), I(17));
+                                         PF(12), PF(13), P(14), I(15), I(16), I(17), P(18), L(19));
                 break;
             case FS_OP_BN_UNIT_BWD:
-                NEED(18);
+                NEED(20);
                 st = fs_bn_act_train_bwd(stream, L(0), I(1), I(2), P(3), I(4), P(5), I(6), P(7), I(8), PF(9), PF(10), PF(11), I(12), I(13),
-                                         P(14), I(15), PF(16), PF(17));
+                                         P(14), I(15), PF(16), PF(17), P(18), L(19));
                 break;
             case FS_OP_ZOOM_CELL:
                 NEED(9);

@@ -26,14 +26,15 @@ static inline int unit_relu(const fs_conv_desc* d, bool forward = false) {
 extern "C" fs_status fs_bn_act_train_fwd(void* stream, long long pixels, int C, int groups, void* z, int z_cs, const float* gamma,
                                          const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                                          long long* num_batches_tracked, float* stats, float* saved, void* y, int y_cs, int dtype,
-                                         int relu) {
+                                         int relu, void* workspace, long long workspace_bytes) {
     FS_REQUIRE(groups >= 1 && pixels > 0 && pixels % groups == 0, FS_ERR_INVALID, "fs_bn_act_train_fwd: %lld pixels in %d groups",
                pixels, groups);
     if (pixels / groups <= BN_COL_MAX_PIXELS)
         return fs_bn_group_fwd(stream, pixels, C, groups, z, z_cs, nullptr, 1, gamma, beta, eps, momentum, running_mean, running_var,
                                num_batches_tracked, saved, y, y_cs, dtype, relu);
     FS_REQUIRE(stats, FS_ERR_INVALID, "fs_bn_act_train_fwd: null stats");
-    fs_status s = fs_channel_stats_g(stream, pixels, C, groups, z, z_cs, dtype, stats);           // stats[groups][2][C], zeroed
+    // stats[groups][2][C] (zeroed); with a workspace the block partials are added up in block order (bit-reproducible)
+    fs_status s = fs_channel_stats_ws(stream, pixels, C, groups, z, z_cs, dtype, stats, workspace, workspace_bytes);
     if (s != FS_OK) return s;
     return fs_bn_train_apply_g(stream, pixels, C, groups, z, z_cs, stats, gamma, beta, eps, momentum, running_mean, running_var,
                                num_batches_tracked, saved, y, y_cs, dtype, relu);
@@ -41,7 +42,8 @@ extern "C" fs_status fs_bn_act_train_fwd(void* stream, long long pixels, int C, 
 
 extern "C" fs_status fs_bn_act_train_bwd(void* stream, long long pixels, int C, int groups, const void* z, int z_cs, const void* dy,
                                          int dy_cs, const void* y, int y_cs, const float* saved, const float* gamma, float* red,
-                                         int dtype, int relu, void* dz, int dz_cs, float* dgamma_acc, float* dbeta_acc) {
+                                         int dtype, int relu, void* dz, int dz_cs, float* dgamma_acc, float* dbeta_acc, void* workspace,
+                                         long long workspace_bytes) {
     FS_REQUIRE(groups >= 1 && pixels > 0 && pixels % groups == 0, FS_ERR_INVALID, "fs_bn_act_train_bwd: %lld pixels in %d groups",
                pixels, groups);
     FS_REQUIRE(saved && red, FS_ERR_INVALID, "fs_bn_act_train_bwd: null argument");
@@ -52,7 +54,8 @@ extern "C" fs_status fs_bn_act_train_bwd(void* stream, long long pixels, int C, 
     const float* invstd = saved + C;
     // red = [2][C] totals (what fs_bn_group_bwd leaves) followed, for groups > 1, by [groups][2][C] zeroed partials
     float* part = groups > 1 ? red + 2 * C : red;
-    fs_status s = fs_bn_bwd_reduce_g(stream, pixels, C, groups, z, z_cs, dy, dy_cs, y, y_cs, mean, invstd, 4 * C, dtype, relu, part);
+    fs_status s = fs_bn_bwd_reduce_ws(stream, pixels, C, groups, z, z_cs, dy, dy_cs, y, y_cs, mean, invstd, 4 * C, dtype, relu, part,
+                                      workspace, workspace_bytes);
     if (s != FS_OK) return s;
     return fs_bn_bwd_apply_g(stream, pixels, C, groups, z, z_cs, dy, dy_cs, y, y_cs, mean, invstd, 4 * C, gamma, part, pixels / groups,
                              dtype, relu, dz, dz_cs, groups > 1 ? red : nullptr, dgamma_acc, dbeta_acc);
@@ -79,11 +82,15 @@ extern "C" fs_status fs_conv_bn_act_train_fwd(void* stream, const fs_conv_desc* 
                                eps, momentum, running_mean, running_var, num_batches_tracked, saved, y, d->y_cs, d->dtype,
                                unit_relu(d, true));
     }
-    if (groups > 1) {              // the conv's fused statistics are per launch, not per group: one reduction launch more
+    // The conv epilogue's fused statistics are float atomics (run-to-run differences in the last bits of a mean) and per launch, not per
+    // group: with a workspace the statistics come from the deterministic reduction pass instead - one launch more.
+    // FS_BN_EPILOGUE_STATS=1 keeps the epilogue statistics for ungrouped maps.
+    static const bool epilogue_stats = [] { const char* e = getenv("FS_BN_EPILOGUE_STATS"); return e && atoi(e) > 0; }();
+    if (groups > 1 || (workspace && !epilogue_stats)) {
         fs_status s = fs_conv2d_fwd_ws(stream, &c, x, w_packed, nullptr, nullptr, z, nullptr, workspace, workspace_bytes);
         if (s != FS_OK) return s;
         return fs_bn_act_train_fwd(stream, count, C, groups, z, d->y_cs, gamma, beta, eps, momentum, running_mean, running_var,
-                                   num_batches_tracked, stats, saved, y, d->y_cs, d->dtype, unit_relu(d, true));
+                                   num_batches_tracked, stats, saved, y, d->y_cs, d->dtype, unit_relu(d, true), workspace, workspace_bytes);
     }
     fs_status s = fs_conv2d_fwd_ws(stream, &c, x, w_packed, nullptr, nullptr, z, stats, workspace, workspace_bytes);   // (+ sum / sumsq)
     if (s != FS_OK) return s;
@@ -108,10 +115,11 @@ extern "C" fs_status fs_conv_bn_act_train_bwd(void* stream, const fs_conv_desc* 
     fs_status s;
     if (pixels / groups <= BN_COL_MAX_PIXELS || groups > 1) {
         s = fs_bn_act_train_bwd(stream, pixels, C, groups, z, d->y_cs, dy, dy_cs, y, d->y_cs, saved, gamma, red, d->dtype, relu, dz, C,
-                                dgamma_acc, dbeta_acc);          // dz is dense: channel stride == Cout
+                                dgamma_acc, dbeta_acc, workspace, workspace_bytes);          // dz is dense: channel stride == Cout
         if (s != FS_OK) return s;
     } else {
-        s = fs_bn_bwd_reduce(stream, pixels, C, z, d->y_cs, dy, dy_cs, y, d->y_cs, mean, invstd, d->dtype, relu, red);
+        s = fs_bn_bwd_reduce_ws(stream, pixels, C, 1, z, d->y_cs, dy, dy_cs, y, d->y_cs, mean, invstd, 0, d->dtype, relu, red, workspace,
+                                workspace_bytes);
         if (s != FS_OK) return s;
         s = fs_bn_bwd_apply(stream, pixels, C, z, d->y_cs, dy, dy_cs, y, d->y_cs, mean, invstd, gamma, red, pixels, d->dtype, relu,
                             dz, C, dgamma_acc, dbeta_acc);

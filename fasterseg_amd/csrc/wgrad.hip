@@ -30,7 +30,13 @@ struct WgradArgs {
     int slabs;
 };
 
-constexpr int KC = 32;      // pixels per chunk
+// Pixels staged per iteration.  Every iteration is one dependent global -> LDS -> MFMA round trip (~1 us of load latency that the
+// two MFMAs of a 32-pixel chunk cannot hide): with 128 pixels per chunk (64 in fp32: LDS) the loads of a whole chunk are in flight
+// together and a typical supernet slab (256 pixels) is 2 iterations instead of 8.
+template <typename T> struct Chunk { static constexpr int KC = 64; };
+template <> struct Chunk<bf16_t> { static constexpr int KC = 128; };
+constexpr int KC_MAX = 128;
+constexpr int SLAB_MIN_PIXELS = 256;     // a slab shorter than this is launch overhead
 constexpr int BCH = 64;     // channels per block tile (both operands)
 constexpr int PITCH = BCH + 4;
 constexpr int PITCH16 = BCH + 8;     // bf16 tile: 144-byte rows
@@ -41,6 +47,7 @@ template <> struct Stage<bf16_t> { typedef bf16_t elem; static constexpr int pit
 template <typename T>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
     constexpr int VEC = Elem<T>::VEC;
+    constexpr int KC = Chunk<T>::KC;
     constexpr int VR = BCH / VEC;                 // vectors per staged row
     constexpr int NV = (KC * VR + 255) / 256;     // vectors per thread per operand
     typedef typename Stage<T>::elem LT;
@@ -151,21 +158,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
         const unsigned int tile = blockIdx.z * gridDim.y + blockIdx.y;
         float* mine = p.part + ((long long)tile * p.slabs + blockIdx.x) * (BCH * BCH);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mine[(wave * 16 + r) * 64 + lane] = acc[r];
-        __threadfence();
-        __syncthreads();
-        if (tid == 0) s_last = (atomicAdd(&p.counters[tile], 1u) == (unsigned int)(p.slabs - 1)) ? 1 : 0;
-        __syncthreads();
-        if (!s_last) return;
-        __threadfence();
+        for (int r = 0; r < 16; ++r) store_coherent(mine + (wave * 16 + r) * 64 + lane, acc[r]);
+        if (!arrive_last(&p.counters[tile], (unsigned int)p.slabs, &s_last)) return;
         const float* all = p.part + (long long)tile * p.slabs * (BCH * BCH);
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         for (int sl = 0; sl < p.slabs; ++sl) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] += __builtin_nontemporal_load(all + (long long)sl * (BCH * BCH) + (wave * 16 + r) * 64 + lane);
+            for (int r = 0; r < 16; ++r) acc[r] += load_coherent(all + (long long)sl * (BCH * BCH) + (wave * 16 + r) * 64 + lane);
         }
-        if (tid == 0) p.counters[tile] = 0u;
+        if (tid == 0) __hip_atomic_store(&p.counters[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // D[i = co][j = ci]: col = lane&31 -> ci, row -> co
     const int ci = ci0 + wn * 32 + (lane & 31);
@@ -242,9 +244,11 @@ static fs_status wgrad_impl(void* stream, const fs_conv_desc* d, const void* x, 
     // commonest C3 geometries weighted by their launch counts: 41.9 ms/step; plain stores instead of atomics: 24.6).  ~1k blocks
     // of >= 8 chunks: 34.7 ms; 512 / 4: 35.1; 256 / 8: 42.1; 4096 / 2: 65.5.  FS_WGRAD_BLOCKS / FS_WGRAD_MIN_CHUNKS override.
     static const int target_blocks = [] { const char* e = getenv("FS_WGRAD_BLOCKS"); return e && atoi(e) > 0 ? atoi(e) : 1024; }();
-    static const int min_chunks = [] { const char* e = getenv("FS_WGRAD_MIN_CHUNKS"); return e && atoi(e) > 0 ? atoi(e) : 8; }();
+    static const int min_chunks = [] { const char* e = getenv("FS_WGRAD_MIN_CHUNKS"); return e && atoi(e) > 0 ? atoi(e) : 1; }();
     long long slabs = (target_blocks + other - 1) / other;
-    const long long max_slabs = (M + min_chunks * KC - 1) / (min_chunks * KC);
+    const int KC = d->dtype == FS_F32 ? Chunk<float>::KC : Chunk<bf16_t>::KC;
+    const long long slab_min = (long long)min_chunks * KC > SLAB_MIN_PIXELS ? (long long)min_chunks * KC : SLAB_MIN_PIXELS;
+    const long long max_slabs = (M + slab_min - 1) / slab_min;
     if (slabs > max_slabs) slabs = max_slabs;
     if (slabs < 1) slabs = 1;
     long long slab = (M + slabs - 1) / slabs;

@@ -418,7 +418,8 @@ def channel_stats(x, stats=None):
     x_cs = require_nhwc(x, "x")
     if stats is None:
         stats = zeros_f32(2 * x.shape[1], x.device)
-    call("fs_channel_stats", _stream(), _pix(x), x.shape[1], _p(x), x_cs, dtype_code(x.dtype), _p(stats))
+    ws, ws_bytes = stream_workspace(x.device)       # block partials added up in block order: bit-reproducible, no float atomics
+    call("fs_channel_stats_ws", _stream(), _pix(x), x.shape[1], 1, _p(x), x_cs, dtype_code(x.dtype), _p(stats), ws, ws_bytes)
     return stats
 
 
@@ -430,8 +431,9 @@ def bn_backward(z, dy, y_out, mean, invstd, gamma, relu, dgamma_acc=None, dbeta_
     y_cs = require_nhwc(y_out, "y_out") if relu else 0
     red = zeros_f32(2 * C, z.device)
     dt = dtype_code(z.dtype)
-    call("fs_bn_bwd_reduce", _stream(), _pix(z), C, _p(z), z_cs, _p(dy), dy_cs, _p(y_out) if relu else None, y_cs, _p(mean),
-         _p(invstd), dt, int(relu), _p(red))
+    ws, ws_bytes = stream_workspace(z.device)
+    call("fs_bn_bwd_reduce_ws", _stream(), _pix(z), C, 1, _p(z), z_cs, _p(dy), dy_cs, _p(y_out) if relu else None, y_cs, _p(mean),
+         _p(invstd), 0, dt, int(relu), _p(red), ws, ws_bytes)
     dz = empty_nhwc(z.shape[0], C, z.shape[2], z.shape[3], z.dtype, z.device)
     call("fs_bn_bwd_apply", _stream(), _pix(z), C, _p(z), z_cs, _p(dy), dy_cs, _p(y_out) if relu else None, y_cs, _p(mean),
          _p(invstd), _p(gamma), _p(red), _pix(z), dt, int(relu), _p(dz), channel_stride(dz), _p(dgamma_acc), _p(dbeta_acc))
@@ -452,7 +454,7 @@ def bn_act_train(z, gamma, beta, eps, momentum, running_mean, running_var, num_b
     stats = zeros_f32(groups * 2 * C, z.device) if pixels // groups > BN_COL_MAX_PIXELS else None
     call("fs_bn_act_train_fwd", _stream(), pixels, C, groups, _p(z), z_cs, _p(gamma), _p(beta), float(eps), float(momentum),
          _p(running_mean), _p(running_var), _p(num_batches_tracked), _p(stats), _p(saved), _p(y), channel_stride(y),
-         dtype_code(z.dtype), int(relu))
+         dtype_code(z.dtype), int(relu), *stream_workspace(z.device))
     return y, saved
 
 
@@ -464,7 +466,8 @@ def bn_act_train_bwd(z, dy, y_out, saved, gamma, relu, groups=1, dgamma_acc=None
     red = zeros_f32((groups + 1 if groups > 1 else 1) * 2 * C, z.device)
     dz = empty_nhwc(z.shape[0], C, z.shape[2], z.shape[3], z.dtype, z.device)
     call("fs_bn_act_train_bwd", _stream(), _pix(z), C, groups, _p(z), z_cs, _p(dy), dy_cs, _p(y_out) if relu else None, y_cs,
-         _p(saved), _p(gamma), _p(red), dtype_code(z.dtype), int(relu), _p(dz), channel_stride(dz), _p(dgamma_acc), _p(dbeta_acc))
+         _p(saved), _p(gamma), _p(red), dtype_code(z.dtype), int(relu), _p(dz), channel_stride(dz), _p(dgamma_acc), _p(dbeta_acc),
+         *stream_workspace(z.device))
     return dz, red[C:2 * C], red[:C]
 
 

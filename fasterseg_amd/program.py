@@ -396,7 +396,7 @@ class _Lowering:
         momentum = 0.1 if b.momentum is None else float(b.momentum)
         f.emit(OP_BN_UNIT_FWD, z.pixels, C2, G, z.ref, z.cs, self.param(b.weight), self.param(b.bias), float(b.eps), momentum,
                self.param(b.running_mean), self.param(b.running_var), self.param(b.num_batches_tracked), stats, saved, y.ref, y.cs,
-               self.dt, 1)
+               self.dt, 1, Ref(WS, 0), K.WORKSPACE_BYTES)
 
         def backward(dy, need_x):
             bl = self.b
@@ -404,7 +404,7 @@ class _Lowering:
             dz = self.new(bl, TMPB, x.N, C2, Ho, Wo)
             acc = (absolute(self.grad_slot(b.weight)), absolute(self.grad_slot(b.bias))) if self.want_w else (NULL, NULL)
             bl.emit(OP_BN_UNIT_BWD, z.pixels, C2, G, z.ref, z.cs, dy.ref, dy.cs, y.ref, y.cs, saved, absolute(b.weight), red,
-                    self.dt, 1, dz.ref, dz.cs, acc[0], acc[1])
+                    self.dt, 1, dz.ref, dz.cs, acc[0], acc[1], Ref(WS, 0), K.WORKSPACE_BYTES)
             dx = None
             for k, conv in enumerate((op.conv1, op.conv2)):
                 w = conv.weight

@@ -88,7 +88,7 @@ typedef struct fs_resize_desc {
 const char* fs_last_error(void);
 /* ABI revision of this header; fs_version() returns the one the library was built from.  Bindings check both this and
  * fs_struct_size() when they load the library (fasterseg_amd/_lib.py) - a stale .so must not be used silently. */
-#define FS_ABI_VERSION 204
+#define FS_ABI_VERSION 205
 int fs_version(void);
 int fs_struct_size(int which);   /* 0 fs_conv_desc, 1 fs_resize_desc, 2 fs_zoom_desc, 3 fs_sgd_tensor, 4 fs_logits_desc; -1 otherwise */
 /* test hook: force the tile configuration of fs_conv2d_fwd (0..6; -1 = heuristic).  Not for production use. */
@@ -244,6 +244,16 @@ fs_status fs_bn_bwd_apply(void* stream, long long pixels, int C, const void* x, 
  * [groups][4][C] layout); red: [groups][2][C] zeroed partials; count = pixels per group; red_total (nullable) receives the
  * sum of the partials over the groups ([2][C]: dbeta, dgamma). */
 fs_status fs_channel_stats_g(void* stream, long long pixels, int C, int groups, const void* x, int x_cs, int dtype, float* stats);
+/* The two reductions with a caller workspace (nullable; layout as for fs_conv2d_wgrad_ws: scratch in front, zero arrival counters in
+ * the last FS_WS_COUNTER_BYTES): every block stores its column sums, the block that arrives last adds them up in block order and
+ * stores the totals - bit-reproducible statistics / parameter gradients, no float atomics.  The train units below take the same
+ * workspace and route every map above 512 pixels per group through these (FS_BN_EPILOGUE_STATS=1: ungrouped maps keep the conv
+ * epilogue's atomically accumulated statistics, one launch fewer). */
+fs_status fs_channel_stats_ws(void* stream, long long pixels, int C, int groups, const void* x, int x_cs, int dtype, float* stats,
+                              void* workspace, long long workspace_bytes);
+fs_status fs_bn_bwd_reduce_ws(void* stream, long long pixels, int C, int groups, const void* x, int x_cs, const void* dy, int dy_cs,
+                              const void* y_out, int y_cs, const float* mean, const float* invstd, int saved_stride, int dtype,
+                              int relu, float* red, void* workspace, long long workspace_bytes);
 fs_status fs_bn_train_apply_g(void* stream, long long pixels, int C, int groups, const void* x, int x_cs, const float* stats,
                               const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                               float* running_var, long long* num_batches_tracked, float* saved, void* y, int y_cs, int dtype,
@@ -271,10 +281,11 @@ fs_status fs_bn_bwd_apply_g(void* stream, long long pixels, int C, int groups, c
  *   `workspace` (nullable, see fs_conv2d_fwd_ws) lets the convs of both directions split K across blocks. */
 fs_status fs_bn_act_train_fwd(void* stream, long long pixels, int C, int groups, void* z, int z_cs, const float* gamma,
                               const float* beta, float eps, float momentum, float* running_mean, float* running_var,
-                              long long* num_batches_tracked, float* stats, float* saved, void* y, int y_cs, int dtype, int relu);
+                              long long* num_batches_tracked, float* stats, float* saved, void* y, int y_cs, int dtype, int relu,
+                              void* workspace, long long workspace_bytes);
 fs_status fs_bn_act_train_bwd(void* stream, long long pixels, int C, int groups, const void* z, int z_cs, const void* dy, int dy_cs,
                               const void* y, int y_cs, const float* saved, const float* gamma, float* red, int dtype, int relu,
-                              void* dz, int dz_cs, float* dgamma_acc, float* dbeta_acc);
+                              void* dz, int dz_cs, float* dgamma_acc, float* dbeta_acc, void* workspace, long long workspace_bytes);
 fs_status fs_conv_bn_act_train_fwd(void* stream, const fs_conv_desc* d, const void* x, const void* w_packed,
                                    const float* gamma, const float* beta, float* running_mean, float* running_var,
                                    long long* num_batches_tracked, float eps, float momentum, float* stats, float* saved,

@@ -300,6 +300,57 @@ def gen_nets():
     np.savez_compressed(os.path.join(GOLD, "nets.npz"), **store)
 
 
+# 4b. the student's KL-distillation train step as train/train.py:219-271 runs it: teacher (arch_0, eval) forward, student (arch_1, train,
+#     3 heads) forward, ProbOhemCrossEntropy2d x3 + KLDivLoss, backward - reference modules and criteria in fp64, 2 x 3x256x512 (maps down
+#     to 4x8 x 2 images = 64 samples per BatchNorm channel; the 128x256 fixture above normalises over 4 samples, where bf16 storage
+#     noise is amplified without bound).  Pins the bf16 student step (tests/test_train_parity_gpu.py).
+def gen_student_step():
+    store = {}
+    B, H, W = 2, 256, 512
+    with ref_loader.reference("train") as wd:
+        import model_seg
+        tools = os.path.join(os.path.dirname(wd), "tools")
+        sys.path.insert(0, tools)
+        for m in [k for k in sys.modules if k.split(".")[0] in ("seg_opr", "engine")]:
+            sys.modules.pop(m)
+        from seg_opr.loss_opr import ProbOhemCrossEntropy2d
+        nets = []
+        for idx in (0, 1):
+            state = torch.load(os.path.join(wd, "fasterseg", "arch_%d.pt" % idx), map_location="cpu", weights_only=False)
+            net = build_ref_net(model_seg, state, idx, [2, 1], True)
+            _load_seeded(net, 12345 + idx)
+            nets.append(net.to(torch.float64))
+        teacher, student = nets
+        teacher.eval()
+        student.train()
+        x = seeded_input((B, 3, H, W), 61).to(torch.float64)
+        g = torch.Generator().manual_seed(62)
+        target = torch.randint(0, 19, (B, H, W), generator=g)
+        target[torch.rand(B, H, W, generator=g) < 0.05] = 255
+        crit = ProbOhemCrossEntropy2d(ignore_label=255, thresh=0.7, min_kept=int(B * H * W // 16), use_weight=False)   # train.py:62
+        kl = torch.nn.KLDivLoss()                                                                                         # train.py:64
+        with torch.no_grad():
+            t_logits = teacher(x)
+        p8, p16, p32 = student(x)
+        loss = crit(p8, target.clone()) + 0.2 * crit(p16, target.clone()) + 0.2 * crit(p32, target.clone())
+        loss = loss + kl(torch.nn.functional.softmax(p8, dim=1).log(), torch.nn.functional.softmax(t_logits, dim=1))
+        loss.backward()
+        store["target"] = _np(target).astype(np.uint8)
+        store["loss"] = np.array([float(loss.detach())])
+        store["p8_sub"] = _np(p8[:, :, ::8, ::8]).astype(np.float32)
+        store["teacher_sub"] = _np(t_logits[:, :, ::8, ::8]).astype(np.float32)
+        named = dict(student.named_parameters())
+        norms = {k: float(p.grad.norm()) for k, p in named.items() if p.grad is not None}
+        for k in ("stem.0.conv.0.weight", "cells.3-0._op._op.conv1.weight", "heads8.conv_1x1.weight", "heads8.conv_1x1.bias",
+                  "cells.9-0._op._op.bn2.weight", "refines32.0.conv.0.weight", "ffm.conv_1x1.bn.bias", "heads16.conv_3x3.bn.bias",
+                  "stem.2.bn2.weight", "cells.5-1._op._op.conv1.weight", "heads32.conv_3x3.conv.weight"):
+            _put(store, "g/" + k, named[k].grad.float())
+        with open(os.path.join(GOLD, "student_step_gradnorms.json"), "w") as f:
+            json.dump(norms, f)
+        print("student step loss", float(loss.detach()), "params with grad:", len(norms))
+    np.savez_compressed(os.path.join(GOLD, "student_step.npz"), **store)
+
+
 # ------------------------------------------------------------------------------------------------
 # 5. the shipped latency LUT (key grammar + published per-op numbers)
 # ------------------------------------------------------------------------------------------------
@@ -514,9 +565,9 @@ def gen_eval():
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(max(1, os.cpu_count() or 1))
-    which = sys.argv[1:] or ["arch", "decode", "ops", "nets", "lut", "loss", "supernet", "supernet_l16", "eval"]
+    which = sys.argv[1:] or ["arch", "decode", "ops", "nets", "student_step", "lut", "loss", "supernet", "supernet_l16", "eval"]
     for w in which:
-        {"arch": gen_arch, "decode": gen_decode_cases, "ops": gen_ops, "nets": gen_nets, "lut": gen_lut, "loss": gen_loss, "supernet": gen_supernet, "supernet_l16": gen_supernet_l16, "eval": gen_eval}[w]()
+        {"arch": gen_arch, "decode": gen_decode_cases, "ops": gen_ops, "nets": gen_nets, "lut": gen_lut, "loss": gen_loss, "supernet": gen_supernet, "supernet_l16": gen_supernet_l16, "eval": gen_eval, "student_step": gen_student_step}[w]()
 
 
 if __name__ == "__main__":

@@ -56,7 +56,8 @@ def _run(case, dtype, splits=0, seed=0, unit=False):
     if unit:          # fs_bn_act_train_fwd: chooses the one-launch kernel or the grouped grid-wide passes by the map size
         stats = torch.zeros(G * 2 * C, dtype=torch.float32, device=dev)
         call("fs_bn_act_train_fwd", K._stream(), pixels, C, G, K._p(z), K.channel_stride(z), K._p(gd), K._p(bd), 1e-5, 0.1,
-             K._p(rm_d), K._p(rv_d), K._p(nbt), K._p(stats), K._p(saved), K._p(y), K.channel_stride(y), K.dtype_code(dtype), relu)
+             K._p(rm_d), K._p(rv_d), K._p(nbt), K._p(stats), K._p(saved), K._p(y), K.channel_stride(y), K.dtype_code(dtype), relu,
+             *K.stream_workspace(dev))
     else:
         call("fs_bn_group_fwd", K._stream(), pixels, C, G, K._p(z), K.channel_stride(z), K._p(partials), splits, K._p(gd), K._p(bd), 1e-5, 0.1,
              K._p(rm_d), K._p(rv_d), K._p(nbt), K._p(saved), K._p(y), K.channel_stride(y), K.dtype_code(dtype), relu)
@@ -68,7 +69,7 @@ def _run(case, dtype, splits=0, seed=0, unit=False):
         red = torch.zeros((G + 1 if G > 1 else 1) * 2 * C, dtype=torch.float32, device=dev)
         call("fs_bn_act_train_bwd", K._stream(), pixels, C, G, K._p(z), K.channel_stride(z), K._p(dyg), K.channel_stride(dyg), K._p(y),
              K.channel_stride(y), K._p(saved), K._p(gd), K._p(red), K.dtype_code(dtype), relu, K._p(dz), K.channel_stride(dz), K._p(dgacc),
-             K._p(dbacc))
+             K._p(dbacc), *K.stream_workspace(dev))
     else:
         call("fs_bn_group_bwd", K._stream(), pixels, C, G, K._p(z), K.channel_stride(z), K._p(dyg), K.channel_stride(dyg), K._p(y),
              K.channel_stride(y), K._p(saved), K._p(gd), K.dtype_code(dtype), relu, K._p(dz), K.channel_stride(dz), K._p(red), K._p(dgacc),

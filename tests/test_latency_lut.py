@@ -49,11 +49,38 @@ def test_hip_timer_contract():
     assert 0.002 < ms < 1.0 and 0.002 < ms_eager < 5.0
     assert ms <= ms_eager * 1.05, "device time of the captured forward cannot exceed the dispatch-inclusive eager time"
     assert layer.training, "the timer must restore the module's mode (it switches to eval() for the measurement)"
-    # independent cross-check of the timer: the same two convs through the engine's per-launch event timing
-    import torch as _t
-    from fasterseg_amd import engine
-    layer.eval()
-    del _t, engine
+
+
+LUT_SAMPLE = ["BasicResidual1x_H128_W256_Cin96_Cout96_stride1_dilation1", "BasicResidual_downup_1x_H64_W128_Cin192_Cout192_stride1_dilation1",
+              "BasicResidual2x_H32_W64_Cin384_Cout384_stride1_dilation1", "BasicResidual_downup_2x_H128_W256_Cin64_Cout64_stride1_dilation1",
+              "BasicResidual2x_H64_W128_Cin128_Cout256_stride2_dilation1", "FactorizedReduce_H64_W128_Cin192_Cout384_stride2",
+              "ConvNorm_H1024_W2048_Cin3_Cout48_kernel3_stride2", "ff_H128_W256_C96", "head_H128_W256_Cin96_Cout19"]
+
+
+@pytest.mark.gpu
+def test_shipped_lut_matches_the_current_kernels():
+    """The shipped MI355X table (fasterseg_amd/fasterseg/latency_lookup_table_mi355x_bf16.json, what the C5 search step is regularised
+    with) must describe THIS build: nine keys - every operator class, all three scales, both strides - are re-timed with the
+    generator's own thunks and have to agree with the shipped values within +-30 % (hipEvent timing of ~10-100 us kernels on a
+    shared box; a table from older kernels was off by 2x on the fused-cell shapes)."""
+    from fasterseg_amd import functional as FN
+    from fasterseg_amd import latency, latency_lookup_table
+    import fasterseg_amd.operations as ops
+    import fasterseg_amd.seg_oprs as sops
+    shipped = latency_lookup_table.load_shipped("bf16")
+    thunks = dict(latency_lookup_table.entries())
+    assert set(LUT_SAMPLE) <= set(thunks) and set(thunks) == set(shipped)
+    real = latency.compute_latency_ms_hip
+    saved = (ops.compute_latency, sops.compute_latency)
+    ops.compute_latency = sops.compute_latency = lambda model, size: real(model, size, min_calib_ms=20.0, budget_ms=60.0)
+    FN.set_compute_dtype(torch.bfloat16)
+    try:
+        got = {k: float(thunks[k]()) for k in LUT_SAMPLE}
+    finally:
+        ops.compute_latency, sops.compute_latency = saved
+        FN.set_compute_dtype(torch.float32)
+    off = {k: (got[k], shipped[k]) for k in LUT_SAMPLE if not (0.7 * shipped[k] <= got[k] <= 1.3 * shipped[k])}
+    assert not off, off
 
 
 @pytest.mark.gpu

@@ -102,3 +102,24 @@ def test_oracle_ohem_matches_reference():
         loss.backward()
         assert abs(float(loss.detach()) - float(store["ohem%d/loss" % i][0])) < 1e-6, i
         np.testing.assert_allclose(pred.grad.numpy(), store["ohem%d/grad" % i], atol=1e-6)
+
+
+def test_oracle_student_distill_step_matches_reference():
+    """oracle/ref_ops (teacher eval + student train forward) + oracle/ref_loss.student_step_loss - the checker of bench.py's C4 parity gate
+    and cpu_baseline - against the reference's own fp64 run of train/train.py:246-262 (fixture tests/golden/student_step.npz)."""
+    from oracle import ref_loss
+    store = load_npz("student_step.npz")
+    metas = [load_json("arch_%d.json" % i)["train_21"] for i in (0, 1)]
+    pt = resolve_aliases(seeded_state(shapes_template(metas[0]["state_shapes"]), 12345), metas[0])
+    ps = resolve_aliases(seeded_state(shapes_template(metas[1]["state_shapes"]), 12346), metas[1])
+    pt = {k: v.double() if v.is_floating_point() else v for k, v in pt.items()}
+    ps = {k: v.double() if v.is_floating_point() else v for k, v in ps.items()}
+    x = seeded_input((2, 3, 256, 512), 61).double()
+    target = torch.tensor(store["target"].astype(np.int64))
+    with torch.no_grad():
+        t_logits = ref_ops.derived_forward(pt, metas[0], x, training=False)
+        p8, p16, p32 = ref_ops.derived_forward(ps, metas[1], x, training=True)
+        loss = float(ref_loss.student_step_loss(p8, p16, p32, t_logits, target, min_kept=2 * 256 * 512 // 16))
+    assert_close_golden(t_logits[:, :, ::8, ::8], store, "teacher_sub", 1e-5, 1e-5)
+    assert_close_golden(p8[:, :, ::8, ::8], store, "p8_sub", 1e-5, 1e-5)
+    assert abs(loss - float(store["loss"][0])) <= 1e-7 * float(store["loss"][0]), (loss, float(store["loss"][0]))

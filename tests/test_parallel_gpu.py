@@ -122,3 +122,29 @@ def test_search_step_data_parallel_two_ranks_one_gpu(tmp_path):
         assert torch.equal(r0[k], r1[k]), "replicas diverged: " + k
         checked += 1
     assert checked > 1000 and any(k.startswith("alpha_") for k in r0)
+
+
+def test_bench_two_ranks_over_gloo_runs_the_collective_path(tmp_path):
+    """`python bench.py --gpus 2` as the driver launches it (self-spawned torch.distributed.run, one rank per process), with both ranks
+    on this box's one GPU over gloo (RCCL refuses two ranks on a device): the data-parallel train path, the parity gate and the timed
+    census (every rank must issue the census step - it contains the gradient all-reduce) all run; the line says what it is."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FS_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workloads", "c4", "--steps", "50", "--warmup", "5", "--train-steps", "2",
+           "--train-warmup", "1", "--min-seconds", "0.05", "--no-cpu-baseline", "--no-class-map", "--no-fp32-leg"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, "exactly one JSON line (rank 0)"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    c4 = d["workloads"]["C4_student_train"]
+    assert c4["global_batch"] == 24 and c4["parity"]["pass"]
+    assert "functional test only" in c4["config"]["parallelism"] and "gloo" in c4["config"]["parallelism"]
+    assert c4["roofline"]["flops_coverage"] == 1.0 and c4["roofline"]["frac"] > 0

@@ -11,8 +11,8 @@ from fasterseg_amd.parallel import FlatGradientSync
 NARGS = {program.OP_MEMSET: 2, program.OP_PACK_WEIGHT: 10, program.OP_CONV_FWD: 9, program.OP_UNIT_FWD: 16, program.OP_UNIT_BWD: 23,
          program.OP_WGRAD_STRIDED: 9, program.OP_CHANNEL_STATS: 6, program.OP_BN_FINALIZE: 14, program.OP_AFFINE_ACT: 10,
          program.OP_BN_BWD_REDUCE: 13, program.OP_BN_BWD_APPLY: 19, program.OP_BILINEAR_FWD: 3, program.OP_BILINEAR_BWD: 4,
-         program.OP_WSUM: 9, program.OP_WSUM_BWD: 9, program.OP_WSUM_DOTS: 9, program.OP_AXPY: 9, program.OP_BN_UNIT_FWD: 18,
-         program.OP_BN_UNIT_BWD: 18}
+         program.OP_WSUM: 9, program.OP_WSUM_BWD: 9, program.OP_WSUM_DOTS: 9, program.OP_AXPY: 9, program.OP_BN_UNIT_FWD: 20,
+         program.OP_BN_UNIT_BWD: 20}
 WIDTHS = [4. / 12, 6. / 12, 8. / 12, 10. / 12, 1.]
 
 

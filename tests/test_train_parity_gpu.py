@@ -5,7 +5,9 @@
   UNMODIFIED reference produced in fp64 (tests/golden/supernet_l16*, oracle/make_golden.py gen_supernet_l16) - through the bare
   modules (fp32) and through train_step.SupernetStep exactly as bench.py builds it (hipGraph replay of the fixed-width passes,
   MixedOp launch programs, pair batching, flat-gradient sink), fp32 AND bf16.
-* the student's train step (3 heads) in bf16 against the reference's fp64 fixture (tests/golden/nets.npz arch1_train64).
+* the student's KL-distillation step (train/train.py:246-262: frozen teacher, 3 student heads, OHEM-CE + KLDiv) through
+  train_step.StudentDistillStep as bench.py builds it, fp32 AND bf16, against the reference's fp64 run at 2x3x256x512
+  (tests/golden/student_step*, oracle/make_golden.py gen_student_step).
 
 Bars.  fp32 (exact-fp32 MFMA, fp32 storage): loss 2e-3 relative, gradient norms 5e-2 (batch-statistics BN on maps of a few
 dozen pixels: a last-bit change of a mean can flip a ReLU-mask element).  bf16 (bf16 storage of every activation, bf16 MFMA
@@ -146,6 +148,7 @@ def test_l16_supernet_step_as_benchmarked(mode, dtype):
     from fasterseg_amd.train_step import SupernetStep
     st = SupernetStep(pretrain=(mode == "pretrain"), cfg=_FrozenLR, compute_dtype=dtype)
     st.architect = None                                   # the fixture is `_loss` of the weight step (train_search.py:246-250)
+    st._prewarmed = True                                  # (the program prewarm after a first step re-arms the gradient buffer)
     st.model.load_state_dict({k: v.cuda() for k, v in _l16_state(st.model).items()})
     st.optimizer.refresh_packs()
     x, target = _batch(mode)
@@ -166,6 +169,7 @@ def test_l16_supernet_step_is_reproducible_in_loss():
     out = []
     for _ in range(2):
         st = SupernetStep(pretrain=True, cfg=_FrozenLR, compute_dtype=torch.bfloat16)
+        st._prewarmed = True
         st.model.load_state_dict({k: v.cuda() for k, v in _l16_state(st.model).items()})
         st.optimizer.refresh_packs()
         x, target = _batch("pretrain")
@@ -177,43 +181,42 @@ def test_l16_supernet_step_is_reproducible_in_loss():
     assert abs(out[0] - out[1]) <= 1e-3 * abs(out[0]), out
 
 
-def test_student_train_step_bf16_vs_fp64_fixture():
-    """The student's train-mode forward + backward (3 heads) with bf16 compute against the reference's fp64 run of the same step
-    (fixture arch1_train64) - the arithmetic bench.py's C4 workload runs."""
-    from fasterseg_amd import functional as FN
-    from tests.test_ops_gpu import build_net
-    store = load_npz("nets.npz")
-    net = build_net(1, [2, 1], True)
-    x = seeded_input((2, 3, 128, 256), 6).cuda().requires_grad_(True)
-    FN.set_compute_dtype(torch.bfloat16)
-    try:
-        p8, p16, p32 = net(x)
-        loss = (p8 * seeded_input(tuple(p8.shape), 7).cuda()).sum() + 0.2 * (p16 * seeded_input(tuple(p16.shape), 8).cuda()).sum() \
-            + 0.2 * (p32 * seeded_input(tuple(p32.shape), 9).cuda()).sum()
-        loss.backward()
-    finally:
-        FN.set_compute_dtype(torch.float32)
-    metrics = {}
-    for name, p in (("p8", p8), ("p16", p16), ("p32", p32)):
-        want, _ = golden_get(store, "arch1_train64/%s_sub" % name)
-        got = p[:, :, ::4, ::4].detach().float().cpu().numpy()
-        metrics[name + "_rel_to_max"] = float(np.abs(got - want).max() / np.abs(want).max())
-        metrics[name + "_rel_l2"] = float(np.sqrt(((got - want) ** 2).sum() / (want ** 2).sum()))
-    params = dict(net.named_parameters())
-    norms = load_json("arch1_train64_gradnorms.json")
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_student_distill_step_as_benchmarked(dtype):
+    """train_step.StudentDistillStep as bench.py's C4 runs it (frozen teacher through the engine, student train forward with three
+    heads, OHEM-CE + KLDiv evaluated from the low-resolution logits, flat-gradient sink, compute dtype) on the fixture's weights and
+    batch, 2 x 3x256x512: loss and gradients against the reference's fp64 run of train/train.py:246-262 (tests/golden/student_step*).
+    (The 128x256 fixture of test_ops_gpu normalises 4 samples per channel in its coarsest maps: fine for fp32, meaningless for bf16.)"""
+    from fasterseg_amd.engine import InferenceEngine
+    from fasterseg_amd.train_step import StudentDistillStep
+    store = load_npz("student_step.npz")
+    norms = load_json("student_step_gradnorms.json")
+    bf16 = dtype == torch.bfloat16
+    B, H, W = 2, 256, 512
+    st = StudentDistillStep(B, H, W, lr=0.0, teacher_engine_dtype=None, compute_dtype=dtype)
+    st.teacher.load_state_dict({k: v.cuda() for k, v in seeded_state(st.teacher.state_dict(), 12345).items()})
+    st.student.load_state_dict({k: v.cuda() for k, v in seeded_state(st.student.state_dict(), 12346).items()})
+    st.optimizer.refresh_packs()
+    st.teacher_engine = InferenceEngine(st.teacher, (B, 3, H, W), dtype=dtype, output="lowres" if st.fused_loss else "logits")
+    x = seeded_input((B, 3, H, W), 61).cuda()
+    target = torch.tensor(store["target"].astype(np.int64)).cuda()
+    loss = float(st.step(x, target))
+    torch.cuda.synchronize()
+    want = float(store["loss"][0])
+    params = dict(st.student.named_parameters())
     assert set(norms) == {k for k, p in params.items() if p.grad is not None}, "same set of parameters receives gradients"
-    errs = {k: abs(float(params[k].grad.norm()) - w) / (w + 1e-12) for k, w in norms.items()}
-    metrics["worst_norm_err"] = max(errs.values())
-    metrics["norms_missed"] = sum(1 for e in errs.values() if e > 0.15)
-    cos_min, rel_max = 1.0, 0.0
+    errs = {k: abs(float(params[k].grad.float().norm()) - w) / (w + 1e-12) for k, w in norms.items()}
+    cos_min, rel_max, per = 1.0, 0.0, {}
     for key in store:
-        if key.startswith("arch1_train64/g/"):
-            pname = key[len("arch1_train64/g/"):].split("@")[0]
-            cos, rel = _cos_rel(params[pname].grad, store, "arch1_train64/g/" + pname)
+        if key.startswith("g/"):
+            pname = key[2:].split("@")[0]
+            cos, rel = _cos_rel(params[pname].grad, store, "g/" + pname)
+            per[pname] = (round(cos, 5), round(rel, 5))
             cos_min, rel_max = min(cos_min, cos), max(rel_max, rel)
-    cos, rel = _cos_rel(x.grad, store, "arch1_train64/gx")
-    metrics.update(cos_min=min(cos_min, cos), rel_l2_max=max(rel_max, rel), gx_rel_l2=rel)
-    _record("student_train_bf16", metrics)
-    assert all(metrics[n + "_rel_l2"] <= 3e-2 for n in ("p8", "p16", "p32")), metrics
-    assert metrics["norms_missed"] <= len(norms) // 50, sorted(errs.items(), key=lambda kv: -kv[1])[:8]
-    assert metrics["cos_min"] >= 0.99 and metrics["rel_l2_max"] <= 0.15, metrics
+    bar = 0.15 if bf16 else 3e-2
+    missed = sorted(((e, k) for k, e in errs.items() if e > bar), reverse=True)
+    _record("student_step_" + ("bf16" if bf16 else "fp32"), dict(loss=loss, want=want, loss_rel=abs(loss - want) / want, worst_norm_err=max(errs.values()),
+                                                              norms_missed=len(missed), cos_min=cos_min, rel_l2_max=rel_max, per_tensor=per))
+    assert abs(loss - want) <= (2e-2 if bf16 else 2e-3) * want, (loss, want)
+    assert len(missed) <= (len(norms) // 50 if bf16 else 0), missed[:8]
+    assert cos_min >= (0.99 if bf16 else 0.999) and rel_max <= bar, per
