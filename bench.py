@@ -285,12 +285,20 @@ def _train_line(args, world, backend, name, batch, elapsed, steps, warmup, extra
     ips = world * batch * steps / elapsed
     line = {"value": round(ips, 4), "unit": "images/s", "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3),
             "dtype": args.dtype, "precision": PRECISION[args.dtype], "per_gpu_batch": batch, "global_batch": world * batch,
-            "config": {"workload": name, "parallelism": parallelism(world, backend, "flat fp32 gradient buckets all-reduced before clip / SGD")}}
+            "config": {"workload": name, "parallelism": parallelism(world, backend, "flat fp32 gradient buckets all-reduced before clip / SGD")},
+            "gradient_fidelity": GRADIENT_FIDELITY[args.dtype]}
     line.update(extra)
     return line
 
 
-PARITY_BARS = {"bf16": 2e-2, "fp32": 2e-3}      # relative error of the first step's loss vs the CPU oracle (tests/test_train_parity_gpu.py)
+# what tests/test_train_parity_gpu.py measures for the step objects below against the reference's fp64 run (fixtures at the
+# benchmarked depth / map size; tiny-batch BatchNorm amplifies a rounding of 1e-7 to 1e-2 in deep-layer gradients)
+GRADIENT_FIDELITY = {
+    "fp32": "loss exact to 7 digits; per-tensor gradient relative L2 <= 2e-2 vs the reference's fp64 run (= the reference's own fp32-vs-fp64 gap)",
+    "bf16": "loss within 1e-3 of the reference's fp64 run, same parameters receive gradients; gradients next to the heads cosine >= 0.99, deep "
+            "layers 0.5-0.9 (bf16 storage rounding x the ~1e5 amplification of tiny-batch BatchNorm): throughput mode - the fp32 leg "
+            "(ms_per_step_fp32) is the reference's arithmetic"}
+PARITY_BARS = {"bf16": 1e-2, "fp32": 2e-3}      # relative error of the first step's loss vs the CPU oracle (tests/test_train_parity_gpu.py)
 
 
 def _parity(what, got, want, dtype_name, extra=None):

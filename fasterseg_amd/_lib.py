@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfasterseg_hip.so")
 
-EXPECTED_ABI = 205          # FS_ABI_VERSION of include/fasterseg_hip.h these bindings were written against
+EXPECTED_ABI = 206          # FS_ABI_VERSION of include/fasterseg_hip.h these bindings were written against
 FS_F32, FS_BF16 = 0, 1
 FS_CONV_RELU, FS_CONV_TRANSPOSED, FS_CONV_ACCUM, FS_CONV_RELU_TAIL = 1, 2, 4, 8
 
@@ -127,6 +127,8 @@ _SPECIAL = {
     "fs_loss_up_workspace_bytes": ([ctypes.POINTER(LogitsDesc)], c_ll),
     "fs_zoom_cell_supported": ([ctypes.POINTER(ZoomDesc)], c_int),
     "fs_workspace_counter_bytes": ([], c_ll),
+    "fs_set_deterministic": ([c_int], None),
+    "fs_get_deterministic": ([], c_int),
     "fs_census_enable": ([c_int], None),
     "fs_census_read": ([c_vp, c_int], c_int),
     "fs_census_read_kernels": ([c_vp, c_int], c_int),

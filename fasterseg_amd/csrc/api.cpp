@@ -1,6 +1,7 @@
 // Error channel + version of libfasterseg_hip (host only).
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include "../../include/fasterseg_hip.h"
 
@@ -14,6 +15,12 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace fs
 
+namespace fs {
+int g_deterministic = [] { const char* e = getenv("FS_DETERMINISTIC"); return (e && atoi(e) > 0) ? 1 : 0; }();
+}  // namespace fs
+
+extern "C" void fs_set_deterministic(int on) { fs::g_deterministic = on ? 1 : 0; }
+extern "C" int fs_get_deterministic(void) { return fs::g_deterministic; }
 extern "C" const char* fs_last_error(void) { return fs::g_err; }
 extern "C" int fs_version(void) { return FS_ABI_VERSION; }
 /* sizeof of the descriptor structs this library was compiled with (0: conv, 1: resize, 2: zoom, 3: sgd tensor): a binding whose

@@ -34,6 +34,11 @@ inline fs_status check_launch(const char* what) {
     return FS_OK;
 }
 
+// Bit-reproducible mode (api.cpp; FS_DETERMINISTIC=1 or fs_set_deterministic): cross-block reductions (wgrad pixel slabs, BatchNorm
+// statistics / parameter gradients of maps above 512 pixels) go through ordered partial sums in the caller's workspace instead of
+// float atomics.  Off by default: on MI355X the ordered form costs 2x on those kernels (per-XCD L2: the partials travel through HBM).
+extern int g_deterministic;
+
 // launch census (census.hip).  g_census_on: 0 off, 1 count conv launches by geometry, 2 count AND time every kernel launch:
 // FS_LAUNCH then goes through hipExtLaunchKernelGGL with a start/stop event pair, i.e. the dispatch's own begin/end timestamps
 // (what rocprofv3's kernel trace reports), on the stream the kernel is launched on.

@@ -19,6 +19,7 @@
 //
 // Replaces: nn.Conv2d/F.conv2d at reference search/operations.py:78,149-152,221-224,298-306,380-388,
 // 461-473, slimmable_ops.py:47, seg_oprs.py:22,245 (+BatchNorm2d/ReLU that follow them).
+#include <type_traits>
 #include "common.h"
 
 namespace fs {
@@ -148,13 +149,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
     for (int j = 0; j < B_SUBS; ++j) bk[j] = k_lo + (b_grp + B_GROUPS * j) * BK64 + lvec * VEC;
 
-    u32x4 a_reg[A_PASS][A_SUBS], b_reg[B_PASS][B_SUBS];
+    // Register stages of the global -> LDS pipeline.  The small-tile configurations (in-block K split) run on launch-latency-sized
+    // layers whose K loop is a handful of iterations, each one exposed global-load latency (the 8 MFMAs of an iteration hide none of
+    // it): they keep the loads of TWO iterations in flight.  The large-tile and virtual-resize configurations stay single-stage
+    // (register budget).
+    constexpr int STAGES = (WAVES_K > 1 && !VRES) ? 2 : 1;
+    u32x4 a_reg[STAGES][A_PASS][A_SUBS], b_reg[STAGES][B_PASS][B_SUBS];
     // VRES: the three other bilinear taps of every A vector and the two interpolation fractions (zero-sized otherwise)
     constexpr int VR = VRES ? 1 : 0;
     u32x4 a_t01[A_PASS * VR + 1][A_SUBS], a_t10[A_PASS * VR + 1][A_SUBS], a_t11[A_PASS * VR + 1][A_SUBS];
     float a_lh[A_PASS * VR + 1][A_SUBS], a_lw[A_PASS * VR + 1][A_SUBS];
-    uint32_t a_keep[A_PASS][A_SUBS], b_keep[B_PASS][B_SUBS];   // zero-masks, applied when the data is consumed (store_chunk)
-    auto load_chunk = [&]() {
+    uint32_t a_keep[STAGES][A_PASS][A_SUBS], b_keep[STAGES][B_PASS][B_SUBS];   // zero-masks, applied when the data is consumed (store_chunk)
+    auto load_chunk = [&](auto stage_tag) {
+        constexpr int SG = decltype(stage_tag)::value;
 #pragma unroll
         for (int j = 0; j < A_SUBS; ++j) {
             const int k = ak[j];
@@ -171,14 +178,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
                 ih >>= tshift;
                 iw >>= tshift;
                 ok = ok && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
-                a_keep[ps][j] = ok ? 0xffffffffu : 0u;
+                a_keep[SG][ps][j] = ok ? 0xffffffffu : 0u;
                 if constexpr (VRES) {
                     // (ih, iw) address the RESAMPLED map; fetch the four source pixels it interpolates (resize.hip arithmetic)
                     const Tap th = make_tap(p.vr_rh, ok ? ih : 0, p.vr_H), tw = make_tap(p.vr_rw, ok ? iw : 0, p.vr_W);
                     const long long r0 = (a_base[ps] + (long long)th.i0 * p.vr_W) * p.x_cs + kc;
                     const long long r1 = (a_base[ps] + (long long)th.i1 * p.vr_W) * p.x_cs + kc;
                     const long long c0 = (long long)tw.i0 * p.x_cs, c1 = (long long)tw.i1 * p.x_cs;
-                    a_reg[ps][j] = ldg16(p.x + (r0 + c0) * (long long)sizeof(T));
+                    a_reg[SG][ps][j] = ldg16(p.x + (r0 + c0) * (long long)sizeof(T));
                     a_t01[ps][j] = ldg16(p.x + (r0 + c1) * (long long)sizeof(T));
                     a_t10[ps][j] = ldg16(p.x + (r1 + c0) * (long long)sizeof(T));
                     a_t11[ps][j] = ldg16(p.x + (r1 + c1) * (long long)sizeof(T));
@@ -189,7 +196,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
                     // all gathers of an iteration are in flight together
                     const long long pix = a_base[ps] + (long long)ih * p.W + iw;
                     const long long off = ok ? (pix * p.x_cs + kc) * (long long)sizeof(T) : 0ll;
-                    a_reg[ps][j] = ldg16(p.x + off);
+                    a_reg[SG][ps][j] = ldg16(p.x + off);
                 }
             }
             ak[j] = k + BKT;
@@ -204,19 +211,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
             for (int ps = 0; ps < B_PASS; ++ps) {
                 const bool ok = kvalid && b_ok[ps];
-                b_keep[ps][j] = ok ? 0xffffffffu : 0u;
-                b_reg[ps][j] = ldg16(ok ? b_ptr[ps] + koff * (long long)sizeof(T) : p.w);
+                b_keep[SG][ps][j] = ok ? 0xffffffffu : 0u;
+                b_reg[SG][ps][j] = ldg16(ok ? b_ptr[ps] + koff * (long long)sizeof(T) : p.w);
             }
             bk[j] += BKT;
         }
     };
-    auto store_chunk = [&]() {
+    auto store_chunk = [&](auto stage_tag) {
+        constexpr int SG = decltype(stage_tag)::value;
 #pragma unroll
         for (int ps = 0; ps < A_PASS; ++ps)
 #pragma unroll
             for (int j = 0; j < A_SUBS; ++j)
             {
-                u32x4 v = a_reg[ps][j];
+                u32x4 v = a_reg[SG][ps][j];
                 if constexpr (VRES) {
                     constexpr int VEC_ = Elem<T>::VEC;
                     float p00[VEC_], p01[VEC_], p10[VEC_], p11[VEC_];
@@ -232,7 +240,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
                     }
                     v = Elem<T>::pack(p00);
                 }
-                const uint32_t keep = a_keep[ps][j];
+                const uint32_t keep = a_keep[SG][ps][j];
                 v[0] &= keep; v[1] &= keep; v[2] &= keep; v[3] &= keep;
                 *reinterpret_cast<u32x4*>(sA + (ps * A_RPP + a_row) * PITCH + (a_grp + A_GROUPS * j) * 64 + lvec * 16) = v;
             }
@@ -241,8 +249,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
             for (int j = 0; j < B_SUBS; ++j)
             {
-                u32x4 v = b_reg[ps][j];
-                const uint32_t keep = b_keep[ps][j];
+                u32x4 v = b_reg[SG][ps][j];
+                const uint32_t keep = b_keep[SG][ps][j];
                 v[0] &= keep; v[1] &= keep; v[2] &= keep; v[3] &= keep;
                 *reinterpret_cast<u32x4*>(sB + (ps * B_RPP + b_row) * PITCH + (b_grp + B_GROUPS * j) * 64 + lvec * 16) = v;
             }
@@ -270,11 +278,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     const unsigned char* fragA = sA + (wm * WM_T * 32 + (lane & 31)) * PITCH + wk * KSUB * 64 + (lane >> 5) * 16;
     const unsigned char* fragB = sB + (wn * WN_T * 32 + (lane & 31)) * PITCH + wk * KSUB * 64 + (lane >> 5) * 16;
 
-    load_chunk();
-    for (int t = 0; t < niter; ++t) {
-        store_chunk();
-        __syncthreads();
-        if (t + 1 < niter) load_chunk();
+    auto mma_chunk = [&]() {
 #pragma unroll
         for (int kk = 0; kk < 2 * KSUB; ++kk) {
             u32x4 af[WM_T], bfr[WN_T];
@@ -287,7 +291,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
                 for (int j = 0; j < WN_T; ++j) Mma<T>::run(af[i], bfr[j], acc[i][j]);
         }
+    };
+    typedef std::integral_constant<int, 0> Stage0;
+    typedef std::integral_constant<int, STAGES - 1> Stage1;
+    load_chunk(Stage0{});
+    if (STAGES == 2 && niter > 1) load_chunk(Stage1{});
+    for (int t = 0; t < niter; t += STAGES) {
+        store_chunk(Stage0{});
         __syncthreads();
+        if (t + STAGES < niter) load_chunk(Stage0{});        // the stage just drained takes the chunk STAGES iterations ahead
+        mma_chunk();
+        __syncthreads();
+        if (STAGES == 2 && t + 1 < niter) {
+            store_chunk(Stage1{});
+            __syncthreads();
+            if (t + 3 < niter) load_chunk(Stage1{});
+            mma_chunk();
+            __syncthreads();
+        }
     }
 
     // ---- in-block split-K reduction ------------------------------------------------------------------

@@ -618,9 +618,8 @@ static int reduce_blocks(long long pixels, int rpb, long long* ppb) {
 // (zero before the first use, left zero).  Returns false (-> float atomics) when there is no room; `blocks` may be lowered to fit.
 static bool reduce_ws(void* workspace, long long workspace_bytes, int groups, int C, long long mg, int rpb, int* blocks, long long* ppb,
                       float** part, unsigned int** counters) {
-    static const bool force_atomics = [] { const char* e = getenv("FS_BN_ATOMICS"); return e && atoi(e) > 0; }();
     *part = nullptr; *counters = nullptr;
-    if (!workspace || force_atomics || !aligned16(workspace) || workspace_bytes <= FS_WS_COUNTER_BYTES) return false;
+    if (!workspace || !g_deterministic || !aligned16(workspace) || workspace_bytes <= FS_WS_COUNTER_BYTES) return false;
     if ((long long)groups * (long long)sizeof(unsigned int) > FS_WS_COUNTER_BYTES) return false;
     const long long room = (workspace_bytes - FS_WS_COUNTER_BYTES) / ((long long)sizeof(float) * 2 * C * groups);
     if (room < 1) return false;

@@ -83,10 +83,8 @@ extern "C" fs_status fs_conv_bn_act_train_fwd(void* stream, const fs_conv_desc* 
                                unit_relu(d, true));
     }
     // The conv epilogue's fused statistics are float atomics (run-to-run differences in the last bits of a mean) and per launch, not per
-    // group: with a workspace the statistics come from the deterministic reduction pass instead - one launch more.
-    // FS_BN_EPILOGUE_STATS=1 keeps the epilogue statistics for ungrouped maps.
-    static const bool epilogue_stats = [] { const char* e = getenv("FS_BN_EPILOGUE_STATS"); return e && atoi(e) > 0; }();
-    if (groups > 1 || (workspace && !epilogue_stats)) {
+    // group: grouped maps, and every map in bit-reproducible mode, take the separate reduction pass instead - one launch more.
+    if (groups > 1 || (workspace && fs::g_deterministic)) {
         fs_status s = fs_conv2d_fwd_ws(stream, &c, x, w_packed, nullptr, nullptr, z, nullptr, workspace, workspace_bytes);
         if (s != FS_OK) return s;
         return fs_bn_act_train_fwd(stream, count, C, groups, z, d->y_cs, gamma, beta, eps, momentum, running_mean, running_var,

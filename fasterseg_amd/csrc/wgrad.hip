@@ -35,7 +35,6 @@ struct WgradArgs {
 // together and a typical supernet slab (256 pixels) is 2 iterations instead of 8.
 template <typename T> struct Chunk { static constexpr int KC = 64; };
 template <> struct Chunk<bf16_t> { static constexpr int KC = 128; };
-constexpr int KC_MAX = 128;
 constexpr int SLAB_MIN_PIXELS = 256;     // a slab shorter than this is launch overhead
 constexpr int BCH = 64;     // channels per block tile (both operands)
 constexpr int PITCH = BCH + 4;
@@ -253,11 +252,10 @@ static fs_status wgrad_impl(void* stream, const fs_conv_desc* d, const void* x, 
     if (slabs < 1) slabs = 1;
     long long slab = (M + slabs - 1) / slabs;
     slab = (slab + KC - 1) / KC * KC;
-    // deterministic slab reduction through the caller's workspace (partials in front, the zero-initialised arrival counters in its
-    // last FS_WS_COUNTER_BYTES); FS_WGRAD_ATOMICS=1, no workspace or too many tiles: fp32 atomics
-    static const bool force_atomics = [] { const char* e = getenv("FS_WGRAD_ATOMICS"); return e && atoi(e) > 0; }();
+    // bit-reproducible mode (fs_set_deterministic): slab reduction through the caller's workspace (partials in front, the
+    // zero-initialised arrival counters in its last FS_WS_COUNTER_BYTES); otherwise, or without room: fp32 atomics
     a.part = nullptr; a.counters = nullptr; a.slabs = 1;
-    if (workspace && !force_atomics && aligned16(workspace) && workspace_bytes > FS_WS_COUNTER_BYTES &&
+    if (workspace && g_deterministic && aligned16(workspace) && workspace_bytes > FS_WS_COUNTER_BYTES &&
         other * (long long)sizeof(unsigned int) <= FS_WS_COUNTER_BYTES) {
         const long long room = (workspace_bytes - FS_WS_COUNTER_BYTES) / ((long long)BCH * BCH * sizeof(float));   // partial tiles that fit
         long long fit = room / other;

@@ -542,3 +542,21 @@ def cat_channels(tensors):
         copy_channels(t, out[:, off:off + t.shape[1]])
         off += t.shape[1]
     return out
+
+
+class deterministic:
+    """with deterministic(): ...  -  bit-reproducible mode of the library for the duration (fs_set_deterministic): ordered partial sums
+    instead of float atomics in the weight-gradient slabs and the BatchNorm reductions of large maps (slower, see the header)."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        from . import _lib
+        self.prev = _lib.lib().fs_get_deterministic()
+        _lib.lib().fs_set_deterministic(int(self.on))
+        return self
+
+    def __exit__(self, *exc):
+        from . import _lib
+        _lib.lib().fs_set_deterministic(self.prev)

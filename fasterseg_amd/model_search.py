@@ -130,7 +130,7 @@ def _eval(op, x, alpha, ratios, groups):
 # the host needs ~2 us to issue one: the MixedOps of a layer only depend on the previous layer, so their programs are issued
 # round-robin on a few side streams (fork after the previous layer, join before the beta merges) and autograd replays the same
 # fork / join in backward (a node's backward runs on the stream of its forward).  FS_EAGER_LANES=1 keeps one stream.
-_EAGER_LANES = int(os.environ.get("FS_EAGER_LANES", "6"))
+_EAGER_LANES = int(os.environ.get("FS_EAGER_LANES", "4"))     # measured on C3: 1 lane 130.6 ms, 4: 120.0, 6: 122.1, 10: 134.2
 
 
 def _run_tasks(tasks):

@@ -88,8 +88,15 @@ typedef struct fs_resize_desc {
 const char* fs_last_error(void);
 /* ABI revision of this header; fs_version() returns the one the library was built from.  Bindings check both this and
  * fs_struct_size() when they load the library (fasterseg_amd/_lib.py) - a stale .so must not be used silently. */
-#define FS_ABI_VERSION 205
+#define FS_ABI_VERSION 206
 int fs_version(void);
+/* Bit-reproducible mode (default off; FS_DETERMINISTIC=1 in the environment turns it on at load): every cross-block reduction that
+ * otherwise uses float atomics - the pixel slabs of fs_conv2d_wgrad_ws, BatchNorm statistics and parameter gradients of maps above
+ * 512 pixels per group (fs_channel_stats_ws / fs_bn_bwd_reduce_ws and the train units) - is summed in a fixed order through the
+ * caller's workspace: two runs of a train step give the same bits.  Costs about 2x on those kernels on MI355X (one L2 per XCD: the
+ * partial sums travel through HBM), 25-30 % of a supernet step. */
+void fs_set_deterministic(int on);
+int fs_get_deterministic(void);
 int fs_struct_size(int which);   /* 0 fs_conv_desc, 1 fs_resize_desc, 2 fs_zoom_desc, 3 fs_sgd_tensor, 4 fs_logits_desc; -1 otherwise */
 /* test hook: force the tile configuration of fs_conv2d_fwd (0..6; -1 = heuristic).  Not for production use. */
 void fs_debug_force_conv_cfg(int cfg);
@@ -165,7 +172,8 @@ fs_status fs_conv2d_wgrad(void* stream, const fs_conv_desc* d, const void* x, co
 fs_status fs_conv2d_wgrad_strided(void* stream, const fs_conv_desc* d, const void* x, const void* dy, float* dw,
                                   long long o_stride, long long i_stride, long long t_stride);
 /* The same with a caller workspace: the partial sums of the pixel slabs are stored there and added up in slab order by the block
- * that arrives last (integer arrival counters), i.e. the result is bit-reproducible and no fp32 atomics are issued.  The LAST
+ * that arrives last (integer arrival counters) when the bit-reproducible mode is on (fs_set_deterministic), i.e. the result is
+ * bit-reproducible and no fp32 atomics are issued; with the mode off the workspace is ignored (atomics).  The LAST
  * FS_WS_COUNTER_BYTES of the workspace hold the counters: zero before the first call, left zero by every call; launches sharing
  * a workspace (or a gradient tensor) must be ordered (same stream).  workspace == NULL: the atomics of the entry points above. */
 #define FS_WS_COUNTER_BYTES 65536
@@ -246,9 +254,8 @@ fs_status fs_bn_bwd_apply(void* stream, long long pixels, int C, const void* x, 
 fs_status fs_channel_stats_g(void* stream, long long pixels, int C, int groups, const void* x, int x_cs, int dtype, float* stats);
 /* The two reductions with a caller workspace (nullable; layout as for fs_conv2d_wgrad_ws: scratch in front, zero arrival counters in
  * the last FS_WS_COUNTER_BYTES): every block stores its column sums, the block that arrives last adds them up in block order and
- * stores the totals - bit-reproducible statistics / parameter gradients, no float atomics.  The train units below take the same
- * workspace and route every map above 512 pixels per group through these (FS_BN_EPILOGUE_STATS=1: ungrouped maps keep the conv
- * epilogue's atomically accumulated statistics, one launch fewer). */
+ * stores the totals - bit-reproducible statistics / parameter gradients, no float atomics - when the bit-reproducible mode is on
+ * (fs_set_deterministic); otherwise, or with a NULL workspace, float atomics.  The train units below take the same workspace. */
 fs_status fs_channel_stats_ws(void* stream, long long pixels, int C, int groups, const void* x, int x_cs, int dtype, float* stats,
                               void* workspace, long long workspace_bytes);
 fs_status fs_bn_bwd_reduce_ws(void* stream, long long pixels, int C, int groups, const void* x, int x_cs, const void* dy, int dy_cs,

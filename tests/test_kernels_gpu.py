@@ -234,8 +234,8 @@ def test_conv2d_dgrad_and_wgrad(case, dtype):
 @pytest.mark.parametrize("case", [(3, 96, 32, 64, 96, 3, 1, 1), (6, 384, 8, 16, 384, 3, 1, 1), (3, 192, 16, 32, 384, 3, 2, 1),
                                   (2, 64, 64, 128, 64, 3, 1, 1), (3, 96, 32, 64, 48, 1, 2, -1)], ids=str)
 def test_wgrad_slab_reduction_is_deterministic_and_matches_atomics(case, dtype):
-    """fs_conv2d_wgrad_ws (partial tiles in the workspace, summed in slab order by the last-arriving block) on the supernet's
-    geometries: bit-identical from run to run, accumulates onto what the gradient tensor already holds, equals the fp32-atomics
+    """fs_conv2d_wgrad_ws in bit-reproducible mode (partial tiles in the workspace, summed in slab order by the last-arriving block) on
+    the supernet's geometries: bit-identical from run to run, accumulates onto what the gradient tensor already holds, equals the fp32-atomics
     entry point up to summation order, and leaves the workspace's arrival counters zero."""
     import ctypes
     from fasterseg_amd import _lib
@@ -251,11 +251,12 @@ def test_wgrad_slab_reduction_is_deterministic_and_matches_atomics(case, dtype):
     ws[-k.WS_COUNTER_BYTES:].zero_()
     st = k._stream()
     outs = []
-    for _ in range(3):
-        dw = base.clone()
-        _lib.call("fs_conv2d_wgrad_ws", st, ctypes.byref(d), k._p(x), k._p(dy), k._p(dw), ks * ks * Cin, 1, Cin, k._p(ws), k.WORKSPACE_BYTES)
-        outs.append(dw)
-    torch.cuda.synchronize()
+    with k.deterministic():
+        for _ in range(3):
+            dw = base.clone()
+            _lib.call("fs_conv2d_wgrad_ws", st, ctypes.byref(d), k._p(x), k._p(dy), k._p(dw), ks * ks * Cin, 1, Cin, k._p(ws), k.WORKSPACE_BYTES)
+            outs.append(dw)
+        torch.cuda.synchronize()
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), "slab reduction is not bit-reproducible"
     assert int(ws[-k.WS_COUNTER_BYTES:].view(torch.int32).abs().sum()) == 0, "arrival counters were not left at zero"
     ref = base.clone()

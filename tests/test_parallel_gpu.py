@@ -26,7 +26,8 @@ def _student_worker(rank, world, port, out):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from fasterseg_amd import train_step
+    from fasterseg_amd import _lib, train_step
+    _lib.lib().fs_set_deterministic(1)       # ordered reductions: the collective-free reference below can be compared tightly
     st = train_step.StudentDistillStep(2, 128, 256, seed=12345 + 7 * rank)      # different init per rank: broadcast must fix it
     assert len(st.sync.buckets) > 1
     imgs, target = train_step.synthetic_batch(2, 128, 256, rank, "cuda")          # each rank its own shard
@@ -77,11 +78,10 @@ def test_student_step_data_parallel_two_ranks_one_gpu(tmp_path):
         worst.append((rel, k))
         n += 1
     worst.sort(reverse=True)
-    # value check against a collective-free computation.  Not bit-exact: two runs of the same step differ at the 1e-4 level
-    # (float-atomic BN statistics above 512 pixels, wgrad atomics), which batch-2 BatchNorm on the 4x8 maps amplifies to
-    # percent level in a few tensors; a sum-instead-of-mean or a missed bucket would be off by 50-100 %.
-    assert worst[0][0] <= 8e-2, worst[:8]
-    assert sum(1 for r, _ in worst if r > 1e-2) <= len(worst) // 10, worst[:12]
+    # value check against a collective-free computation, in the library's bit-reproducible mode (round 2 ran this with float atomics
+    # in the BN statistics / wgrad slabs: two runs of one step then differ at the 1e-4 level, which batch-2 BatchNorm on 4x8 maps
+    # amplifies to several per cent in a few tensors - the bar had to be 8e-2): a sum-instead-of-mean or a missed bucket is off by 50-100 %.
+    assert worst[0][0] <= 1e-4, worst[:8]
     assert n > 100
     for k in r0["state"]:
         if k.endswith(("running_mean", "running_var", "num_batches_tracked")):

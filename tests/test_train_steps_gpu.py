@@ -52,6 +52,19 @@ def test_graphed_supernet_step_equals_eager():
         assert rel < 2e-2, (k, rel)
 
 
+def test_deterministic_mode_makes_supernet_steps_bit_identical():
+    """kernels.deterministic() (fs_set_deterministic): two fresh builds of the graphed pretrain step - fused MixedOp programs, eager
+    lanes, pair batching and all - on the same batch and seeds produce the SAME bits: losses of three consecutive SGD steps and the
+    updated weights.  (Default mode: weight-gradient slabs and large-map BatchNorm reductions use float atomics, whose order varies.)"""
+    from fasterseg_amd import kernels as K
+    with K.deterministic():
+        a_losses, a_w = _run(True)
+        b_losses, b_w = _run(True)
+    assert a_losses == b_losses, (a_losses, b_losses)
+    for k in a_w:
+        assert torch.equal(a_w[k], b_w[k]), k
+
+
 def _run_search(use_graphs, steps=2):
     import json
     import os
