@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     // layers whose K loop is a handful of iterations, each one exposed global-load latency (the 8 MFMAs of an iteration hide none of
     // it): they keep the loads of TWO iterations in flight.  The large-tile and virtual-resize configurations stay single-stage
     // (register budget).
-    constexpr int STAGES = (WAVES_K > 1 && !VRES) ? 2 : 1;
+    constexpr int STAGES = ((WAVES_K > 1 || KSUB >= 6) && !VRES) ? 2 : 1;
     u32x4 a_reg[STAGES][A_PASS][A_SUBS], b_reg[STAGES][B_PASS][B_SUBS];
     // VRES: the three other bilinear taps of every A vector and the two interpolation fractions (zero-sized otherwise)
     constexpr int VR = VRES ? 1 : 0;
@@ -565,6 +565,11 @@ template <typename T> static void dispatch(hipStream_t st, ConvArgs& a, int forc
     else if (nblocks(a, 64, 32) >= 2 * FILL) cfg = 4;
     else if (nblocks(a, 32, 32) >= 2 * FILL) cfg = 5;        // 512+ small tiles: the lighter staging keeps more blocks per CU
     else cfg = (a.K > 8 * 64 / (int)sizeof(T)) ? 6 : 5;      // long K: stage 16 sub-chunks per iteration
+    // Wide layers on small maps (the fused first convs of a MixedOp pair: 768 output channels on 768 pixels, K = 3456): 32 x 32 tiles
+    // re-read every operand row 24 times through the L2 (a quarter of a GB per launch); 64 x 64 tiles with a 6-sub-chunk, two-stage K
+    // loop halve that at 100+ blocks.  FS_IGEMM_WIDE=0 disables, =N sets the minimum number of 64 x 64 blocks (default 96).
+    static const int wide_min = [] { const char* e = getenv("FS_IGEMM_WIDE"); return e ? atoi(e) : 96; }();
+    if (force < 0 && wide_min > 0 && cfg >= 4 && a.vr_H == 0 && a.Cout >= 128 && a.K >= 1024 && nblocks(a, 64, 64) >= wide_min) cfg = 7;
     if (a.vr_H > 0) {        // resampled input: only the small-map configurations carry the interpolating gather
         if (cfg < 3) cfg = 3;
         switch (cfg) {
@@ -582,6 +587,7 @@ template <typename T> static void dispatch(hipStream_t st, ConvArgs& a, int forc
         case 3: launch_cfg<T, 2, 2, 1, 1, 1, 2>(st, a); break;   // 64 x 64
         case 4: launch_cfg<T, 2, 1, 2, 1, 1, 2>(st, a); break;   // 64 x 32, K split 2
         case 5: launch_cfg<T, 1, 1, 4, 1, 1, 2>(st, a, ws, ws_bytes); break;   // 32 x 32, K split 4, 8 sub-chunks / iteration
+        case 7: launch_cfg<T, 2, 2, 1, 1, 1, 6>(st, a); break;   // 64 x 64, 6 sub-chunks / iteration, two register stages
         default: launch_cfg<T, 1, 1, 4, 1, 1, 4>(st, a, ws, ws_bytes); break;  // 32 x 32, K split 4, 16 sub-chunks / iteration
     }
 }

@@ -98,7 +98,7 @@ int fs_version(void);
 void fs_set_deterministic(int on);
 int fs_get_deterministic(void);
 int fs_struct_size(int which);   /* 0 fs_conv_desc, 1 fs_resize_desc, 2 fs_zoom_desc, 3 fs_sgd_tensor, 4 fs_logits_desc; -1 otherwise */
-/* test hook: force the tile configuration of fs_conv2d_fwd (0..6; -1 = heuristic).  Not for production use. */
+/* test hook: force the tile configuration of fs_conv2d_fwd (0..7; -1 = heuristic).  Not for production use. */
 void fs_debug_force_conv_cfg(int cfg);
 /* number of elements of a packed filter bank for (Cout,R,S,Cin) */
 long long fs_packed_weight_elems(int Cout, int R, int S, int Cin);

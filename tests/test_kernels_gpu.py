@@ -75,7 +75,7 @@ def force_cfg(request):
     _lib.lib().fs_debug_force_conv_cfg(-1)
 
 
-@pytest.mark.parametrize("force_cfg", [-1, 0, 1, 2, 3, 4, 5, 6], indirect=True, ids=lambda c: "cfg%d" % c)
+@pytest.mark.parametrize("force_cfg", [-1, 0, 1, 2, 3, 4, 5, 6, 7], indirect=True, ids=lambda c: "cfg%d" % c)
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=[str(c) for c in CONV_CASES])
 def test_conv2d_fwd(case, dtype, force_cfg):
@@ -442,7 +442,47 @@ def test_weighted_sum_fwd_bwd_dots(dtype, n):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
-@pytest.mark.parametrize("cfg", [-1, 0, 3, 5, 6])
+@pytest.mark.parametrize("cfg", [-1, 3, 5, 6, 7])
+def test_conv_two_segment_filter_bank_and_contraction(dtype, cfg):
+    """fs_conv_desc.n_seg / n_jump (output channels >= n_seg read filter rows n_jump further: two filter banks as one GEMM) and
+    k_seg / k_jump (input channels >= k_seg of every tap are k_jump elements further: the data gradient of the fused pair over both
+    rotated packs) against the same convolutions on densely concatenated packs - the horizontal fusion of a MixedOp's
+    'conv' + 'conv_2x'.conv1 (fusion.py), on the widths of a wide supernet cell."""
+    import ctypes
+    from fasterseg_amd import _lib
+    k = K()
+    O, I, cout, cin, N, H, W = 192, 160, 144, 128, 2, 12, 16
+    wa, wb = q(rnd(O, I, 3, 3, seed=70) * 0.1, dtype).cuda(), q(rnd(O, I, 3, 3, seed=71) * 0.1, dtype).cuda()
+    x = k.to_nhwc(q(rnd(N, cin, H, W, seed=72), dtype).cuda(), dtype)
+    es = 4 if dtype == torch.float32 else 2
+    # forward: two full-size [O][3][3][I] banks back to back (what optim.FlatSGD lays out for a pair)
+    banks = torch.cat([k.pack_weight(wa, dtype).reshape(-1), k.pack_weight(wb, dtype).reshape(-1)])
+    dense = torch.cat([k.pack_weight(wa, dtype, cout, cin).reshape(-1), k.pack_weight(wb, dtype, cout, cin).reshape(-1)])
+    _lib.lib().fs_debug_force_conv_cfg(cfg)
+    try:
+        ref = k.conv2d(x, dense.view(2 * cout, 3, 3, cin), 2 * cout, 3, 3, 1, 1)
+        got = k.empty_nhwc(N, 2 * cout, H, W, dtype, "cuda")
+        d = k.conv_desc(x.shape, cin, 2 * cout, 3, 3, 1, 1, 2 * cout, dtype)
+        d.w_os, d.w_ts, d.n_seg, d.n_jump = 9 * I, I, cout, O - cout
+        ws, wsb = k.stream_workspace("cuda")
+        _lib.call("fs_conv2d_fwd_ws", k._stream(), ctypes.byref(d), k._p(x), k._p(banks), None, None, k._p(got), None, ws, wsb)
+        assert torch.equal(ref, got), float((ref.float() - got.float()).abs().max())
+        # data gradient: contraction over the 2 * cout channels of dz, rotated packs [I][3][3][O] back to back
+        dz = k.to_nhwc(q(rnd(N, 2 * cout, H, W, seed=73), dtype).cuda(), dtype)
+        flips = torch.cat([k.pack_weight(wa, dtype, flip=True).reshape(-1), k.pack_weight(wb, dtype, flip=True).reshape(-1)])
+        fa, fb = k.pack_weight(wa, dtype, cout, cin, flip=True), k.pack_weight(wb, dtype, cout, cin, flip=True)      # [cin][3][3][cout]
+        ref = k.conv2d(dz, torch.cat([fa, fb], dim=3).contiguous(), cin, 3, 3, 1, 1)
+        got = k.empty_nhwc(N, cin, H, W, dtype, "cuda")
+        g = k.conv_desc(dz.shape, 2 * cout, cin, 3, 3, 1, 1, cin, dtype)
+        g.w_os, g.w_ts, g.k_seg, g.k_jump = 9 * O, O, cout, I * 9 * O - cout
+        _lib.call("fs_conv2d_fwd_ws", k._stream(), ctypes.byref(g), k._p(dz), k._p(flips), None, None, k._p(got), None, ws, wsb)
+        assert torch.equal(ref, got), float((ref.float() - got.float()).abs().max())
+    finally:
+        _lib.lib().fs_debug_force_conv_cfg(-1)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("cfg", [-1, 0, 3, 5, 6, 7])
 def test_conv_reads_filter_block_of_wider_pack(dtype, cfg):
     """fs_conv_desc.w_os / w_ts: the [:cout][..][:cin] block of a full-size packed bank read in place equals the densely
     re-packed slice (USConv2d widths, slimmable_ops.py:42), forward and flipped (data-gradient) banks."""
