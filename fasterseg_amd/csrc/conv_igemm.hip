@@ -567,8 +567,10 @@ template <typename T> static void dispatch(hipStream_t st, ConvArgs& a, int forc
     else cfg = (a.K > 8 * 64 / (int)sizeof(T)) ? 6 : 5;      // long K: stage 16 sub-chunks per iteration
     // Wide layers on small maps (the fused first convs of a MixedOp pair: 768 output channels on 768 pixels, K = 3456): 32 x 32 tiles
     // re-read every operand row 24 times through the L2 (a quarter of a GB per launch); 64 x 64 tiles with a 6-sub-chunk, two-stage K
-    // loop halve that at 100+ blocks.  FS_IGEMM_WIDE=0 disables, =N sets the minimum number of 64 x 64 blocks (default 96).
-    static const int wide_min = [] { const char* e = getenv("FS_IGEMM_WIDE"); return e ? atoi(e) : 96; }();
+    // loop halve that at 100+ blocks.  Measured (tools/conv_sweep.py, bf16): 192->384 on 3072 pixels 21.9 vs 23.9 us, but 384->768 on
+    // 768 pixels 33.5 vs 26.3 us (144 blocks leave 44 % of the CUs idle) and the C3 step 101.5 vs 99.5 ms - so the configuration is
+    // opt-in: FS_IGEMM_WIDE=N enables it for layers with at least N 64 x 64 blocks (0 / unset: off).
+    static const int wide_min = [] { const char* e = getenv("FS_IGEMM_WIDE"); return e ? atoi(e) : 0; }();
     if (force < 0 && wide_min > 0 && cfg >= 4 && a.vr_H == 0 && a.Cout >= 128 && a.K >= 1024 && nblocks(a, 64, 64) >= wide_min) cfg = 7;
     if (a.vr_H > 0) {        // resampled input: only the small-map configurations carry the interpolating gather
         if (cfg < 3) cfg = 3;
