@@ -276,7 +276,7 @@ class MixedOp(nn.Module):
             from . import program
             prog = cache[key] = program.lower_mixed_op(self, tuple(x.shape), x.stride(3), x.dtype, x.device, need_x, need_coef,
                                                        want_w, sink, groups)
-            if x.stride(3) == x.shape[1]:          # call site, for prewarm_programs(): everything in the key but the widths
+            if x.stride(3) == x.shape[1] and _SAMPLING_PASS:   # call site of a width-sampling pass, for prewarm_programs(): everything in the key but the widths
                 site = (x.shape[0], x.shape[2], x.shape[3], x.dtype, x.device, need_x, need_coef, want_w, groups)
                 self.__dict__.setdefault("_sites", {}).setdefault(site, (ratio0, ratio1))
         return prog
@@ -341,6 +341,7 @@ _LINEAR_LATENCY = bool(int(os.environ.get("FS_LINEAR_LATENCY", "1")))
 # the MixedOp coefficients of a whole pass in a few batched ops (Network_Multi_Path._coefficient_rows); FS_BATCHED_COEFS=0: per MixedOp
 _BATCHED_COEFS = bool(int(os.environ.get("FS_BATCHED_COEFS", "1")))
 _SAMPLED = object()        # stands in for a sampled width in _cell_ratio probes
+_SAMPLING_PASS = False     # the forward in progress draws its widths ("random" / Gumbel "arch_ratio"): its call sites are worth prewarming
 
 
 class Cell(nn.Module):
@@ -564,6 +565,8 @@ class Network_Multi_Path(nn.Module):
         stem, refine16, refine32 = self.stem[k], self.refine16[k], self.refine32[k]
         alphas, betas = self._arch_tensors()
         mode = self.prun_mode if self.prun_mode is not None else self._prun_modes[k]
+        global _SAMPLING_PASS
+        _SAMPLING_PASS = mode in ("random", "arch_ratio")
         ratios = self.sample_prun_ratio(mode=mode)
         coef_rows = self._coefficient_rows(alphas, ratios, mode) if _BATCHED_COEFS else None
         # one host read of the whole beta tables instead of one implicit sync per cell (reference :326-328)

@@ -252,7 +252,11 @@ def test_prewarm_enumerates_every_width_combination_of_a_call_site():
     x = torch.empty_strided((2, 32, 16, 24), (16 * 24 * 32, 1, 24 * 32, 32)).requires_grad_(True)
     coef = torch.ones(5, requires_grad=True)
     assert m.prewarm_programs() == 0                         # no call site, no sampling information yet
-    assert m._program(x, coef, r0, r1) is not None
+    model_search._SAMPLING_PASS = False
+    assert m._program(x, coef, r0, r1) is not None and not m.__dict__.get("_sites"), "a fixed-width pass records no call site"
+    m.__dict__["_programs"].clear()
+    model_search._SAMPLING_PASS = True                       # as Network_Multi_Path.forward sets it for "random" / Gumbel passes
+    assert m._program(x, coef, r0, r1) is not None and len(m.__dict__["_sites"]) == 1
     m.__dict__["_ratio_sampled"] = (True, False)             # in-width sampled, out-width fixed (e.g. the last layer's head width)
     assert m.prewarm_programs() == len(WIDTHS) - 1
     m.__dict__["_ratio_sampled"] = (True, True)
@@ -268,3 +272,4 @@ def test_prewarm_enumerates_every_width_combination_of_a_call_site():
             assert prog is not None and prog.out_shape[0] == 2
     assert m._programs == before, "a later call lowered a program the prewarm should have built"
     assert m.prewarm_programs() == 0
+    model_search._SAMPLING_PASS = False

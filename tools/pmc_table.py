@@ -7,7 +7,8 @@ divided by STEPS.  Derived columns (MI355X_MICROARCH.md, sections HBM / PMC slot
   hbm_read_bytes  = 2 x FETCH_SIZE x 1024   (FETCH_SIZE is in KiB and on gfx950 reports half of the bytes of 16-byte coalesced loads -
                                              all loads of these kernels are 16-byte vectors)
   hbm_write_bytes = WRITE_SIZE x 1024
-  mfma_util       = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 256 CUs x 4 SIMDs)   (gfx94x MfmaUtil formula)
+  mfma_util       = sum(SQ_VALU_MFMA_BUSY_CYCLES) / (GRBM_GUI_ACTIVE x 256 CUs x 4 SIMDs)   (gfx94x MfmaUtil formula; GRBM_GUI_ACTIVE is
+                    reported once per XCD: the MAXIMUM over a dispatch's instances is taken, the SQ counter is summed over its instances)
 Infinity-Cache hits are counted by the fabric-side FETCH/WRITE counters: with working sets < 256 MiB the byte figures are an upper bound
 on DRAM traffic.
 """
@@ -31,13 +32,20 @@ def main():
     for spec in args:
         _, path = spec.split("=", 1)
         seen = collections.defaultdict(set)
+        gui = {}                                     # (kernel, dispatch) -> max GRBM_GUI_ACTIVE over its per-XCD instances
         for r in csv.DictReader(open(path)):
             ts = int(r.get("Start_Timestamp", 0) or 0)
             if lo is not None and not (lo <= ts <= hi):
                 continue
             k = short(r["Kernel_Name"])
-            table[k][r["Counter_Name"]] += float(r["Counter_Value"])
-            seen[k].add(r.get("Dispatch_Id", ts))
+            disp = r.get("Dispatch_Id", ts)
+            if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+                gui[(k, disp)] = max(gui.get((k, disp), 0.0), float(r["Counter_Value"]))
+            else:
+                table[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            seen[k].add(disp)
+        for (k, _), v in gui.items():
+            table[k]["GRBM_GUI_ACTIVE"] += v
         for k, s in seen.items():
             table[k]["dispatches"] = max(table[k]["dispatches"], len(s))
     res = {}

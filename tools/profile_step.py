@@ -17,7 +17,7 @@ else:
     mk = lambda: (torch.randn(b, 3, h, w, generator=g).cuda(), torch.randint(0, 19, (b, h // 8, w // 8), generator=g).cuda())
     (imgs, target), (imgs_s, target_s) = mk(), mk()
     run = lambda: st.step(imgs, target, imgs_s, target_s)
-for _ in range(2):
+for _ in range(int(os.environ.get("FS_PROFILE_WARMUP", "2"))):
     run()
 torch.cuda.synchronize()
 import time
