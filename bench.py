@@ -149,6 +149,43 @@ def parallelism(world, backend, what):
     return "dp%d, %s, torch.distributed backend '%s'%s" % (world, what, backend, " (= RCCL)" if backend == "nccl" else " (functional test only)")
 
 
+# ---- measured HBM traffic (rocprofv3 --pmc passes of earlier runs, committed under profiles/) ----------------------------------------
+def frame_traffic(family, dtype):
+    """HBM bytes per launch of a kernel family of the C2 frame: profiles/r03_c2_pmc_frame.json (tools/pmc_frame.py: FETCH_SIZE / WRITE_SIZE
+    passes over plan-order frames, conv3x3 and conv1x1 separately), else the round-2 table; None when there is no measurement."""
+    for name, get in (("r03_c2_pmc_frame.json", lambda d: d.get(family, {}).get("hbm_bytes_per_launch")),
+                      ("pmc_traffic.json", lambda d: d.get(dtype, {}).get(family))):
+        path = os.path.join(ROOT, "profiles", name)
+        if dtype == "bf16" and os.path.exists(path):
+            try:
+                with open(path) as f:
+                    v = get(json.load(f))
+                if v:
+                    return int(v)
+            except Exception:
+                pass
+    return None
+
+
+def step_traffic(workload, kernels):
+    """HBM bytes per launch of the given kernels of a train step from profiles/r03_<workload>_pmc.json (tools/pmc_table.py), or None."""
+    path = os.path.join(ROOT, "profiles", "r03_%s_pmc.json" % workload)
+    if not os.path.exists(path):
+        return None
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        n = sum(d[k]["launches"] for k in kernels if k in d)
+        b = sum(d[k]["launches"] * (d[k].get("hbm_read_bytes_per_launch", 0) + d[k].get("hbm_write_bytes_per_launch", 0)) for k in kernels if k in d)
+        return int(b / n) if n else None
+    except Exception:
+        return None
+
+
+STEP_FAMILY_KERNELS = {"conv_igemm (fwd + dgrad)": ("conv_igemm_kernel", "splitk_reduce_kernel"), "conv_wgrad": ("wgrad_kernel",),
+                       "conv3x3_halo": ("conv3x3_halo_kernel",)}
+
+
 # ---- C2: student inference ---------------------------------------------------------------------------------------------
 def roofline_from_profile(rows, dtype):
     fam = {}
@@ -169,13 +206,7 @@ def roofline_from_profile(rows, dtype):
         ach = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
         out.update(bound="hbm", achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(ach / PEAK_HBM_GBS, 4),
                    alg_bytes_per_launch=dom["bytes"] / dom["n"])
-    traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # HBM bytes/launch from rocprofv3 --pmc passes
-    if os.path.exists(traffic_file):
-        try:
-            with open(traffic_file) as f:
-                out["traffic"] = json.load(f).get(dtype, {}).get(name)
-        except Exception:
-            pass
+    out["traffic"] = frame_traffic(name, dtype)
     families = {k: {"ms": round(v["ms"], 4), "launches": v["n"], "TFLOPs": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else 0.0,
                     "GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)} for k, v in fam.items()}
     return out, families, total_ms
@@ -312,7 +343,7 @@ def _parity(what, got, want, dtype_name, extra=None):
     return out
 
 
-def _timed_census(args, world, rank, step_fn, extra_entries=()):
+def _timed_census(args, world, rank, step_fn, extra_entries=(), workload=None):
     """ONE more step, issued eagerly with every kernel launch timed by its own HIP event pair (census level 2).  Every rank runs it
     (the step contains the gradient all-reduce), rank 0 reports."""
     from fasterseg_amd import census
@@ -322,6 +353,8 @@ def _timed_census(args, world, rank, step_fn, extra_entries=()):
     if rank != 0:
         return None
     roof, families, kernels = census.roofline_timed(rec, args.dtype, PEAK_TFLOPS[args.dtype], PEAK_HBM_GBS, extra_entries)
+    if roof is not None and workload and args.dtype == "bf16":
+        roof["traffic"] = step_traffic(workload, STEP_FAMILY_KERNELS.get(roof["kernel"], ()))
     return {"roofline": roof, "kernel_families": families, "kernels_in_step": kernels}
 
 
@@ -381,7 +414,7 @@ def run_student_train(args, world, rank, backend):
         extra = []
         if rank == 0 and stepper.teacher_engine is not None:
             extra = stepper.teacher_engine.census_entries(stepper.teacher_engine.profile_in_frame(frames=3, warm=1))
-        timed = _timed_census(args, world, rank, lambda: stepper.step(imgs, target), extra)
+        timed = _timed_census(args, world, rank, lambda: stepper.step(imgs, target), extra, workload="c4")
         if timed:
             line.update(timed)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -498,7 +531,8 @@ def run_supernet(args, world, rank, backend, pretrain):
                         "eager_passes_per_phase": sum(1 for s_ in stepper._specs() if not stepper._is_static(s_)),
                         "execution": stepper.describe()})
     if not args.no_roofline:
-        timed = _timed_census(args, world, rank, lambda: stepper.step(imgs, target, imgs_s, target_s, force_eager=True))
+        timed = _timed_census(args, world, rank, lambda: stepper.step(imgs, target, imgs_s, target_s, force_eager=True),
+                              workload="c3" if pretrain else "c5")
         if timed:
             line.update(timed)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

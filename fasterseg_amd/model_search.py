@@ -276,9 +276,11 @@ class MixedOp(nn.Module):
             from . import program
             prog = cache[key] = program.lower_mixed_op(self, tuple(x.shape), x.stride(3), x.dtype, x.device, need_x, need_coef,
                                                        want_w, sink, groups)
-            if x.stride(3) == x.shape[1] and _SAMPLING_PASS:   # call site of a width-sampling pass, for prewarm_programs(): everything in the key but the widths
-                site = (x.shape[0], x.shape[2], x.shape[3], x.dtype, x.device, need_x, need_coef, want_w, groups)
-                self.__dict__.setdefault("_sites", {}).setdefault(site, (ratio0, ratio1))
+        if _SAMPLING_PASS and x.stride(3) == x.shape[1]:
+            # call site of a width-sampling pass, for prewarm_programs(): everything in the key but the widths.  Recorded on cache hits
+            # too: a draw that happens to equal a width pair the fixed-width passes already lowered must still register the site.
+            site = (x.shape[0], x.shape[2], x.shape[3], x.dtype, x.device, need_x, need_coef, want_w, groups)
+            self.__dict__.setdefault("_sites", {}).setdefault(site, (ratio0, ratio1))
         return prog
 
     def prewarm_programs(self):
