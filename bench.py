@@ -499,7 +499,7 @@ def run_supernet(args, world, rank, backend, pretrain):
     torch.manual_seed(SEED)
     first_w, first_a = stepper.step(imgs, target, imgs_s, target_s)
     parity = None
-    if rank == 0 and not os.environ.get("FS_BENCH_SKIP_GATE"):          # (debugging aid: the gate is part of every reported run)
+    if rank == 0:
         np.random.seed(SEED)
         torch.manual_seed(SEED)
         threads = torch.get_num_threads()
