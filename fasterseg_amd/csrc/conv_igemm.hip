@@ -64,6 +64,7 @@ template <> struct Mma<bf16_t> {
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 constexpr int CONV_SCALAR_STORE = 0x100;   // internal flag: output slice not 16-byte aligned -> element-wise epilogue
+constexpr int CONV_BIG_OPERANDS = 0x200;   // internal flag: x or the filter bank spans 2 GiB or more -> no 32-bit offset configurations
 
 template <typename T, int WAVES_M, int WAVES_N, int WAVES_K, int WM_T, int WN_T, int KSUB, bool VRES = false>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
@@ -84,9 +85,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     constexpr int RED_BYTES = (WAVES_K - 1) * WAVES_M * WAVES_N * TILES * 16 * 64 * 4;   // split-K partials
     constexpr int OUT_PITCH = 32 * (int)sizeof(T) + 16;
     constexpr int OUT_BYTES = WAVES_M * WAVES_N * 32 * OUT_PITCH;                         // epilogue transpose
-    constexpr int SMEM = cmax(STAGE_BYTES, RED_BYTES + OUT_BYTES);
+    constexpr int SMEM = (cmax(STAGE_BYTES, RED_BYTES + OUT_BYTES) + 15) & ~15;
+    // FAST configurations (the small-tile, two-stage ones): per-vector address arithmetic is what bounds them - the K loop of the 32x32
+    // K-split kernel issued 510 VALU instructions per iteration for its 16 gathers and 8 MFMAs (ISA count).  They look the byte offset of
+    // (tile row, filter tap) up in an LDS table filled once per block (offset or ~0 for padding / out-of-range rows) instead of
+    // re-deriving (n, ih, iw), the bounds tests and a 64-bit pixel offset for every 16-byte vector.  Offsets are 32-bit: the host routes
+    // tensors of 2 GiB and more to the other configurations.
+    constexpr bool FAST = (WAVES_K > 1 || KSUB >= 6) && !VRES;
+    constexpr int TAP_PITCH = 12;                 // table row: up to 9 taps, padded
+    constexpr int TAP_BYTES = FAST ? BM * TAP_PITCH * 4 : 0;
 
-    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM + TAP_BYTES];
+    uint32_t* sTap = reinterpret_cast<uint32_t*>(smem + SMEM);
     unsigned char* sA = smem;
     unsigned char* sB = smem + BM * PITCH;
 
@@ -113,7 +123,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
     for (int ps = 0; ps < A_PASS; ++ps) {
         const int m = m0 + ps * A_RPP + a_row;
-        if (m < p.M) {
+        if (FAST) {
+            a_ih0[ps] = 0; a_iw0[ps] = 0; a_base[ps] = 0;      // unused: the tap table below replaces them
+        } else if (m < p.M) {
             const int n = m / p.HoWo;
             const int rem = m - n * p.HoWo;
             const int oh = rem / p.Wo;
@@ -136,6 +148,30 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
     for (int j = 0; j < A_SUBS; ++j) ak[j] = k_lo + (a_grp + A_GROUPS * j) * BK64 + lvec * VEC;
     const int tshift = transposed ? 1 : 0;
+    if constexpr (FAST) {
+        const int taps = p.K / p.Cin;                          // R * S
+        for (int idx = tid; idx < BM * TAP_PITCH; idx += 256) {
+            const int row = idx / TAP_PITCH, tap = idx - row * TAP_PITCH;
+            const int m = m0 + row;
+            uint32_t v = 0xffffffffu;
+            if (tap < taps && m < p.M) {
+                const int n = m / p.HoWo;
+                const int rem = m - n * p.HoWo;
+                const int oh = rem / p.Wo;
+                const int ow = rem - oh * p.Wo;
+                const int kr = tap / p.S, ks = tap - kr * p.S;
+                int ih = oh * p.stride - p.pad + kr;
+                int iw = ow * p.stride - p.pad + ks;
+                bool ok = ((ih | iw) & tshift) == 0;           // transposed: only even positions carry data
+                ih >>= tshift;
+                iw >>= tshift;
+                ok = ok && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
+                if (ok) v = (uint32_t)((((long long)n * p.H + ih) * p.W + iw) * p.x_cs * (long long)sizeof(T));
+            }
+            sTap[idx] = v;
+        }
+        __syncthreads();
+    }
     const unsigned char* b_ptr[B_PASS];
     bool b_ok[B_PASS];
 #pragma unroll
@@ -168,6 +204,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
             const bool kvalid = k < k_hi;
             const int rs = (int)__umulhi((unsigned)k, p.cin_magic);
             const int kc = (VRES && !kvalid) ? 0 : k - rs * p.Cin;
+            if constexpr (FAST) {
+                const int rs_c = kvalid ? rs : 0;
+                const uint32_t kbytes = (uint32_t)kc * (uint32_t)sizeof(T);
+#pragma unroll
+                for (int ps = 0; ps < A_PASS; ++ps) {
+                    const uint32_t t = sTap[(ps * A_RPP + a_row) * TAP_PITCH + rs_c];
+                    const bool ok = kvalid && t != 0xffffffffu;
+                    a_keep[SG][ps][j] = ok ? 0xffffffffu : 0u;
+                    a_reg[SG][ps][j] = ldg16(p.x + (ok ? t + kbytes : 0u));
+                }
+                ak[j] = k + BKT;
+                continue;
+            }
             const int kr = (p.S == 3) ? ((rs * 11) >> 5) : rs;     // rs / 3 for rs < 9
             const int ks = rs - kr * p.S;
 #pragma unroll
@@ -206,6 +255,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
             const bool kvalid = bk[j] < k_hi;
             // a slice of a wider resident pack: taps are w_tgap elements further apart than Cin (0 for a dense pack)
             const int brs = (int)__umulhi((unsigned)bk[j], p.cin_magic);
+            if constexpr (FAST) {          // 32-bit offsets inside a filter row (rows and two-segment jumps stay far below 2 GiB)
+                int koff = bk[j] + brs * p.w_tgap;
+                if (p.k_seg > 0 && bk[j] - brs * p.Cin >= p.k_seg) koff += p.k_jump;
+                const uint32_t kb = (uint32_t)koff * (uint32_t)sizeof(T);
+#pragma unroll
+                for (int ps = 0; ps < B_PASS; ++ps) {
+                    const bool ok = kvalid && b_ok[ps];
+                    b_keep[SG][ps][j] = ok ? 0xffffffffu : 0u;
+                    b_reg[SG][ps][j] = ldg16(ok ? b_ptr[ps] + kb : p.w);
+                }
+                bk[j] += BKT;
+                continue;
+            }
             long long koff = bk[j] + (long long)brs * p.w_tgap;
             if (p.k_seg > 0 && bk[j] - brs * p.Cin >= p.k_seg) koff += p.k_jump;
 #pragma unroll
@@ -572,6 +634,8 @@ template <typename T> static void dispatch(hipStream_t st, ConvArgs& a, int forc
     // opt-in: FS_IGEMM_WIDE=N enables it for layers with at least N 64 x 64 blocks (0 / unset: off).
     static const int wide_min = [] { const char* e = getenv("FS_IGEMM_WIDE"); return e ? atoi(e) : 0; }();
     if (force < 0 && wide_min > 0 && cfg >= 4 && a.vr_H == 0 && a.Cout >= 128 && a.K >= 1024 && nblocks(a, 64, 64) >= wide_min) cfg = 7;
+    // configurations 4..7 address x and a filter row with 32-bit byte offsets
+    if ((a.flags & CONV_BIG_OPERANDS) && cfg >= 4) cfg = 3;
     if (a.vr_H > 0) {        // resampled input: only the small-map configurations carry the interpolating gather
         if (cfg < 3) cfg = 3;
         switch (cfg) {
@@ -686,6 +750,12 @@ extern "C" fs_status fs_conv2d_fwd_ws(void* stream, const fs_conv_desc* d, const
         FS_REQUIRE(d->w_ts >= tap_need && d->w_os >= d->R * d->S * d->w_ts && d->w_ts % vec == 0 && d->w_os % vec == 0,
                    FS_ERR_INVALID, "fs_conv2d_fwd: filter strides (%d,%d) invalid for Cin=%d", d->w_os, d->w_ts, d->Cin);
         a.w_os = d->w_os; a.w_tgap = d->w_ts - d->Cin;
+    }
+    {
+        const long long es = elem_size(d->dtype);
+        const long long x_bytes = (long long)d->N * (d->vr_H > 0 ? (long long)d->vr_H * d->vr_W : (long long)d->H * d->W) * d->x_cs * es;
+        const long long w_row = ((long long)a.w_os + (d->k_seg > 0 ? (d->k_jump > 0 ? d->k_jump : -(long long)d->k_jump) : 0)) * es;
+        if (x_bytes >= (1ll << 31) || w_row >= (1ll << 31)) a.flags |= CONV_BIG_OPERANDS;
     }
     // 16-byte epilogue stores need an aligned slice; otherwise every tile takes the element-wise path
     if (!(aligned16(y) && (d->y_cs % vec == 0))) a.flags |= CONV_SCALAR_STORE;

@@ -15,6 +15,7 @@ shapes = [(3, 96, 96, 32, 64), (3, 192, 192, 16, 32), (3, 384, 384, 8, 16), (3, 
           (6, 768, 384, 8, 16), (6, 384, 192, 16, 32), (3, 192, 96, 32, 64), (6, 768, 384, 4, 8)]
 if os.environ.get("FS_SWEEP_ONLY_R3"):
     shapes = shapes[-10:] + [(6, 384, 384, 8, 16), (6, 192, 192, 16, 32), (3, 96, 96, 32, 64)]
+CFGS = tuple(int(c) for c in os.environ["FS_SWEEP_CFGS"].split(",")) if os.environ.get("FS_SWEEP_CFGS") else (-1, 1, 2, 3, 4, 5, 6, 7)
 DTYPES = [torch.bfloat16] if os.environ.get("FS_SWEEP_DTYPE") == "bf16" else [torch.float32, torch.bfloat16]
 def bench(fn, iters=200):
     for _ in range(10): fn()
@@ -40,7 +41,7 @@ for dtype in DTYPES:
         out = K.empty_nhwc(N, cout, H, W, dtype, "cuda")
         stats = torch.zeros(2 * cout, device="cuda")
         res = []
-        for cfg in (-1, 1, 2, 3, 4, 5, 6, 7):
+        for cfg in CFGS:
             lib.fs_debug_force_conv_cfg(cfg)
             try:
                 t = bench(lambda: K.conv2d(x, w, cout, 3, 3, 1, 1, out=out, stats=stats))
@@ -49,5 +50,5 @@ for dtype in DTYPES:
             res.append(t)
         lib.fs_debug_force_conv_cfg(-1)
         gf = 2 * N * H * W * cout * cin * 9 / 1e9
-        print("N%d %3d->%3d @%2dx%2d  M=%5d K=%4d %.2fGF | heur %.1f | cfg1 %.1f cfg2 %.1f cfg3 %.1f cfg4 %.1f cfg5 %.1f cfg6 %.1f cfg7 %.1f us" % (
-            N, cin, cout, H, W, N * H * W, cin * 9, gf, *res))
+        print("N%d %3d->%3d @%2dx%2d  M=%5d K=%4d %.2fGF | " % (N, cin, cout, H, W, N * H * W, cin * 9, gf) +
+              " ".join("%s %.1f" % ("heur" if c < 0 else "cfg%d" % c, t) for c, t in zip(CFGS, res)) + " us")
