@@ -1,0 +1,58 @@
+"""The line bench.py prints must stay small enough for the driver to parse (round 3 printed 24 KB and the driver
+recorded `parsed: null`).  Built here from a canned full result - round 3's own 24 KB line - without a GPU."""
+import json
+import os
+
+import bench
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _canned():
+    with open(os.path.join(ROOT, "profiles", "r03_bench_default.json")) as f:
+        full = json.load(f)
+    assert len(json.dumps(full)) > 20000                       # the input really is the oversized line
+    train = {k: v for k, v in full["workloads"].items() if k != "C2_student_infer"}
+    c2 = {k: v for k, v in full.items() if k != "workloads"}
+    return c2, train
+
+
+def test_line_is_small_and_round_trips(tmp_path):
+    c2, train = _canned()
+    line, detail = bench.build_line(c2, train, 1, 20, "bf16", str(tmp_path / "bench_detail.json"))
+    text = json.dumps(line)
+    assert len(text) < bench.LINE_LIMIT, len(text)
+    assert "\n" not in text
+    back = json.loads(text)
+    assert back == line
+    assert back["parity"]["pass"] is True
+    # the contract's keys and the two objects the judge reads
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in back, k
+    assert set(back["config"]) == {"workload", "parallelism"}
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in back["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in back["cpu_baseline"], k
+    assert abs(back["roofline"]["frac"] - back["roofline"]["achieved"] / back["roofline"]["peak"]) < 1e-3
+    # one small object per workload, numbers only
+    assert set(back["workloads"]) == {"C2_student_infer", "C3_supernet_pretrain", "C4_student_train", "C5_supernet_search"}
+    for name, w in back["workloads"].items():
+        assert len(json.dumps(w)) < 700, (name, len(json.dumps(w)))
+        if name != "C2_student_infer":                       # C2's objects are the top-level ones
+            assert w["parity"]["pass"] is True
+            assert "roofline" in w and "cpu_baseline" in w
+            assert "ms_per_step_fp32" in w
+    # nothing was lost: the big tables live in the detail object
+    assert "kernels_in_step" in detail["C3_supernet_pretrain"]
+    assert "conv_autotune" in detail["C2_student_infer"]["config"]
+
+
+def test_line_without_optional_parts():
+    c2, _ = _canned()
+    for k in ("roofline", "cpu_baseline", "class_map", "frame_roofline"):
+        c2.pop(k, None)
+    line, _ = bench.build_line(c2, {}, 2, None, "bf16", None)
+    assert line["n_gpus"] == 2 and "roofline" not in line and line["detail"] is None
+    assert len(json.dumps(line)) < 1500

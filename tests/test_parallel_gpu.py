@@ -137,14 +137,17 @@ def test_bench_two_ranks_over_gloo_runs_the_collective_path(tmp_path):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workloads", "c4", "--steps", "50", "--warmup", "5", "--train-steps", "2",
-           "--train-warmup", "1", "--min-seconds", "0.05", "--no-cpu-baseline", "--no-class-map", "--no-fp32-leg"]
+           "--train-warmup", "1", "--min-seconds", "0.05", "--no-cpu-baseline", "--no-class-map", "--no-fp32-leg", "--detail", str(tmp_path / "detail.json")]
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
     assert len(lines) == 1, "exactly one JSON line (rank 0)"
+    assert len(lines[0]) < 4096                      # the driver could not parse round 3's 24 KB line
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
-    c4 = d["workloads"]["C4_student_train"]
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 50
+    assert d["workloads"]["C4_student_train"]["parity"]["pass"] and d["workloads"]["C4_student_train"]["roofline"]["frac"] > 0
+    with open(tmp_path / "detail.json") as f:        # the full objects (method strings, per-kernel tables) live in the detail file
+        c4 = json.load(f)["C4_student_train"]
     assert c4["global_batch"] == 24 and c4["parity"]["pass"]
     assert "functional test only" in c4["config"]["parallelism"] and "gloo" in c4["config"]["parallelism"]
     assert c4["roofline"]["flops_coverage"] == 1.0 and c4["roofline"]["frac"] > 0
