@@ -12,8 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_build")
 LIB = os.path.join(HERE, "libfasterseg_hip.so")
-SOURCES = ["api.cpp", "census.hip", "conv_igemm.hip", "conv3x3_halo.hip", "zoom_cell.hip", "elementwise.hip", "bn_col.hip", "resize.hip", "stem.hip", "wgrad.hip", "units.hip", "optim.hip", "program.hip", "loss.hip", "loss_up.hip", "eval.hip"]
-HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(HERE), "include", "fasterseg_hip.h")]
+SOURCES = ["api.cpp", "census.hip", "conv_igemm.hip", "conv_igemm2.hip", "conv3x3_halo.hip", "zoom_cell.hip", "elementwise.hip", "bn_col.hip", "resize.hip", "stem.hip", "wgrad.hip", "units.hip", "optim.hip", "program.hip", "loss.hip", "loss_up.hip", "eval.hip"]
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_igemm.h"), os.path.join(os.path.dirname(HERE), "include", "fasterseg_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 

@@ -1,0 +1,66 @@
+// Shared between the implicit-GEMM convolution kernels (conv_igemm.hip: register-staged tiles, virtual resize; conv_igemm2.hip: the
+// LDS-DMA pipelined small-map kernel): launch arguments, MFMA wrappers, internal flags.
+#pragma once
+#include "common.h"
+
+namespace fs {
+
+struct ConvArgs {
+    const unsigned char* x;
+    const unsigned char* w;
+    unsigned char* y;
+    const float* scale;
+    const float* shift;
+    float* stats;
+    int H, W, Cin, Cout, S, stride, pad, Ho, Wo;
+    int x_cs, y_cs;
+    int M, K, HoWo;
+    int flags;
+    int tiles_n;
+    unsigned cin_magic;   // ceil(2^32 / Cin): k / Cin == umulhi(k, cin_magic) for k < 2^16
+    int w_os, w_tgap;     // filter row stride (elements) and (tap stride - Cin): 0 gap = dense [Cout][R*S][Cin] pack
+    int vr_H, vr_W;       // virtual-resize input (VRES kernels): x is a (vr_H, vr_W) map, bilinearly resampled
+    float vr_rh, vr_rw;   //   (align_corners=True) to the (H, W) map the convolution reads; scale = (vr-1)/(H-1)
+    int vr_relu;          //   ReLU applied to the resampled value (zoomed-conv up-sample, operations.py:275-276)
+    float* ws;            // cross-block split-K: fp32 partial tiles [gridDim.z][M][Cout] (null = whole K in one block)
+    int k_slice;          // K elements per gridDim.z slice (multiple of the config's BKT)
+    int n_seg, n_jump;    // two-segment filter bank: output channels >= n_seg read filter row (n + n_jump); n_seg = 0: one bank
+    int k_seg, k_jump;    // two-segment contraction: input channels >= k_seg of a tap are k_jump elements further; k_seg = 0: off
+    // ---- conv_igemm2.hip only ----
+    int R;                // filter rows (K = R * S * Cin)
+    int tiles_m;          // tiles along M (class mode: summed over the parity classes)
+    int slices;           // cross-block split-K slices, folded into the 1-D grid (1: whole K in one block)
+    int slice_units;      // 16-byte K units per slice (multiple of 8 = one 128-byte stage)
+    int n_major;          // 1: consecutive logical blocks walk tile_m first (one XCD's L2 holds few filter panels), 0: tile_n first
+    int cls_start[5];     // class mode (exact stride-2 data gradient): first tile_m of each output-parity class (ph * 2 + pw), [4] = total
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<float> {
+    static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[j]), __uint_as_float(b[j]), c, 0, 0, 0);
+    }
+};
+template <> struct Mma<bf16_t> {
+    static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c,
+                                                    0, 0, 0);
+    }
+};
+
+constexpr int CONV_CLASSES = 0x400;        // internal flag (conv_igemm2): FS_CONV_TRANSPOSED evaluated per output-parity class (no zero taps)
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+constexpr int CONV_SCALAR_STORE = 0x100;   // internal flag: output slice not 16-byte aligned -> element-wise epilogue
+constexpr int CONV_BIG_OPERANDS = 0x200;   // internal flag: x or the filter bank spans 2 GiB or more -> no 32-bit offset configurations
+
+
+// conv_igemm2.hip: launches the LDS-DMA pipelined kernel when the geometry qualifies (returns false: caller falls back to
+// conv_igemm.hip's configurations).  ws / ws_bytes: cross-block split-K scratch (may be null); *slices_out receives the slice count
+// when defer_reduce leaves the partial slabs to the caller.
+bool igemm2_launch(hipStream_t st, ConvArgs& a, int dtype, int force_cfg, float* ws, long long ws_bytes, bool defer_reduce, int* slices_out);
+// conv_igemm.hip: second pass of a cross-block split-K conv (sum of the slabs, scale / shift / ReLU, BN statistics)
+void launch_splitk_reduce(hipStream_t st, const ConvArgs& a, int dtype, float* ws, int slices);
+
+}  // namespace fs

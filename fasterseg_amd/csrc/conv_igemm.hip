@@ -20,51 +20,9 @@
 // Replaces: nn.Conv2d/F.conv2d at reference search/operations.py:78,149-152,221-224,298-306,380-388,
 // 461-473, slimmable_ops.py:47, seg_oprs.py:22,245 (+BatchNorm2d/ReLU that follow them).
 #include <type_traits>
-#include "common.h"
+#include "conv_igemm.h"
 
 namespace fs {
-
-struct ConvArgs {
-    const unsigned char* x;
-    const unsigned char* w;
-    unsigned char* y;
-    const float* scale;
-    const float* shift;
-    float* stats;
-    int H, W, Cin, Cout, S, stride, pad, Ho, Wo;
-    int x_cs, y_cs;
-    int M, K, HoWo;
-    int flags;
-    int tiles_n;
-    unsigned cin_magic;   // ceil(2^32 / Cin): k / Cin == umulhi(k, cin_magic) for k < 2^16
-    int w_os, w_tgap;     // filter row stride (elements) and (tap stride - Cin): 0 gap = dense [Cout][R*S][Cin] pack
-    int vr_H, vr_W;       // virtual-resize input (VRES kernels): x is a (vr_H, vr_W) map, bilinearly resampled
-    float vr_rh, vr_rw;   //   (align_corners=True) to the (H, W) map the convolution reads; scale = (vr-1)/(H-1)
-    int vr_relu;          //   ReLU applied to the resampled value (zoomed-conv up-sample, operations.py:275-276)
-    float* ws;            // cross-block split-K: fp32 partial tiles [gridDim.z][M][Cout] (null = whole K in one block)
-    int k_slice;          // K elements per gridDim.z slice (multiple of the config's BKT)
-    int n_seg, n_jump;    // two-segment filter bank: output channels >= n_seg read filter row (n + n_jump); n_seg = 0: one bank
-    int k_seg, k_jump;    // two-segment contraction: input channels >= k_seg of a tap are k_jump elements further; k_seg = 0: off
-};
-
-template <typename T> struct Mma;
-template <> struct Mma<float> {
-    static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[j]), __uint_as_float(b[j]), c, 0, 0, 0);
-    }
-};
-template <> struct Mma<bf16_t> {
-    static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) {
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c,
-                                                    0, 0, 0);
-    }
-};
-
-constexpr int cmax(int a, int b) { return a > b ? a : b; }
-constexpr int CONV_SCALAR_STORE = 0x100;   // internal flag: output slice not 16-byte aligned -> element-wise epilogue
-constexpr int CONV_BIG_OPERANDS = 0x200;   // internal flag: x or the filter bank spans 2 GiB or more -> no 32-bit offset configurations
 
 template <typename T, int WAVES_M, int WAVES_N, int WAVES_K, int WM_T, int WN_T, int KSUB, bool VRES = false>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
@@ -550,6 +508,19 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
+template <typename T> static void launch_reduce_t(hipStream_t st, const ConvArgs& a, float* ws, int slices) {
+    const int cv = a.Cout / Elem<T>::VEC;
+    const int rpb = 256 / cv;
+    int rows = ((a.M + 511) / 512 + rpb - 1) / rpb * rpb;        // ~512 blocks, whole row groups per block
+    if (rows < rpb) rows = rpb;
+    FS_LAUNCH((splitk_reduce_kernel<T>), dim3((unsigned)((a.M + rows - 1) / rows)), dim3(256), 0, st, ws, slices, a.M, a.Cout, a.scale,
+              a.shift, (a.flags & FS_CONV_RELU) ? 1 : 0, (T*)a.y, a.y_cs, a.stats, rows);
+}
+void launch_splitk_reduce(hipStream_t st, const ConvArgs& a, int dtype, float* ws, int slices) {
+    if (dtype == FS_F32) launch_reduce_t<float>(st, a, ws, slices);
+    else launch_reduce_t<bf16_t>(st, a, ws, slices);
+}
+
 constexpr long long SPLITK_TARGET_BLOCKS = 1024;
 static thread_local bool t_defer_reduce = false;     // conv_fwd_deferred(): leave the split-K slabs to the caller
 static thread_local int t_slices = 1;
@@ -596,12 +567,7 @@ static void launch_cfg(hipStream_t st, ConvArgs& a, float* ws = nullptr, long lo
             t_slices = slices;
             return;
         }
-        const int cv = a.Cout / Elem<T>::VEC;
-        const int rpb = 256 / cv;
-        int rows = ((a.M + 511) / 512 + rpb - 1) / rpb * rpb;        // ~512 blocks, whole row groups per block
-        if (rows < rpb) rows = rpb;
-        FS_LAUNCH((splitk_reduce_kernel<T>), dim3((unsigned)((a.M + rows - 1) / rows)), dim3(256), 0, st, ws, slices, a.M,
-                           a.Cout, a.scale, a.shift, (a.flags & FS_CONV_RELU) ? 1 : 0, (T*)a.y, a.y_cs, a.stats, rows);
+        launch_reduce_t<T>(st, a, ws, slices);
         return;
     }
     a.ws = nullptr;
@@ -676,7 +642,7 @@ fs_status fs::conv_fwd_deferred(void* stream, const fs_conv_desc* d, const void*
 }
 
 static int g_force_cfg = -1;
-/* test hook: force a tile configuration (0..6), -1 = heuristic */
+/* test hook: force a tile configuration (0..7; 100.. = conv_igemm2.hip, see igemm2_launch), -1 = heuristic, -2 = heuristic without igemm2 */
 extern "C" void fs_debug_force_conv_cfg(int cfg) { g_force_cfg = cfg; }
 
 extern "C" fs_status fs_conv2d_fwd(void* stream, const fs_conv_desc* d, const void* x, const void* w_packed,
@@ -765,7 +731,17 @@ extern "C" fs_status fs_conv2d_fwd_ws(void* stream, const fs_conv_desc* d, const
     FS_CENSUS(FS_CENSUS_CONV_IGEMM | (stats ? FS_CENSUS_STATS : 0), d);
     // the last FS_WS_COUNTER_BYTES of every workspace are the (zero) arrival counters of the deterministic reductions: not scratch
     const long long ws_bytes = workspace_bytes > FS_WS_COUNTER_BYTES ? workspace_bytes - FS_WS_COUNTER_BYTES : 0;
-    if (d->dtype == FS_F32) dispatch<float>((hipStream_t)stream, a, g_force_cfg, (float*)workspace, ws_bytes);
-    else dispatch<bf16_t>((hipStream_t)stream, a, g_force_cfg, (float*)workspace, ws_bytes);
+    a.R = d->R; a.tiles_m = 0; a.slices = 1; a.slice_units = 0; a.n_major = 0;
+    for (int c = 0; c < 5; ++c) a.cls_start[c] = 0;
+    {
+        int slices = 1;
+        if (igemm2_launch((hipStream_t)stream, a, d->dtype, g_force_cfg, (float*)workspace, ws_bytes, t_defer_reduce, &slices)) {
+            if (t_defer_reduce) t_slices = slices;
+            return check_launch("fs_conv2d_fwd");
+        }
+    }
+    const int old_force = (g_force_cfg >= 100 || g_force_cfg < 0) ? -1 : g_force_cfg;       // igemm2 codes mean nothing to these kernels
+    if (d->dtype == FS_F32) dispatch<float>((hipStream_t)stream, a, old_force, (float*)workspace, ws_bytes);
+    else dispatch<bf16_t>((hipStream_t)stream, a, old_force, (float*)workspace, ws_bytes);
     return check_launch("fs_conv2d_fwd");
 }

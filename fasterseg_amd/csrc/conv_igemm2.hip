@@ -1,0 +1,483 @@
+// Implicit-GEMM convolution for the launch-latency-sized layers of the supernet and the small maps of the student (gfx950).
+//
+//   D[m][n] = sum_k A[m][k] * B[n][k]     m = output pixel, n = output channel, k = (tap, input channel) flattened
+//
+// Same contract as conv_igemm.hip (ConvArgs, epilogue, split-K slabs); what differs is how the operands reach the matrix cores.
+// The round-3 kernels staged global -> registers -> LDS with per-vector address arithmetic, bounds masks and 64-bit selects: the ISA of
+// the 32x32 K-split configuration issued 340 VALU instructions per K iteration for 16 gathers and 8 MFMAs, kept 240 VGPRs (2 waves per
+// SIMD) and re-read every operand row ~24 times through the L2.  Here:
+//   * operands go global -> LDS directly (`buffer_load_dwordx4 ... lds`, 1 KiB per wave instruction): no staging registers, no
+//     ds_write pass.  The buffer resource's range check supplies the zeros of padded taps, rows beyond M / Cout and the K tail: an
+//     invalid lane's offset is 0x80000000, which the hardware answers with zeros (no masks, no selects on the data);
+//   * a stage is 128 bytes of K per tile row (64 bf16 / 32 fp32): one full cache line per row, 8 lanes each; NSTAGE-deep LDS ring,
+//     counted `s_waitcnt vmcnt(N)` + ONE raw `s_barrier` per stage, loads of NSTAGE-1 stages always in flight;
+//   * the LDS image of a DMA is lane-linear (row pitch exactly 128 B), so bank conflicts of the ds_read_b128 fragment reads are
+//     removed on the SOURCE side: the lane that fills 16-byte slot s of row r fetches K chunk s ^ ((r >> 1) & 7), the reader applies the
+//     same XOR (16 rows of a lane group then cover all 16 slots of the two 256-byte bank rows they touch);
+//   * per stage a lane derives (tap, channel) of its chunk ONCE (all its rows share the chunk index), and the byte offset of
+//     (tile row, tap) comes from an LDS table filled once per block: ~8 VALU + 1 ds_read_b32 per 1 KiB moved;
+//   * 64x64 ... 128x128 block tiles (+ cross-block split-K into fp32 slabs for chip fill), 32x32 with the K loop split over the four
+//     waves only for the tiniest maps; workgroups are renumbered so that one XCD's L2 sees a contiguous range of tiles;
+//   * the data gradient of a stride-2 convolution (FS_CONV_TRANSPOSED) is evaluated per output-parity class: the rows of a tile all
+//     have the same (oh & 1, ow & 1), and only the taps that meet real (not zero-inserted) pixels are contracted - 1 / 2 / 2 / 4 of
+//     the 9 taps of a 3x3 filter instead of 9 (VERDICT r3 missing #3; what cuDNN's dgrad does for search/operations.py:149,298,467-473).
+//
+// Replaces: the same torch call sites as conv_igemm.hip (nn.Conv2d / F.conv2d forward and backward-input).
+#include "conv_igemm.h"
+
+namespace fs {
+
+constexpr unsigned OOB = 0x80000000u;          // byte offset no buffer resource below covers: the load returns zeros
+
+// the stage's DMA writes have landed (counted: N newer loads stay in flight) and this wave's own LDS reads of the previous stage
+// have returned, so the barrier that follows orders both against the other waves
+template <int N> __device__ __forceinline__ void wait_stage() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
+
+template <typename T, int WAVES_M, int WAVES_N, int WAVES_K, int WM_T, int WN_T, int NSTAGE>
+__global__ __launch_bounds__(256) void conv_igemm2_kernel(ConvArgs p) {
+    constexpr int ES = (int)sizeof(T);
+    constexpr int BM = WAVES_M * WM_T * 32;
+    constexpr int BN = WAVES_N * WN_T * 32;
+    constexpr int BKB = 128;                       // bytes of K per tile row per stage
+    constexpr int ROWS = BM + BN;
+    constexpr int STAGE_BYTES = ROWS * BKB;
+    constexpr int A_SLOTS = BM / 32, B_SLOTS = BN / 32, SLOTS = A_SLOTS + B_SLOTS;   // DMA instructions per wave per stage
+    constexpr int UNITS = BKB / 32;                // 32-byte MFMA k-units per stage
+    constexpr int KU = UNITS / WAVES_K;            // ... per wave
+    constexpr int TILES = WM_T * WN_T;
+    constexpr int TAPP = 9;                        // tap table pitch
+    static_assert(WAVES_M * WAVES_N * WAVES_K == 4 && KU >= 1, "4 waves per block");
+    constexpr int RING_BYTES = NSTAGE * STAGE_BYTES;
+    constexpr int RED_BYTES = (WAVES_K - 1) * WAVES_M * WAVES_N * TILES * 16 * 64 * 4;   // in-block split-K partials
+    constexpr int OUT_PITCH = 32 * ES + 16;
+    constexpr int OUT_BYTES = WAVES_M * WAVES_N * 32 * OUT_PITCH;                         // epilogue transpose
+    static_assert(RED_BYTES + OUT_BYTES <= RING_BYTES, "epilogue scratch overlays the ring");
+    constexpr int TAP_OFF = RING_BYTES;            // uint32 [BM][TAPP]: byte offset of (tile row, compact tap) in x, or OOB
+    constexpr int WTAP_OFF = TAP_OFF + BM * TAPP * 4;   // uint32 [12]: byte offset of a compact tap inside a filter row
+    constexpr int ROWM_OFF = WTAP_OFF + 48;        // int [BM]: output pixel index of a tile row, -1 beyond the map
+    constexpr int SMEM = ROWM_OFF + BM * 4;
+
+    // ONE shared array: hipcc drains vmcnt before every ds_read of a DMA pipeline as soon as a second __shared__ object exists
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
+    uint32_t* sTap = reinterpret_cast<uint32_t*>(smem + TAP_OFF);
+    uint32_t* sWtap = reinterpret_cast<uint32_t*>(smem + WTAP_OFF);
+    int* sRowM = reinterpret_cast<int*>(smem + ROWM_OFF);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wk = wave / (WAVES_M * WAVES_N);
+    const int wmn = wave % (WAVES_M * WAVES_N);
+    const int wm = wmn / WAVES_N;
+    const int wn = wmn % WAVES_N;
+
+    // ---- which tile / K slice: XCD-aware renumbering (workgroup b runs on XCD b % 8; speed only) ------------------------------
+    int tile_m, tile_n, slice;
+    {
+        const int nwg = (int)gridDim.x, bid = (int)blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        const int ntiles = p.tiles_m * p.tiles_n;
+        slice = logical / ntiles;
+        const int t = logical - slice * ntiles;
+        if (p.n_major) { tile_n = t / p.tiles_m; tile_m = t - tile_n * p.tiles_m; }
+        else { tile_m = t / p.tiles_n; tile_n = t - tile_m * p.tiles_n; }
+    }
+    const int n0 = tile_n * BN;
+    const bool classes = (p.flags & CONV_CLASSES) != 0;
+    const bool zero_insert = (p.flags & FS_CONV_TRANSPOSED) != 0 && !classes;      // legacy form: all taps, odd positions read zeros
+
+    // ---- per-block geometry ------------------------------------------------------------------------------------------------------
+    // class mode: this block's rows are the output pixels (oh, ow) with (oh & 1, ow & 1) = (ph, pw); taps th x tw are the ones whose
+    // zero-inserted position (o - pad + k) is even
+    int ph = 0, pw = 0, tile_c = tile_m, Hc = p.Ho, Wc = p.Wo, Mc = p.M;
+    int th = 0x24, tw = 0x24;                      // tap lists, 2 bits per entry ({0, 1, 2}); packed: runtime-indexed arrays go to scratch
+    int nth = p.R, ntw = p.S;
+    if (classes) {
+        int c = 0;
+#pragma unroll
+        for (int k = 1; k < 4; ++k) c += (tile_m >= p.cls_start[k]) ? 1 : 0;
+        ph = c >> 1; pw = c & 1;
+        tile_c = tile_m - p.cls_start[c];
+        Hc = (p.Ho - ph + 1) >> 1;
+        Wc = (p.Wo - pw + 1) >> 1;
+        Mc = (p.M / p.HoWo) * Hc * Wc;
+        nth = ntw = th = tw = 0;
+        for (int k = 0; k < p.R; ++k) if (((ph - p.pad + k) & 1) == 0) th |= k << (2 * nth++);
+        for (int k = 0; k < p.S; ++k) if (((pw - p.pad + k) & 1) == 0) tw |= k << (2 * ntw++);
+    }
+    const int ntaps = nth * ntw;
+    const int m0 = tile_c * BM;
+    const int CBU = p.Cin * ES / 16;               // 16-byte K units per tap
+    const int w_ts_bytes = (p.Cin + p.w_tgap) * ES;
+    const int KU_TOT = ntaps * CBU;
+    const int ku_lo = slice * p.slice_units;
+    const int ku_hi = (p.slices > 1 && ku_lo + p.slice_units < KU_TOT) ? ku_lo + p.slice_units : KU_TOT;
+    const int nsteps = ku_hi > ku_lo ? (ku_hi - ku_lo + 7) >> 3 : 0;
+
+    // ---- tables: 256 / BM threads per tile row; the row's pixel is decoded once, its taps are cheap ----------------------------------
+    {
+        constexpr int TPR = 256 / BM;
+        const int row = tid / TPR, sub = tid - row * TPR;
+        const int mi = m0 + row;
+        const bool rvalid = mi < Mc;
+        const int HW = Hc * Wc;
+        const int n = rvalid ? mi / HW : 0;
+        const int rem = mi - n * HW;
+        const int qh = rvalid ? rem / Wc : 0;
+        const int qw = rem - qh * Wc;
+        if (sub == 0) sRowM[row] = !rvalid ? -1 : classes ? (n * p.Ho + 2 * qh + ph) * p.Wo + 2 * qw + pw : mi;
+        const int ih0 = classes ? 2 * qh + ph - p.pad : qh * p.stride - p.pad;
+        const int iw0 = classes ? 2 * qw + pw - p.pad : qw * p.stride - p.pad;
+        const int tshift = (classes || zero_insert) ? 1 : 0;
+        for (int j = sub; j < ntaps; j += TPR) {
+            const int jh = ntw == 3 ? (j * 11) >> 5 : ntw == 2 ? j >> 1 : j;       // j / ntw for j < 9
+            const int jw = j - jh * ntw;
+            int ih = ih0 + ((th >> (2 * jh)) & 3);
+            int iw = iw0 + ((tw >> (2 * jw)) & 3);
+            bool ok = rvalid && (((ih | iw) & tshift) == 0);        // zero-inserted form: odd positions are the inserted zeros
+            ih >>= tshift;
+            iw >>= tshift;
+            ok = ok && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
+            sTap[row * TAPP + j] = ok ? (uint32_t)((((long long)n * p.H + ih) * p.W + iw) * p.x_cs * ES) : OOB;
+        }
+    }
+    if (tid < 9) {
+        uint32_t v = 0;
+        if (tid < ntaps) {
+            const int jh = ntw == 3 ? (tid * 11) >> 5 : ntw == 2 ? tid >> 1 : tid;
+            const int jw = tid - jh * ntw;
+            v = (uint32_t)((((th >> (2 * jh)) & 3) * p.S + ((tw >> (2 * jw)) & 3)) * w_ts_bytes);
+        }
+        sWtap[tid] = v;
+    }
+
+    // ---- DMA bookkeeping: lane -> (row within a 32-row slot, 16-byte slot), the K chunk it fetches ---------------------------------
+    const int lrow = wave * 8 + (lane >> 3);
+    const int swz = (lrow >> 1) & 7;                               // every 32-row slot has the same swizzle for this lane
+    const int chunk = (lane & 7) ^ swz;                            // logical 16-byte K chunk (0..7) of a stage this lane fetches
+    const unsigned cbu_magic = p.cin_magic;                        // ceil(2^32 / CBU): ku / CBU == umulhi(ku, magic) for ku < 2^16
+    uint32_t b_off[B_SLOTS];
+#pragma unroll
+    for (int b = 0; b < B_SLOTS; ++b) {
+        const int n = n0 + b * 32 + lrow;
+        const int nrow = n + ((p.n_seg > 0 && n >= p.n_seg) ? p.n_jump : 0);
+        b_off[b] = n < p.Cout ? (uint32_t)nrow * (uint32_t)(p.w_os * ES) : OOB;
+    }
+
+    // two-segment contraction: channel bytes >= kseg_eff of a tap are kjump_bytes further (never, when the filter is one array)
+    const int kseg_eff = p.k_seg > 0 ? p.k_seg * ES : 0x7fffffff;
+    const uint32_t kjump_bytes = (uint32_t)(p.k_jump * ES);
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0x7fffffff, 0x00020000);
+
+    // Straight-line on purpose (masks, no ?: on the offsets): a DMA under a divergent branch is split by hipcc into one instruction
+    // per exec half, which would make the number of vmcnt events per stage depend on the data.
+    auto issue = [&](int step, int buf) {
+        const int ku = ku_lo + step * 8 + chunk;
+        const uint32_t valid = (uint32_t)((ku - ku_hi) >> 31);      // all ones while ku < ku_hi
+        const int tap = (int)(__umulhi((unsigned)ku, cbu_magic) & valid);
+        const uint32_t cb = (uint32_t)(ku - tap * CBU) * 16u;      // byte offset inside the tap's channel run
+        const uint32_t jump = kjump_bytes & (uint32_t)((kseg_eff - 1 - (int)cb) >> 31);
+        const uint32_t wt = sWtap[tap] + cb + jump;
+        unsigned char* dst = smem + buf * STAGE_BYTES + wave * 1024;
+#pragma unroll
+        for (int a = 0; a < A_SLOTS; ++a) {
+            const uint32_t t = sTap[(a * 32 + lrow) * TAPP + tap];
+            const uint32_t off = ((t + cb) & valid) | (OOB & ~valid);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(dst + a * 4096), 16, off, 0, 0, 0);
+        }
+#pragma unroll
+        for (int b = 0; b < B_SLOTS; ++b) {
+            const uint32_t off = ((b_off[b] + wt) & valid) | (OOB & ~valid);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(dst + (A_SLOTS + b) * 4096), 16, off, 0, 0,
+                                                     0);
+        }
+    };
+
+    f32x16 acc[WM_T][WN_T];
+#pragma unroll
+    for (int i = 0; i < WM_T; ++i)
+#pragma unroll
+        for (int j = 0; j < WN_T; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment addresses: lane reads row (lane & 31) of its tile, logical chunk 2 * unit + (lane >> 5), at the swizzled slot
+    const int frow = lane & 31;
+    const int fsw = (frow >> 1) & 7;
+    uint32_t a_frag[WM_T], b_frag[WN_T];
+#pragma unroll
+    for (int i = 0; i < WM_T; ++i) a_frag[i] = (uint32_t)(((wm * WM_T + i) * 32 + frow) * BKB);
+#pragma unroll
+    for (int j = 0; j < WN_T; ++j) b_frag[j] = (uint32_t)((BM + (wn * WN_T + j) * 32 + frow) * BKB);
+    uint32_t f_slot[KU];
+#pragma unroll
+    for (int kk = 0; kk < KU; ++kk) f_slot[kk] = (uint32_t)((((wk * KU + kk) * 2 + (lane >> 5)) ^ fsw) * 16);
+
+    __syncthreads();                                               // tables visible (no DMA in flight yet)
+
+    // ---- pipeline ----------------------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s)
+        if (s < nsteps) issue(s, s);
+    int buf = 0;
+    for (int t = 0; t < nsteps; ++t) {
+        // stages t .. min(t + NSTAGE - 2, nsteps - 1) are in flight; stage t must have landed (loads return in order)
+        const int after = nsteps - 1 - t;
+        if (after >= NSTAGE - 2) wait_stage<(NSTAGE - 2) * SLOTS>();
+        else if (NSTAGE > 3 && after == 1) wait_stage<SLOTS>();
+        else if (NSTAGE > 4 && after == 2) wait_stage<2 * SLOTS>();
+        else wait_stage<0>();
+        __builtin_amdgcn_s_barrier();                              // every wave's part of stage t is in LDS; stage t - 1 is drained
+        asm volatile("" ::: "memory");
+        if (t + NSTAGE - 1 < nsteps) issue(t + NSTAGE - 1, buf == 0 ? NSTAGE - 1 : buf - 1);
+        const unsigned char* st = smem + buf * STAGE_BYTES;
+        u32x4 af[KU][WM_T], bfr[KU][WN_T];                         // all fragment reads of the stage in flight before the first MFMA
+#pragma unroll
+        for (int kk = 0; kk < KU; ++kk) {
+#pragma unroll
+            for (int i = 0; i < WM_T; ++i) af[kk][i] = *reinterpret_cast<const u32x4*>(st + a_frag[i] + f_slot[kk]);
+#pragma unroll
+            for (int j = 0; j < WN_T; ++j) bfr[kk][j] = *reinterpret_cast<const u32x4*>(st + b_frag[j] + f_slot[kk]);
+        }
+#pragma unroll
+        for (int kk = 0; kk < KU; ++kk)
+#pragma unroll
+            for (int i = 0; i < WM_T; ++i)
+#pragma unroll
+                for (int j = 0; j < WN_T; ++j) Mma<T>::run(af[kk][i], bfr[kk][j], acc[i][j]);
+        buf = buf + 1 == NSTAGE ? 0 : buf + 1;
+    }
+    wait_stage<0>();
+    __syncthreads();                                               // ring drained: its memory becomes epilogue scratch
+
+    // ---- in-block split-K reduction ------------------------------------------------------------------------------------------------
+    if (WAVES_K > 1) {
+        float* red = reinterpret_cast<float*>(smem);
+        if (wk > 0) {
+#pragma unroll
+            for (int i = 0; i < WM_T; ++i)
+#pragma unroll
+                for (int j = 0; j < WN_T; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        red[((((wk - 1) * WAVES_M * WAVES_N + wmn) * TILES + i * WN_T + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (wk == 0) {
+#pragma unroll
+            for (int q = 0; q < WAVES_K - 1; ++q)
+#pragma unroll
+                for (int i = 0; i < WM_T; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN_T; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            acc[i][j][r] += red[(((q * WAVES_M * WAVES_N + wmn) * TILES + i * WN_T + j) * 16 + r) * 64 + lane];
+        }
+    }
+    if (wk != 0) return;
+
+    if (p.slices > 1) {        // partial tile of this K slice; scale / shift / ReLU / statistics are applied by the slab reduction
+        float* part = p.ws + (long long)slice * p.M * p.Cout;
+#pragma unroll
+        for (int j = 0; j < WN_T; ++j) {
+            const int co = n0 + (wn * WN_T + j) * 32 + (lane & 31);
+#pragma unroll
+            for (int i = 0; i < WM_T; ++i) {
+                const int rbase = (wm * WM_T + i) * 32;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = sRowM[rbase + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
+                    if (m >= 0 && co < p.Cout) part[(long long)m * p.Cout + co] = acc[i][j][r];
+                }
+            }
+        }
+        return;
+    }
+
+    // ---- epilogue (conv_igemm.hip's, with the tile-row -> pixel map) -----------------------------------------------------------------
+    const bool relu = (p.flags & FS_CONV_RELU) != 0;
+    const bool accum = (p.flags & FS_CONV_ACCUM) != 0;
+    T* y = reinterpret_cast<T*>(p.y);
+    unsigned char* sOut = smem + RED_BYTES + wmn * 32 * OUT_PITCH;
+    constexpr int LPR = 32 * ES / 16;                      // lanes (16-byte vectors) per output row: 4 bf16 / 8 fp32
+    constexpr int RPP = 64 / LPR;                          // rows per store pass
+#pragma unroll
+    for (int j = 0; j < WN_T; ++j) {
+        const int cbase = n0 + (wn * WN_T + j) * 32;
+        const int co = cbase + (lane & 31);
+        const bool cvalid = co < p.Cout;
+        const float sc = (p.scale && cvalid) ? p.scale[co] : 1.f;
+        const float sh = (p.shift && cvalid) ? p.shift[co] : 0.f;
+        const bool full_n = (cbase + 32 <= p.Cout) && !accum && !(p.flags & CONV_SCALAR_STORE);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < WM_T; ++i) {
+            const int rbase = (wm * WM_T + i) * 32;
+            if (full_n) {
+                // registers -> LDS (row = pixel, col = channel) -> 16-byte global stores
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const float v = acc[i][j][r];
+                    s1 += v;
+                    s2 += v * v;
+                    float o = v * sc + sh;
+                    if (relu) o = fmaxf(o, 0.f);
+                    Elem<T>::store(reinterpret_cast<T*>(sOut + row * OUT_PITCH) + (lane & 31), o);
+                }
+                __builtin_amdgcn_wave_barrier();           // DS ops of one wave execute in order; keep the compiler from reordering
+#pragma unroll
+                for (int ps = 0; ps < 32 / RPP; ++ps) {
+                    const int row = ps * RPP + lane / LPR;
+                    const int seg = lane % LPR;
+                    const int m = sRowM[rbase + row];
+                    if (m >= 0)
+                        stg16(y + (long long)m * p.y_cs + cbase + seg * (16 / ES), *reinterpret_cast<const u32x4*>(sOut + row * OUT_PITCH + seg * 16));
+                }
+                __builtin_amdgcn_wave_barrier();
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const int m = sRowM[rbase + row];
+                    const float v = acc[i][j][r];
+                    s1 += v;
+                    s2 += v * v;
+                    if (m >= 0 && cvalid) {
+                        float o = v * sc + sh;
+                        T* dst = y + (long long)m * p.y_cs + co;
+                        if (accum) o += Elem<T>::load(dst);
+                        if (relu) o = fmaxf(o, 0.f);
+                        Elem<T>::store(dst, o);
+                    }
+                }
+            }
+        }
+        if (p.stats) {   // rows beyond M and the K tail contribute exact zeros
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (lane < 32 && cvalid) {
+                atomicAdd(p.stats + co, s1);
+                atomicAdd(p.stats + p.Cout + co, s2);
+            }
+        }
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------------------
+struct Cfg2 {
+    int bm, bn;
+};
+static const Cfg2 CFG2[] = {{64, 64}, {128, 64}, {64, 128}, {128, 128}, {32, 32}, {64, 32}, {32, 64}};
+constexpr int NCFG2 = (int)(sizeof(CFG2) / sizeof(CFG2[0]));
+
+template <typename T> static void launch2(hipStream_t st, const ConvArgs& a, int cfg, int grid) {
+    switch (cfg) {
+        case 0: FS_LAUNCH((conv_igemm2_kernel<T, 2, 2, 1, 1, 1, 4>), dim3((unsigned)grid), dim3(256), 0, st, a); break;    // 64 x 64
+        case 1: FS_LAUNCH((conv_igemm2_kernel<T, 2, 2, 1, 2, 1, 4>), dim3((unsigned)grid), dim3(256), 0, st, a); break;    // 128 x 64
+        case 2: FS_LAUNCH((conv_igemm2_kernel<T, 2, 2, 1, 1, 2, 4>), dim3((unsigned)grid), dim3(256), 0, st, a); break;    // 64 x 128
+        case 3: FS_LAUNCH((conv_igemm2_kernel<T, 2, 2, 1, 2, 2, 3>), dim3((unsigned)grid), dim3(256), 0, st, a); break;    // 128 x 128
+        case 4: FS_LAUNCH((conv_igemm2_kernel<T, 1, 1, 4, 1, 1, 4>), dim3((unsigned)grid), dim3(256), 0, st, a); break;    // 32 x 32, K over 4 waves
+        case 5: FS_LAUNCH((conv_igemm2_kernel<T, 2, 1, 2, 1, 1, 4>), dim3((unsigned)grid), dim3(256), 0, st, a); break;    // 64 x 32, K over 2 waves
+        default: FS_LAUNCH((conv_igemm2_kernel<T, 1, 2, 2, 1, 1, 4>), dim3((unsigned)grid), dim3(256), 0, st, a); break;   // 32 x 64, K over 2 waves
+    }
+}
+
+static int g_igemm2_mode = [] { const char* e = getenv("FS_IGEMM2"); return e ? atoi(e) : 1; }();   // 0: never, 1: heuristic
+static int g_igemm2_slices = [] { const char* e = getenv("FS_IGEMM2_SLICES"); return e ? atoi(e) : 0; }();   // > 0: force a slice count
+
+bool igemm2_launch(hipStream_t st, ConvArgs& a, int dtype, int force_cfg, float* ws, long long ws_bytes, bool defer_reduce, int* slices_out) {
+    // force_cfg: -1 heuristic; -2 conv_igemm.hip's heuristic (this kernel off); 0..99 conv_igemm.hip's configurations; 100 + c forces
+    // configuration c of CFG2 and 1000 * s + 100 + c additionally s K slices (s = 1: no split) - tests and tools/conv_sweep.py
+    if (slices_out) *slices_out = 1;
+    if (force_cfg == -2 || (force_cfg >= 0 && force_cfg < 100)) return false;
+    const int force_slices = force_cfg >= 1000 ? force_cfg / 1000 : 0;
+    if (force_cfg >= 1000) force_cfg %= 1000;
+    if (force_cfg < 0 && g_igemm2_mode == 0) return false;
+    const int es = elem_size(dtype);
+    if (a.vr_H > 0 || (a.flags & CONV_BIG_OPERANDS) || a.k_jump < 0 || a.n_jump < 0) return false;
+    if ((a.Cin * es) % 16 != 0 || a.R * a.S > 9) return false;
+    const bool transposed = (a.flags & FS_CONV_TRANSPOSED) != 0;
+    if ((long long)a.Cin * es * a.R * a.S / 16 >= 65536) return false;
+    int cfg;
+    if (force_cfg >= 100) {
+        cfg = force_cfg - 100;
+        if (cfg >= NCFG2) return false;
+    } else {
+        // heuristic: the largest tile whose block count (with split-K where allowed) still covers the chip
+        const long long b64 = (long long)((a.M + 63) / 64) * ((a.Cout + 63) / 64);
+        if (a.Cout <= 32) cfg = a.M >= 64 * 256 ? 5 : 4;
+        else if (b64 >= 1024 && a.Cout >= 128 && a.M >= 128 * 64) cfg = 3;
+        else if (b64 >= 512 && a.M >= 4096) cfg = 1;
+        else if (b64 >= 512 && a.Cout >= 256) cfg = 2;
+        else cfg = 0;
+    }
+    const int bm = CFG2[cfg].bm, bn = CFG2[cfg].bn;
+    a.tiles_n = (a.Cout + bn - 1) / bn;
+    const int batch = a.M / a.HoWo;
+    int flags = a.flags;
+    if (transposed) {          // exact stride-2 data gradient: one group of tiles per output-parity class
+        flags |= CONV_CLASSES;
+        int acc = 0;
+        for (int c = 0; c < 4; ++c) {
+            const int ph = c >> 1, pw = c & 1;
+            const long long mc = (long long)batch * ((a.Ho - ph + 1) / 2) * ((a.Wo - pw + 1) / 2);
+            a.cls_start[c] = acc;
+            acc += (int)((mc + bm - 1) / bm);
+        }
+        a.cls_start[4] = acc;
+        a.tiles_m = acc;
+    } else {
+        a.tiles_m = (a.M + bm - 1) / bm;
+        for (int c = 0; c < 5; ++c) a.cls_start[c] = 0;
+    }
+    const long long ntiles = (long long)a.tiles_m * a.tiles_n;
+    // cross-block split-K: fp32 slabs [slices][M][Cout] in the caller's workspace, summed by splitk_reduce / the BatchNorm kernel
+    const int cbu = a.Cin * es / 16;
+    const int steps = (a.R * a.S * cbu + 7) / 8;
+    int slices = 1;
+    const bool can_split = ws && !transposed && !(a.flags & (FS_CONV_ACCUM | CONV_SCALAR_STORE)) && a.Cout % (16 / es) == 0 &&
+                           a.Cout / (16 / es) <= 256;
+    if (can_split) {
+        if (force_slices > 0) slices = force_slices;
+        else if (g_igemm2_slices > 0) slices = g_igemm2_slices;
+        else if (ntiles < 192 && steps >= 8) {
+            slices = (int)((384 + ntiles - 1) / ntiles);
+            if (slices > steps / 4) slices = steps / 4;            // at least four stages per slice
+        }
+        if (slices > steps) slices = steps;
+        if (slices < 1) slices = 1;
+        while (slices > 1 && (long long)slices * a.M * a.Cout * 4 > ws_bytes) --slices;
+    }
+    a.slices = slices;
+    a.slice_units = slices > 1 ? (steps + slices - 1) / slices * 8 : 0;
+    if (slices > 1) {          // no empty trailing slice
+        slices = (steps * 8 + a.slice_units - 1) / a.slice_units;
+        a.slices = slices;
+    }
+    a.ws = slices > 1 ? ws : nullptr;
+    a.k_slice = 0;
+    const unsigned saved_magic = a.cin_magic;
+    a.cin_magic = (unsigned)(((1ull << 32) + (unsigned)cbu - 1) / (unsigned)cbu);
+    a.n_major = (9ll * a.Cout > a.M) ? 1 : 0;
+    const int saved_flags = a.flags;
+    a.flags = flags;
+    const int grid = (int)(ntiles * slices);
+    if (dtype == FS_F32) launch2<float>(st, a, cfg, grid);
+    else launch2<bf16_t>(st, a, cfg, grid);
+    a.flags = saved_flags;
+    a.cin_magic = saved_magic;
+    if (slices > 1) {
+        if (defer_reduce) {
+            if (slices_out) *slices_out = slices;
+        } else {
+            launch_splitk_reduce(st, a, dtype, ws, slices);
+        }
+    }
+    return true;
+}
+
+}  // namespace fs

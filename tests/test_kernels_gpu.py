@@ -75,7 +75,10 @@ def force_cfg(request):
     _lib.lib().fs_debug_force_conv_cfg(-1)
 
 
-@pytest.mark.parametrize("force_cfg", [-1, 0, 1, 2, 3, 4, 5, 6, 7], indirect=True, ids=lambda c: "cfg%d" % c)
+# -1: production heuristic (conv_igemm2.hip where it qualifies); -2: conv_igemm.hip's heuristic alone; 0..7: its configurations;
+# 100..106: conv_igemm2.hip's configurations; 1000 * s + 100 + c: with s K slices (fp32 slabs + reduce launch)
+@pytest.mark.parametrize("force_cfg", [-1, -2, 0, 1, 2, 3, 4, 5, 6, 7, 100, 101, 102, 103, 104, 105, 106, 3100, 2104], indirect=True,
+                         ids=lambda c: "cfg%d" % c)
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=[str(c) for c in CONV_CASES])
 def test_conv2d_fwd(case, dtype, force_cfg):
@@ -228,6 +231,41 @@ def test_conv2d_dgrad_and_wgrad(case, dtype):
         float((got - ref).abs().max()), float(ref.abs().max()))
     if Cp != Cout:
         assert float(gw[Cout:].abs().max()) == 0.0
+
+
+S2_DGRAD_CASES = [
+    # N, Cin, H, W, Cout, k, stride, pad   (forward geometry; dx has the size of x)
+    (2, 32, 12, 16, 64, 3, 2, 1),
+    (1, 48, 9, 13, 32, 3, 2, 1),          # odd map: the four parity classes have different sizes
+    (1, 16, 1, 7, 24, 3, 2, 1),           # one row: the odd-row classes are empty
+    (2, 64, 8, 12, 32, 1, 2, 0),          # FactorizedReduce conv_1 (operations.py:521): only even pixels receive a gradient
+    (2, 64, 8, 12, 32, 1, 2, -1),         # conv_2 on x[:, :, 1:, 1:] (:523): only odd pixels do
+    (1, 64, 7, 9, 40, 1, 2, -1),
+    (3, 96, 32, 64, 192, 3, 2, 1),        # a stride-2 MixedOp of the supernet at 1/8 scale, fused pair (2 x 96 output channels)
+]
+
+
+@pytest.mark.parametrize("force_cfg", [-1, -2, 100, 101, 102, 104, 105, 106], indirect=True, ids=lambda c: "cfg%d" % c)
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", S2_DGRAD_CASES, ids=[str(c) for c in S2_DGRAD_CASES])
+def test_stride2_dgrad_by_parity_classes(case, dtype, force_cfg):
+    """FS_CONV_TRANSPOSED through conv_igemm2.hip: the data gradient of a stride-2 convolution evaluated per output-parity class (only
+    the taps that meet real pixels: 1 / 2 / 2 / 4 of 9) equals autograd's input gradient - and the zero-insertion form of
+    conv_igemm.hip (cfg -2).  Every pixel of dx is written (classes without any tap get zeros)."""
+    k = K()
+    N, Cin, H, W, Cout, ks, stride, pad = case
+    x = q(rnd(N, Cin, H, W, seed=11), dtype).requires_grad_(True)
+    w = q(rnd(Cout, Cin, ks, ks, seed=12, scale=0.2), dtype)
+    y = ref_conv(x, w, stride, pad)
+    dy = q(rnd(*y.shape, seed=13), dtype)
+    y.backward(dy)
+    dyd = k.to_nhwc(dy.cuda(), dtype)
+    wf = k.pack_weight(w.cuda(), dtype, flip=True)
+    dx = k.empty_nhwc(N, Cin, H, W, dtype, "cuda")
+    dx.fill_(float("nan"))
+    k.conv2d(dyd, wf, Cin, ks, ks, 1, ks - 1 - pad, transposed=True, out_hw=(H, W), out=dx)
+    assert bool(torch.isfinite(dx.float()).all()), "some pixel of dx was not written"
+    check(dx, x.grad, dtype, "stride-2 dgrad")
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
@@ -442,7 +480,7 @@ def test_weighted_sum_fwd_bwd_dots(dtype, n):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
-@pytest.mark.parametrize("cfg", [-1, 3, 5, 6, 7])
+@pytest.mark.parametrize("cfg", [-1, -2, 3, 5, 6, 7, 100, 101, 104, 2102])
 def test_conv_two_segment_filter_bank_and_contraction(dtype, cfg):
     """fs_conv_desc.n_seg / n_jump (output channels >= n_seg read filter rows n_jump further: two filter banks as one GEMM) and
     k_seg / k_jump (input channels >= k_seg of every tap are k_jump elements further: the data gradient of the fused pair over both
@@ -482,7 +520,7 @@ def test_conv_two_segment_filter_bank_and_contraction(dtype, cfg):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
-@pytest.mark.parametrize("cfg", [-1, 0, 3, 5, 6, 7])
+@pytest.mark.parametrize("cfg", [-1, -2, 0, 3, 5, 6, 7, 100, 103, 105, 106])
 def test_conv_reads_filter_block_of_wider_pack(dtype, cfg):
     """fs_conv_desc.w_os / w_ts: the [:cout][..][:cin] block of a full-size packed bank read in place equals the densely
     re-packed slice (USConv2d widths, slimmable_ops.py:42), forward and flipped (data-gradient) banks."""
