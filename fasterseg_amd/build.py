@@ -59,6 +59,9 @@ def build(force=False, verbose=True):
             print("built", LIB)
     elif verbose:
         print("up to date:", LIB)
+    # undefined symbols (a kernel whose host stub hipcc dropped, a missing object) must fail HERE, not at first use on the GPU box
+    import ctypes
+    ctypes.CDLL(LIB, mode=os.RTLD_NOW)
     return LIB
 
 

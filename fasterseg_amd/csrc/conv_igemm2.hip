@@ -33,7 +33,12 @@ constexpr unsigned OOB = 0x80000000u;          // byte offset no buffer resource
 // have returned, so the barrier that follows orders both against the other waves
 template <int N> __device__ __forceinline__ void wait_stage() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
 
-template <typename T, int WAVES_M, int WAVES_N, int WAVES_K, int WM_T, int WN_T, int NSTAGE>
+template <int KU, int WM_T, int WN_T> struct Frags2 {   // MFMA operand fragments of one stage
+    u32x4 a[KU][WM_T], b[KU][WN_T];
+};
+
+// ABL (measurement builds only, tools/conv_sweep.py): 0 the kernel; 1 no fragment reads / MFMAs; 2 no DMA; 3 no K loop at all
+template <typename T, int WAVES_M, int WAVES_N, int WAVES_K, int WM_T, int WN_T, int NSTAGE, int ABL = 0>
 __global__ __launch_bounds__(256) void conv_igemm2_kernel(ConvArgs p) {
     constexpr int ES = (int)sizeof(T);
     constexpr int BM = WAVES_M * WM_T * 32;
@@ -113,7 +118,7 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(ConvArgs p) {
     const int KU_TOT = ntaps * CBU;
     const int ku_lo = slice * p.slice_units;
     const int ku_hi = (p.slices > 1 && ku_lo + p.slice_units < KU_TOT) ? ku_lo + p.slice_units : KU_TOT;
-    const int nsteps = ku_hi > ku_lo ? (ku_hi - ku_lo + 7) >> 3 : 0;
+    const int nsteps = (ku_hi > ku_lo && ABL != 3) ? (ku_hi - ku_lo + 7) >> 3 : 0;
 
     // ---- tables: 256 / BM threads per tile row; the row's pixel is decoded once, its taps are cheap ----------------------------------
     {
@@ -173,25 +178,33 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(ConvArgs p) {
 
     // Straight-line on purpose (masks, no ?: on the offsets): a DMA under a divergent branch is split by hipcc into one instruction
     // per exec half, which would make the number of vmcnt events per stage depend on the data.
-    auto issue = [&](int step, int buf) {
+    // gen(step): the byte offsets of this lane's SLOTS loads of a stage - derived one stage AHEAD of their use, so that the tap-table
+    // reads and the address arithmetic are off the barrier -> DMA -> fragment-read -> MFMA chain of the loop.
+    uint32_t off_a[A_SLOTS], off_b[B_SLOTS];       // captured arrays (a struct parameter here keeps hipcc from emitting the kernel's host stub)
+    auto gen = [&](int step) {
         const int ku = ku_lo + step * 8 + chunk;
         const uint32_t valid = (uint32_t)((ku - ku_hi) >> 31);      // all ones while ku < ku_hi
-        const int tap = (int)(__umulhi((unsigned)ku, cbu_magic) & valid);
+        const int tap = (int)((CBU == 1 ? (unsigned)ku : __umulhi((unsigned)ku, cbu_magic)) & valid);
         const uint32_t cb = (uint32_t)(ku - tap * CBU) * 16u;      // byte offset inside the tap's channel run
         const uint32_t jump = kjump_bytes & (uint32_t)((kseg_eff - 1 - (int)cb) >> 31);
         const uint32_t wt = sWtap[tap] + cb + jump;
+#pragma unroll
+        for (int a = 0; a < A_SLOTS; ++a) off_a[a] = ((sTap[(a * 32 + lrow) * TAPP + tap] + cb) & valid) | (OOB & ~valid);
+#pragma unroll
+        for (int b = 0; b < B_SLOTS; ++b) off_b[b] = ((b_off[b] + wt) & valid) | (OOB & ~valid);
+    };
+    auto fire = [&](int buf) {
+        if (ABL == 2) return;
         unsigned char* dst = smem + buf * STAGE_BYTES + wave * 1024;
 #pragma unroll
         for (int a = 0; a < A_SLOTS; ++a) {
-            const uint32_t t = sTap[(a * 32 + lrow) * TAPP + tap];
-            const uint32_t off = ((t + cb) & valid) | (OOB & ~valid);
+            const uint32_t off = off_a[a];         // (an array element as the builtin's argument makes hipcc drop the kernel's host stub - silently)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(dst + a * 4096), 16, off, 0, 0, 0);
         }
 #pragma unroll
         for (int b = 0; b < B_SLOTS; ++b) {
-            const uint32_t off = ((b_off[b] + wt) & valid) | (OOB & ~valid);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(dst + (A_SLOTS + b) * 4096), 16, off, 0, 0,
-                                                     0);
+            const uint32_t off = off_b[b];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(dst + (A_SLOTS + b) * 4096), 16, off, 0, 0, 0);
         }
     };
 
@@ -218,36 +231,79 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(ConvArgs p) {
     __syncthreads();                                               // tables visible (no DMA in flight yet)
 
     // ---- pipeline ----------------------------------------------------------------------------------------------------------------
-#pragma unroll
-    for (int s = 0; s < NSTAGE - 1; ++s)
-        if (s < nsteps) issue(s, s);
-    int buf = 0;
-    for (int t = 0; t < nsteps; ++t) {
-        // stages t .. min(t + NSTAGE - 2, nsteps - 1) are in flight; stage t must have landed (loads return in order)
-        const int after = nsteps - 1 - t;
-        if (after >= NSTAGE - 2) wait_stage<(NSTAGE - 2) * SLOTS>();
-        else if (NSTAGE > 3 && after == 1) wait_stage<SLOTS>();
-        else if (NSTAGE > 4 && after == 2) wait_stage<2 * SLOTS>();
-        else wait_stage<0>();
-        __builtin_amdgcn_s_barrier();                              // every wave's part of stage t is in LDS; stage t - 1 is drained
-        asm volatile("" ::: "memory");
-        if (t + NSTAGE - 1 < nsteps) issue(t + NSTAGE - 1, buf == 0 ? NSTAGE - 1 : buf - 1);
+    // NSTAGE ring buffers; the fragments of the stage being multiplied live in registers (two sets, swapped every stage), so a buffer
+    // is free as soon as every wave has READ it and NSTAGE stages are in flight behind the one in registers.  Per stage: one counted
+    // wait + one raw barrier, then the DMA of stage t + NSTAGE (offsets precomputed), the fragment reads of stage t + 1 and the MFMAs
+    // of stage t - the LDS latency of the reads hides under the MFMAs.
+    typedef Frags2<KU, WM_T, WN_T> Frags;
+    auto read_frags = [&](Frags& f, int buf) {
+        if (ABL == 1) return;
         const unsigned char* st = smem + buf * STAGE_BYTES;
-        u32x4 af[KU][WM_T], bfr[KU][WN_T];                         // all fragment reads of the stage in flight before the first MFMA
 #pragma unroll
         for (int kk = 0; kk < KU; ++kk) {
 #pragma unroll
-            for (int i = 0; i < WM_T; ++i) af[kk][i] = *reinterpret_cast<const u32x4*>(st + a_frag[i] + f_slot[kk]);
+            for (int i = 0; i < WM_T; ++i) f.a[kk][i] = *reinterpret_cast<const u32x4*>(st + a_frag[i] + f_slot[kk]);
 #pragma unroll
-            for (int j = 0; j < WN_T; ++j) bfr[kk][j] = *reinterpret_cast<const u32x4*>(st + b_frag[j] + f_slot[kk]);
+            for (int j = 0; j < WN_T; ++j) f.b[kk][j] = *reinterpret_cast<const u32x4*>(st + b_frag[j] + f_slot[kk]);
         }
+    };
+    auto mma = [&](const Frags& f) {
+        if (ABL == 1) return;
 #pragma unroll
         for (int kk = 0; kk < KU; ++kk)
 #pragma unroll
             for (int i = 0; i < WM_T; ++i)
 #pragma unroll
-                for (int j = 0; j < WN_T; ++j) Mma<T>::run(af[kk][i], bfr[kk][j], acc[i][j]);
-        buf = buf + 1 == NSTAGE ? 0 : buf + 1;
+                for (int j = 0; j < WN_T; ++j) Mma<T>::run(f.a[kk][i], f.b[kk][j], acc[i][j]);
+    };
+    // stage `first` must have landed while `newer` = min(NSTAGE - 2, stages issued after it) stay in flight (loads return in order)
+    auto wait_landed = [&](int newer) {
+        if (newer >= NSTAGE - 2) wait_stage<(NSTAGE - 2) * SLOTS>();
+        else if (NSTAGE > 3 && newer == 1) wait_stage<SLOTS>();
+        else if (NSTAGE > 4 && newer == 2) wait_stage<2 * SLOTS>();
+        else if (NSTAGE > 5 && newer == 3) wait_stage<3 * SLOTS>();
+        else wait_stage<0>();
+    };
+#pragma unroll
+    for (int s = 0; s < NSTAGE; ++s)
+        if (s < nsteps) {
+            gen(s);
+            fire(s);
+        }
+    if (NSTAGE < nsteps) gen(NSTAGE);
+    Frags f0, f1;
+    if (nsteps > 0) {
+        // stages 0 .. min(NSTAGE, nsteps) - 1 are in flight; stage 0 first
+        const int newer = (nsteps < NSTAGE ? nsteps : NSTAGE) - 1;
+        if (newer >= NSTAGE - 1) wait_stage<(NSTAGE - 1) * SLOTS>();
+        else wait_landed(newer);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        read_frags(f0, 0);
+    }
+    // one pipeline step: `cur` holds stage t, `nxt` receives stage t + 1
+    auto step = [&](const Frags& cur, Frags& nxt, int t, int buf_t) {
+        const bool more = t + 1 < nsteps;
+        if (more) {
+            wait_landed(nsteps - 2 - t);                           // stage t + 1 landed; up to NSTAGE - 2 newer ones stay in flight
+            __builtin_amdgcn_s_barrier();                          // ... in every wave, and every wave holds stage t in registers
+            asm volatile("" ::: "memory");
+            if (t + NSTAGE < nsteps) fire(buf_t);            // stage t's buffer is free
+            read_frags(nxt, buf_t + 1 == NSTAGE ? 0 : buf_t + 1);
+        }
+        mma(cur);
+        if (t + NSTAGE + 1 < nsteps) gen(t + NSTAGE + 1);
+    };
+    {
+        int buf = 0;
+        int t = 0;
+        for (; t + 1 < nsteps; t += 2) {
+            step(f0, f1, t, buf);
+            buf = buf + 1 == NSTAGE ? 0 : buf + 1;
+            step(f1, f0, t + 1, buf);
+            buf = buf + 1 == NSTAGE ? 0 : buf + 1;
+        }
+        if (t < nsteps) step(f0, f1, t, buf);
     }
     wait_stage<0>();
     __syncthreads();                                               // ring drained: its memory becomes epilogue scratch
@@ -371,7 +427,7 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(ConvArgs p) {
 struct Cfg2 {
     int bm, bn;
 };
-static const Cfg2 CFG2[] = {{64, 64}, {128, 64}, {64, 128}, {128, 128}, {32, 32}, {64, 32}, {32, 64}};
+static const Cfg2 CFG2[] = {{64, 64}, {128, 64}, {64, 128}, {128, 128}, {32, 32}, {64, 32}, {32, 64}, {32, 32}, {64, 64}};
 constexpr int NCFG2 = (int)(sizeof(CFG2) / sizeof(CFG2[0]));
 
 template <typename T> static void launch2(hipStream_t st, const ConvArgs& a, int cfg, int grid) {
@@ -381,8 +437,16 @@ template <typename T> static void launch2(hipStream_t st, const ConvArgs& a, int
         case 2: FS_LAUNCH((conv_igemm2_kernel<T, 2, 2, 1, 1, 2, 4>), dim3((unsigned)grid), dim3(256), 0, st, a); break;    // 64 x 128
         case 3: FS_LAUNCH((conv_igemm2_kernel<T, 2, 2, 1, 2, 2, 3>), dim3((unsigned)grid), dim3(256), 0, st, a); break;    // 128 x 128
         case 4: FS_LAUNCH((conv_igemm2_kernel<T, 1, 1, 4, 1, 1, 4>), dim3((unsigned)grid), dim3(256), 0, st, a); break;    // 32 x 32, K over 4 waves
+        case 20: FS_LAUNCH((conv_igemm2_kernel<T, 2, 2, 1, 1, 1, 4, 1>), dim3((unsigned)grid), dim3(256), 0, st, a); break;   // ablations of 64 x 64
+        case 21: FS_LAUNCH((conv_igemm2_kernel<T, 2, 2, 1, 1, 1, 4, 2>), dim3((unsigned)grid), dim3(256), 0, st, a); break;
+        case 22: FS_LAUNCH((conv_igemm2_kernel<T, 2, 2, 1, 1, 1, 4, 3>), dim3((unsigned)grid), dim3(256), 0, st, a); break;
+        case 23: FS_LAUNCH((conv_igemm2_kernel<T, 1, 1, 4, 1, 1, 4, 1>), dim3((unsigned)grid), dim3(256), 0, st, a); break;   // ... of 32 x 32 K4
+        case 24: FS_LAUNCH((conv_igemm2_kernel<T, 1, 1, 4, 1, 1, 4, 2>), dim3((unsigned)grid), dim3(256), 0, st, a); break;
+        case 25: FS_LAUNCH((conv_igemm2_kernel<T, 1, 1, 4, 1, 1, 4, 3>), dim3((unsigned)grid), dim3(256), 0, st, a); break;
         case 5: FS_LAUNCH((conv_igemm2_kernel<T, 2, 1, 2, 1, 1, 4>), dim3((unsigned)grid), dim3(256), 0, st, a); break;    // 64 x 32, K over 2 waves
-        default: FS_LAUNCH((conv_igemm2_kernel<T, 1, 2, 2, 1, 1, 4>), dim3((unsigned)grid), dim3(256), 0, st, a); break;   // 32 x 64, K over 2 waves
+        case 6: FS_LAUNCH((conv_igemm2_kernel<T, 1, 2, 2, 1, 1, 4>), dim3((unsigned)grid), dim3(256), 0, st, a); break;    // 32 x 64, K over 2 waves
+        case 7: FS_LAUNCH((conv_igemm2_kernel<T, 1, 1, 4, 1, 1, 8>), dim3((unsigned)grid), dim3(256), 0, st, a); break;    // 32 x 32, K over 4 waves, 8 stages
+        default: FS_LAUNCH((conv_igemm2_kernel<T, 2, 2, 1, 1, 1, 6>), dim3((unsigned)grid), dim3(256), 0, st, a); break;   // 64 x 64, 6 stages
     }
 }
 
@@ -402,22 +466,59 @@ bool igemm2_launch(hipStream_t st, ConvArgs& a, int dtype, int force_cfg, float*
     if ((a.Cin * es) % 16 != 0 || a.R * a.S > 9) return false;
     const bool transposed = (a.flags & FS_CONV_TRANSPOSED) != 0;
     if ((long long)a.Cin * es * a.R * a.S / 16 >= 65536) return false;
-    int cfg;
+    const int batch = a.M / a.HoWo;
+    const int cbu = a.Cin * es / 16;
+    const int taps = a.R * a.S;
+    const int steps = (taps * cbu + 7) / 8;                       // 128-byte stages of the whole contraction
+    const bool can_split = ws && !transposed && !(a.flags & (FS_CONV_ACCUM | CONV_SCALAR_STORE)) && a.Cout % (16 / es) == 0 &&
+                           a.Cout / (16 / es) <= 256;
+    // tiles along M of a block height (class mode: summed over the four output-parity classes)
+    auto tiles_m_of = [&](int bm) {
+        if (!transposed) return (a.M + bm - 1) / bm;
+        int acc = 0;
+        for (int c = 0; c < 4; ++c) acc += (int)(((long long)batch * ((a.Ho - (c >> 1) + 1) / 2) * ((a.Wo - (c & 1) + 1) / 2) + bm - 1) / bm);
+        return acc;
+    };
+    int cfg, slices = 1;
     if (force_cfg >= 100) {
         cfg = force_cfg - 100;
-        if (cfg >= NCFG2) return false;
+        if (cfg >= NCFG2 && !(cfg >= 20 && cfg <= 25)) return false;
+        if (can_split) {
+            if (force_slices > 0) slices = force_slices;
+            else if (g_igemm2_slices > 0) slices = g_igemm2_slices;
+        }
     } else {
-        // heuristic: the largest tile whose block count (with split-K where allowed) still covers the chip
-        const long long b64 = (long long)((a.M + 63) / 64) * ((a.Cout + 63) / 64);
-        if (a.Cout <= 32) cfg = a.M >= 64 * 256 ? 5 : 4;
-        else if (b64 >= 1024 && a.Cout >= 128 && a.M >= 128 * 64) cfg = 3;
-        else if (b64 >= 512 && a.M >= 4096) cfg = 1;
-        else if (b64 >= 512 && a.Cout >= 256) cfg = 2;
-        else cfg = 0;
+        // Cost model fitted to tools/conv_sweep.py on MI355X (tools/fit_igemm2.py; mean regret 2 % against the best measured
+        // configuration over the supernet's and the student's small-map geometries).  What the measurements say (profiles/r04_igemm2_*):
+        // a block's fixed cost is ~3.3 us; the operand fill (L2 -> LDS) runs at ~35 bytes / clock / CU whatever the tile, so the loop
+        // time is the staged bytes over that rate (a lone block per CU: its own stage time); fp32 adds the 1/16-rate MFMA term; a K split
+        // pays a reduce launch (unless the BatchNorm kernel sums the slabs) and (slices + 1) passes over the fp32 slabs.
+        struct Model { double t0, a, bw, mf, ts, bws, ovl; };
+        static const Model MB = {3.28, 2.41, 9.4, 0.25, 1.18, 1.95, 0.21}, MF = {3.36, 5.07, 18.5, 3.02, 1.65, 0.93, 0.98};
+        const Model& m = es == 4 ? MF : MB;
+        static const int cand[4] = {0, 4, 5, 6};
+        const double S = transposed ? 0.25 * steps : (double)steps;             // parity classes contract 2.25 of 9 taps on average
+        double best = 1e30;
+        cfg = 0;
+        for (int ci = 0; ci < 4; ++ci) {
+            const int bm = CFG2[cand[ci]].bm, bn = CFG2[cand[ci]].bn;
+            const double tiles = (double)tiles_m_of(bm) * ((a.Cout + bn - 1) / bn);
+            for (int sl = 1; sl <= 8; sl *= 2) {
+                if (sl > 1 && (!can_split || steps / sl < 2 || (long long)sl * a.M * a.Cout * 4 > ws_bytes)) break;
+                const double st = (S + sl - 1) / sl, rows = bm + bn, share = tiles * sl > 256 ? tiles * sl / 256.0 : 1.0;
+                double fill = st * rows * m.a * 1e-3;
+                const double chip = tiles * S * rows * 128 / (m.bw * 1e6);
+                if (chip > fill) fill = chip;
+                const double mfma = st * (bm * bn / 32.0) * (es == 4 ? 8.0 : 1.0) / 2400.0 * m.mf * share;
+                double t = m.t0 + (fill > mfma ? fill + m.ovl * mfma : mfma + m.ovl * fill);
+                if (sl > 1) t += (defer_reduce ? 0.3 : m.ts) + (sl + 1.0) * a.M * a.Cout * 4 / (m.bws * 1e6);
+                else if (a.stats) t += 0.012 * (a.M / 32);                      // epilogue statistics: M / 32 float atomics per channel
+                if (t < best) { best = t; cfg = cand[ci]; slices = sl; }
+            }
+        }
     }
-    const int bm = CFG2[cfg].bm, bn = CFG2[cfg].bn;
+    const int bm = cfg >= 23 ? 32 : cfg >= 20 ? 64 : CFG2[cfg].bm, bn = cfg >= 23 ? 32 : cfg >= 20 ? 64 : CFG2[cfg].bn;
     a.tiles_n = (a.Cout + bn - 1) / bn;
-    const int batch = a.M / a.HoWo;
     int flags = a.flags;
     if (transposed) {          // exact stride-2 data gradient: one group of tiles per output-parity class
         flags |= CONV_CLASSES;
@@ -436,22 +537,9 @@ bool igemm2_launch(hipStream_t st, ConvArgs& a, int dtype, int force_cfg, float*
     }
     const long long ntiles = (long long)a.tiles_m * a.tiles_n;
     // cross-block split-K: fp32 slabs [slices][M][Cout] in the caller's workspace, summed by splitk_reduce / the BatchNorm kernel
-    const int cbu = a.Cin * es / 16;
-    const int steps = (a.R * a.S * cbu + 7) / 8;
-    int slices = 1;
-    const bool can_split = ws && !transposed && !(a.flags & (FS_CONV_ACCUM | CONV_SCALAR_STORE)) && a.Cout % (16 / es) == 0 &&
-                           a.Cout / (16 / es) <= 256;
-    if (can_split) {
-        if (force_slices > 0) slices = force_slices;
-        else if (g_igemm2_slices > 0) slices = g_igemm2_slices;
-        else if (ntiles < 192 && steps >= 8) {
-            slices = (int)((384 + ntiles - 1) / ntiles);
-            if (slices > steps / 4) slices = steps / 4;            // at least four stages per slice
-        }
-        if (slices > steps) slices = steps;
-        if (slices < 1) slices = 1;
-        while (slices > 1 && (long long)slices * a.M * a.Cout * 4 > ws_bytes) --slices;
-    }
+    if (slices > steps) slices = steps;
+    if (slices < 1) slices = 1;
+    while (slices > 1 && (long long)slices * a.M * a.Cout * 4 > ws_bytes) --slices;
     a.slices = slices;
     a.slice_units = slices > 1 ? (steps + slices - 1) / slices * 8 : 0;
     if (slices > 1) {          // no empty trailing slice

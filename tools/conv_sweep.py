@@ -36,7 +36,7 @@ FWD = [(6, 384, 768, 8, 16), (6, 384, 384, 8, 16), (6, 384, 768, 4, 8), (6, 384,
        (1, 192, 128, 64, 128)]
 # stride-2 forward geometries (N, cin, cout, H, W of the INPUT): their data gradients are the s2 set
 S2 = [(3, 96, 384, 32, 64), (3, 192, 768, 16, 32), (6, 96, 192, 32, 64), (3, 32, 128, 32, 64)]
-CFGS2 = [100, 101, 102, 103, 104, 105, 106]
+CFGS2 = [int(c) for c in os.environ.get("FS_SWEEP_CFGS2", "100,101,102,103,104,105,106").split(",")]
 SLICES = [1, 2, 4, 8]
 
 
