@@ -56,6 +56,12 @@ def recording(level=1):
 
 
 def conv_flops(d):
+    """ALGORITHMIC multiply-adds x 2.  A FS_CONV_TRANSPOSED descriptor is the data gradient of a stride-2 convolution written as a
+    stride-1 convolution over the zero-inserted grid (N x Ho x Wo output pixels, (H, W) = the forward OUTPUT map): its algorithmic work
+    is the forward convolution's, 2 N H W Cin Cout R S - not the 4x larger dense count of the zero-inserted geometry;
+    conv_igemm2.hip executes exactly these (parity classes), conv_igemm.hip's zero-insertion form executes 4x as many on zeros."""
+    if d.flags & FS_CONV_TRANSPOSED:
+        return 2.0 * d.N * d.H * d.W * d.Cout * d.Cin * d.R * d.S
     return 2.0 * d.N * d.Ho * d.Wo * d.Cout * d.Cin * d.R * d.S
 
 
@@ -110,7 +116,9 @@ def time_entry(family, d, device="cuda"):
         w = (torch.randn(n, device=device) * 0.05).to(dt)
         return _graph_time_ms(lambda st: call("fs_conv3x3_s1_fwd", st, ctypes.byref(dd), K._p(x), K._p(w), None, None, K._p(y), K._p(stats)))
     rows = max(d.w_os, d.R * d.S * max(d.w_ts, d.Cin)) if d.w_os else d.R * d.S * d.Cin
-    w = (torch.randn(d.Cout * rows, device=device) * 0.05).to(dt)
+    # two-segment descriptors (fused pairs) read filter rows n_jump further / k_jump elements further: size the bank for them
+    n_rows = d.Cout + (max(d.n_jump, 0) if d.n_seg > 0 else 0)
+    w = (torch.randn(n_rows * rows + (abs(d.k_jump) if d.k_seg > 0 else 0), device=device) * 0.05).to(dt)
     ws = torch.empty(K.WORKSPACE_BYTES, dtype=torch.uint8, device=device)
     return _graph_time_ms(lambda st: call("fs_conv2d_fwd_ws", st, ctypes.byref(dd), K._p(x), K._p(w), None, None, K._p(y), K._p(stats),
                                           K._p(ws), K.WORKSPACE_BYTES))

@@ -30,6 +30,7 @@ struct Pending {
     int kernel;                  // index into g_names
     int tag;                     // caller's tag at launch time (fs_census_tag), -1: none
     fs_census_entry* entry;      // geometry entry the launch belongs to (or null)
+    int group;                   // grouped launch: index into g_groups (its time is shared out over several entries), -1: none
 };
 
 std::recursive_mutex g_mutex;                        // autograd runs backward on its own thread
@@ -40,6 +41,8 @@ std::vector<KernelAcc> g_kernels;
 std::vector<Pending> g_pending;
 std::vector<std::pair<hipEvent_t, hipEvent_t>> g_free;
 thread_local fs_census_entry* t_scope = nullptr;
+thread_local int t_group = -1;
+std::vector<std::vector<std::pair<fs_census_entry*, double>>> g_groups;     // (entry, share of the launch's duration)
 std::map<int, KernelAcc> g_tags;
 int g_tag = -1;
 constexpr size_t MAX_PENDING = 8192;                 // harvest (one stream sync) when this many launches are outstanding
@@ -59,6 +62,8 @@ void harvest() {
         if (hipEventSynchronize(p.e1) == hipSuccess && hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
             g_kernels[p.kernel].ms += ms;
             if (p.entry) p.entry->ms += ms;
+            if (p.group >= 0)
+                for (auto& es : g_groups[p.group]) es.first->ms += ms * es.second;
             if (p.tag >= 0) {
                 KernelAcc& t = g_tags[p.tag];
                 t.count += 1;
@@ -70,9 +75,35 @@ void harvest() {
         g_free.emplace_back(p.e0, p.e1);
     }
     g_pending.clear();
+    g_groups.clear();
 }
 
 }  // namespace
+
+// One launch that serves several (family, geometry) entries: each is counted once and receives `share[i]` of the measured duration
+CensusGroupScope::CensusGroupScope(int family, const fs_conv_desc* const* d, const double* share, int n) : live(false) {
+    if (!g_census_on) return;
+    std::lock_guard<std::recursive_mutex> lock(g_mutex);
+    std::vector<std::pair<fs_census_entry*, double>> grp;
+    for (int i = 0; i < n; ++i) {
+        fs_census_entry e;
+        memset(&e, 0, sizeof(e));
+        e.family = family;
+        e.desc = *d[i];
+        std::string key((const char*)&e, sizeof(int) + sizeof(fs_conv_desc));
+        auto it = g_census.find(key);
+        if (it == g_census.end()) it = g_census.emplace(key, e).first;
+        it->second.count += 1;
+        grp.emplace_back(&it->second, share[i]);
+    }
+    g_groups.push_back(grp);
+    t_group = (int)g_groups.size() - 1;
+    live = true;
+}
+
+CensusGroupScope::~CensusGroupScope() {
+    if (live) t_group = -1;
+}
 
 CensusScope::CensusScope(int family, const fs_conv_desc* d) : live(false) {
     if (!g_census_on) return;
@@ -124,7 +155,7 @@ bool census_events(const char* kernel, hipStream_t stream, hipEvent_t* start, hi
         k = it->second;
     }
     g_kernels[k].count += 1;
-    g_pending.push_back(Pending{ev.first, ev.second, k, g_tag, t_scope});
+    g_pending.push_back(Pending{ev.first, ev.second, k, g_tag, t_scope, t_group});
     *start = ev.first;
     *stop = ev.second;
     return true;

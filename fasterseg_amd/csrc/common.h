@@ -48,6 +48,11 @@ struct CensusScope {          // every FS_LAUNCH issued while the scope lives is
     CensusScope(int family, const fs_conv_desc* d);
     ~CensusScope();
 };
+struct CensusGroupScope {     // a grouped launch: n entries counted, the launch's measured time shared out by `share`
+    bool live;
+    CensusGroupScope(int family, const fs_conv_desc* const* d, const double* share, int n);
+    ~CensusGroupScope();
+};
 bool census_events(const char* kernel, hipStream_t stream, hipEvent_t* start, hipEvent_t* stop);
 #define FS_CENSUS(family, d) fs::CensusScope fs_census_scope_((family), (d))
 #define FS_LAUNCH(kernel, grid, block, shmem, stream, ...)                                                      \
@@ -64,6 +69,24 @@ bool census_events(const char* kernel, hipStream_t stream, hipEvent_t* start, hi
 // `workspace` ([*slices][M][Cout] fp32, y untouched) and the caller sums them (fs_bn_group_fwd does); *slices == 1: y is written.
 fs_status conv_fwd_deferred(void* stream, const fs_conv_desc* d, const void* x, const void* w_packed, void* y, void* workspace,
                             long long workspace_bytes, int* slices);
+
+// wgrad.hip: n fs_conv2d_wgrad_ws calls as one launch (program.hip's lockstep executor)
+fs_status wgrad_launch_group(void* stream, int n, const fs_conv_desc* const* d, const void* const* x, const void* const* dy, float* const* dw,
+                             const long long* o_stride, const long long* i_stride, const long long* t_stride, void* workspace,
+                             long long workspace_bytes);
+
+// units.hip: the arguments of fs_conv_bn_act_train_fwd / _bwd as records, and n of them executed with grouped convolution launches
+struct UnitFwdCall {
+    const fs_conv_desc* d; const void* x; const void* w; const float* gamma; const float* beta; float* running_mean; float* running_var;
+    long long* num_batches_tracked; float eps, momentum; float* stats; float* saved; void* z; void* y; void* ws; long long ws_bytes;
+};
+struct UnitBwdCall {
+    const fs_conv_desc* d; const void* x; const void* w_flip; const void* z; const void* y; const void* dy; int dy_cs; const float* saved;
+    const float* gamma; float* red; float* dgamma_acc; float* dbeta_acc; void* dz; float* dw; long long o_stride, i_stride, t_stride;
+    void* dx; int dx_cs, wf_os, wf_ts; void* ws; long long ws_bytes;
+};
+fs_status unit_fwd_group(void* stream, const UnitFwdCall* u, int n);
+fs_status unit_bwd_group(void* stream, const UnitBwdCall* u, int n);
 
 // `relu` argument of the BatchNorm kernels: bit 0 = apply ReLU, bits 8.. = the first channel it applies to (0: every channel);
 // forward kernels: bit 1 = num_batches_tracked points at TWO adjacent counters (the two BatchNorm modules of a fused pair).

@@ -60,6 +60,20 @@ constexpr int CONV_BIG_OPERANDS = 0x200;   // internal flag: x or the filter ban
 // conv_igemm.hip's configurations).  ws / ws_bytes: cross-block split-K scratch (may be null); *slices_out receives the slice count
 // when defer_reduce leaves the partial slabs to the caller.
 bool igemm2_launch(hipStream_t st, ConvArgs& a, int dtype, int force_cfg, float* ws, long long ws_bytes, bool defer_reduce, int* slices_out);
+// conv_igemm2.hip: n qualifying convolutions of one dtype as ONE launch (every workgroup finds its problem in the kernel arguments);
+// false when some problem does not qualify (nothing launched)
+bool igemm2_group_launch(hipStream_t st, ConvArgs* a, int n, int dtype);
+bool igemm2_group_ok(const ConvArgs* a, int n, int dtype);
+// conv_igemm.hip: validation + kernel arguments of a conv call; grouped launch with per-problem fallback
+fs_status conv_prepare(const fs_conv_desc* d, const void* x, const void* w_packed, const float* scale, const float* shift, void* y,
+                       float* stats, ConvArgs* out);
+fs_status conv_launch_group(void* stream, const fs_conv_desc* const* descs, ConvArgs* args, int n);
+constexpr int FS_MAX_GROUP = 8;          // problems per grouped launch (their arguments travel as kernel arguments: < 4 KB)
+struct ConvGroupArgs {
+    int n;
+    int blk_start[FS_MAX_GROUP + 1];     // first workgroup of every problem, [n] = grid size
+    ConvArgs p[FS_MAX_GROUP];
+};
 // conv_igemm.hip: second pass of a cross-block split-K conv (sum of the slabs, scale / shift / ReLU, BN statistics)
 void launch_splitk_reduce(hipStream_t st, const ConvArgs& a, int dtype, float* ws, int slices);
 

@@ -650,12 +650,10 @@ extern "C" fs_status fs_conv2d_fwd(void* stream, const fs_conv_desc* d, const vo
     return fs_conv2d_fwd_ws(stream, d, x, w_packed, scale, shift, y, stats, nullptr, 0);
 }
 
-extern "C" fs_status fs_conv2d_fwd_ws(void* stream, const fs_conv_desc* d, const void* x, const void* w_packed,
-                                      const float* scale, const float* shift, void* y, float* stats, void* workspace,
-                                      long long workspace_bytes) {
+// Validation of a conv call + its kernel arguments (shared by fs_conv2d_fwd_ws and the grouped launches of program.hip)
+fs_status fs::conv_prepare(const fs_conv_desc* d, const void* x, const void* w_packed, const float* scale, const float* shift, void* y,
+                           float* stats, ConvArgs* out) {
     FS_REQUIRE(d && x && w_packed && y, FS_ERR_INVALID, "fs_conv2d_fwd: null argument");
-    FS_REQUIRE(workspace == nullptr || (aligned16(workspace) && workspace_bytes >= 0), FS_ERR_INVALID,
-               "fs_conv2d_fwd_ws: workspace must be 16-byte aligned");
     FS_REQUIRE(d->dtype == FS_F32 || d->dtype == FS_BF16, FS_ERR_INVALID, "fs_conv2d_fwd: bad dtype %d", d->dtype);
     const int vec = vec_elems(d->dtype);
     FS_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->Ho > 0 && d->Wo > 0, FS_ERR_INVALID,
@@ -676,7 +674,7 @@ extern "C" fs_status fs_conv2d_fwd_ws(void* stream, const fs_conv_desc* d, const
     FS_REQUIRE(d->R * d->S * d->Cin < (1 << 16), FS_ERR_UNSUPPORTED, "fs_conv2d_fwd: K = R*S*Cin too large");
     FS_REQUIRE(M < (1ll << 31) && (long long)d->N * d->H * d->W * d->x_cs < (1ll << 40), FS_ERR_UNSUPPORTED,
                "fs_conv2d_fwd: tensor too large");
-    ConvArgs a;
+    ConvArgs& a = *out;
     a.x = (const unsigned char*)x;
     a.w = (const unsigned char*)w_packed;
     a.y = (unsigned char*)y;
@@ -728,11 +726,23 @@ extern "C" fs_status fs_conv2d_fwd_ws(void* stream, const fs_conv_desc* d, const
     }
     // 16-byte epilogue stores need an aligned slice; otherwise every tile takes the element-wise path
     if (!(aligned16(y) && (d->y_cs % vec == 0))) a.flags |= CONV_SCALAR_STORE;
+    a.R = d->R; a.tiles_m = 0; a.slices = 1; a.slice_units = 0; a.n_major = 0;
+    a.ws = nullptr; a.k_slice = 0;
+    for (int c = 0; c < 5; ++c) a.cls_start[c] = 0;
+    return FS_OK;
+}
+
+extern "C" fs_status fs_conv2d_fwd_ws(void* stream, const fs_conv_desc* d, const void* x, const void* w_packed,
+                                      const float* scale, const float* shift, void* y, float* stats, void* workspace,
+                                      long long workspace_bytes) {
+    FS_REQUIRE(workspace == nullptr || (aligned16(workspace) && workspace_bytes >= 0), FS_ERR_INVALID,
+               "fs_conv2d_fwd_ws: workspace must be 16-byte aligned");
+    ConvArgs a;
+    const fs_status ps = conv_prepare(d, x, w_packed, scale, shift, y, stats, &a);
+    if (ps != FS_OK) return ps;
     FS_CENSUS(FS_CENSUS_CONV_IGEMM | (stats ? FS_CENSUS_STATS : 0), d);
     // the last FS_WS_COUNTER_BYTES of every workspace are the (zero) arrival counters of the deterministic reductions: not scratch
     const long long ws_bytes = workspace_bytes > FS_WS_COUNTER_BYTES ? workspace_bytes - FS_WS_COUNTER_BYTES : 0;
-    a.R = d->R; a.tiles_m = 0; a.slices = 1; a.slice_units = 0; a.n_major = 0;
-    for (int c = 0; c < 5; ++c) a.cls_start[c] = 0;
     {
         int slices = 1;
         if (igemm2_launch((hipStream_t)stream, a, d->dtype, g_force_cfg, (float*)workspace, ws_bytes, t_defer_reduce, &slices)) {
@@ -743,5 +753,33 @@ extern "C" fs_status fs_conv2d_fwd_ws(void* stream, const fs_conv_desc* d, const
     const int old_force = (g_force_cfg >= 100 || g_force_cfg < 0) ? -1 : g_force_cfg;       // igemm2 codes mean nothing to these kernels
     if (d->dtype == FS_F32) dispatch<float>((hipStream_t)stream, a, old_force, (float*)workspace, ws_bytes);
     else dispatch<bf16_t>((hipStream_t)stream, a, old_force, (float*)workspace, ws_bytes);
+    return check_launch("fs_conv2d_fwd");
+}
+
+// n independent convolutions as ONE launch (conv_igemm2.hip's grouped kernel) when every one of them qualifies, else one launch each.
+// No split-K (the group fills the chip), statistics epilogue / scale / shift / ReLU as in the single launch.
+fs_status fs::conv_launch_group(void* stream, const fs_conv_desc* const* descs, ConvArgs* args, int n) {
+    if (n <= 0) return FS_OK;
+    static const bool no_group = getenv("FS_GROUP_NOCONV") != nullptr;          // (debugging aid: grouped convolutions off)
+    bool same = n > 1 && !no_group && g_force_cfg != -2 && !(g_force_cfg >= 0 && g_force_cfg < 100);
+    for (int i = 1; i < n && same; ++i) same = descs[i]->dtype == descs[0]->dtype;
+    if (same && igemm2_group_ok(args, n, descs[0]->dtype)) {
+        double share[FS_MAX_GROUP], total = 0;
+        for (int i = 0; i < n; ++i) {          // a problem's share of the launch = its share of the multiply-adds
+            share[i] = (double)args[i].M * args[i].Cout * args[i].K * ((args[i].flags & FS_CONV_TRANSPOSED) ? 0.25 : 1.0);
+            total += share[i];
+        }
+        for (int i = 0; i < n; ++i) share[i] /= total;
+        CensusGroupScope scope(FS_CENSUS_CONV_IGEMM, descs, share, n);
+        if (igemm2_group_launch((hipStream_t)stream, args, n, descs[0]->dtype)) return check_launch("fs_conv2d_fwd (group)");
+    }
+    for (int i = 0; i < n; ++i) {
+        ConvArgs& a = args[i];
+        FS_CENSUS(FS_CENSUS_CONV_IGEMM | (a.stats ? FS_CENSUS_STATS : 0), descs[i]);
+        if (igemm2_launch((hipStream_t)stream, a, descs[i]->dtype, g_force_cfg, nullptr, 0, false, nullptr)) continue;
+        const int old_force = (g_force_cfg >= 100 || g_force_cfg < 0) ? -1 : g_force_cfg;
+        if (descs[i]->dtype == FS_F32) dispatch<float>((hipStream_t)stream, a, old_force, nullptr, 0);
+        else dispatch<bf16_t>((hipStream_t)stream, a, old_force, nullptr, 0);
+    }
     return check_launch("fs_conv2d_fwd");
 }

@@ -39,7 +39,7 @@ template <int KU, int WM_T, int WN_T> struct Frags2 {   // MFMA operand fragment
 
 // ABL (measurement builds only, tools/conv_sweep.py): 0 the kernel; 1 no fragment reads / MFMAs; 2 no DMA; 3 no K loop at all
 template <typename T, int WAVES_M, int WAVES_N, int WAVES_K, int WM_T, int WN_T, int NSTAGE, int ABL = 0>
-__global__ __launch_bounds__(256) void conv_igemm2_kernel(ConvArgs p) {
+__device__ __forceinline__ void igemm2_body(const ConvArgs& p, const int bid, const int nwg) {
     constexpr int ES = (int)sizeof(T);
     constexpr int BM = WAVES_M * WM_T * 32;
     constexpr int BN = WAVES_N * WN_T * 32;
@@ -79,7 +79,6 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(ConvArgs p) {
     // ---- which tile / K slice: XCD-aware renumbering (workgroup b runs on XCD b % 8; speed only) ------------------------------
     int tile_m, tile_n, slice;
     {
-        const int nwg = (int)gridDim.x, bid = (int)blockIdx.x;
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
         const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
         const int ntiles = p.tiles_m * p.tiles_n;
@@ -423,6 +422,25 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(ConvArgs p) {
     }
 }
 
+template <typename T, int WAVES_M, int WAVES_N, int WAVES_K, int WM_T, int WN_T, int NSTAGE, int ABL = 0>
+__global__ __launch_bounds__(256) void conv_igemm2_kernel(ConvArgs p) {
+    igemm2_body<T, WAVES_M, WAVES_N, WAVES_K, WM_T, WN_T, NSTAGE, ABL>(p, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Grouped form: n independent convolutions in ONE launch.  A supernet layer is ~6 MixedOps x 4 convolutions of 100 - 600 workgroups
+// and ~10 us each, and the step is the SUM of its kernel durations (dependent launches do not overlap, each pays ~4 us of ramp-up /
+// drain + boundary whatever its size): the launch programs of a layer's MixedOps are replayed in lockstep (program.hip) and the
+// convolutions at the same position go out together - the problems' arguments travel as kernel arguments, a workgroup finds its
+// problem with a scalar search over the block prefix and runs the single-problem body on its local block id.
+template <typename T, int WAVES_M, int WAVES_N, int WAVES_K, int WM_T, int WN_T, int NSTAGE>
+__global__ __launch_bounds__(256) void conv_igemm2_group_kernel(ConvGroupArgs g) {
+    const int bid = (int)blockIdx.x;
+    int i = 0;
+#pragma unroll
+    for (int k = 1; k < FS_MAX_GROUP; ++k) i += (k < g.n && bid >= g.blk_start[k]) ? 1 : 0;
+    igemm2_body<T, WAVES_M, WAVES_N, WAVES_K, WM_T, WN_T, NSTAGE, 0>(g.p[i], bid - g.blk_start[i], g.blk_start[i + 1] - g.blk_start[i]);
+}
+
 // ---- host side ---------------------------------------------------------------------------------------------------------------------
 struct Cfg2 {
     int bm, bn;
@@ -453,6 +471,101 @@ template <typename T> static void launch2(hipStream_t st, const ConvArgs& a, int
 static int g_igemm2_mode = [] { const char* e = getenv("FS_IGEMM2"); return e ? atoi(e) : 1; }();   // 0: never, 1: heuristic
 static int g_igemm2_slices = [] { const char* e = getenv("FS_IGEMM2_SLICES"); return e ? atoi(e) : 0; }();   // > 0: force a slice count
 
+template <typename T> static void launch2_group(hipStream_t st, const ConvGroupArgs& g, int cfg, int grid) {
+    switch (cfg) {
+        case 0: FS_LAUNCH((conv_igemm2_group_kernel<T, 2, 2, 1, 1, 1, 4>), dim3((unsigned)grid), dim3(256), 0, st, g); break;    // 64 x 64
+        case 4: FS_LAUNCH((conv_igemm2_group_kernel<T, 1, 1, 4, 1, 1, 4>), dim3((unsigned)grid), dim3(256), 0, st, g); break;    // 32 x 32, K over 4 waves
+        case 5: FS_LAUNCH((conv_igemm2_group_kernel<T, 2, 1, 2, 1, 1, 4>), dim3((unsigned)grid), dim3(256), 0, st, g); break;    // 64 x 32, K over 2 waves
+        default: FS_LAUNCH((conv_igemm2_group_kernel<T, 1, 2, 2, 1, 1, 4>), dim3((unsigned)grid), dim3(256), 0, st, g); break;   // 32 x 64, K over 2 waves
+    }
+}
+
+// geometries the kernel takes (the others stay with conv_igemm.hip: virtual resize, operands of 2 GiB and more, negative segment jumps)
+static bool igemm2_qualifies(const ConvArgs& a, int es) {
+    if (a.vr_H > 0 || (a.flags & CONV_BIG_OPERANDS) || a.k_jump < 0 || a.n_jump < 0) return false;
+    if ((a.Cin * es) % 16 != 0 || a.R * a.S > 9) return false;
+    if ((long long)a.Cin * es * a.R * a.S / 16 >= 65536) return false;
+    return true;
+}
+
+static int igemm2_tiles_m(const ConvArgs& a, int bm) {          // class mode: summed over the four output-parity classes
+    if (!(a.flags & FS_CONV_TRANSPOSED)) return (a.M + bm - 1) / bm;
+    const int batch = a.M / a.HoWo;
+    int acc = 0;
+    for (int c = 0; c < 4; ++c) acc += (int)(((long long)batch * ((a.Ho - (c >> 1) + 1) / 2) * ((a.Wo - (c & 1) + 1) / 2) + bm - 1) / bm);
+    return acc;
+}
+
+// fills the launch fields of `a` for tile (bm, bn) and `slices` K slices; returns the number of workgroups
+static int igemm2_configure(ConvArgs& a, int es, int bm, int bn, int slices, float* ws) {
+    const int cbu = a.Cin * es / 16;
+    const int steps = (a.R * a.S * cbu + 7) / 8;
+    a.tiles_n = (a.Cout + bn - 1) / bn;
+    if (a.flags & FS_CONV_TRANSPOSED) {          // exact stride-2 data gradient: one group of tiles per output-parity class
+        const int batch = a.M / a.HoWo;
+        a.flags |= CONV_CLASSES;
+        int acc = 0;
+        for (int c = 0; c < 4; ++c) {
+            const long long mc = (long long)batch * ((a.Ho - (c >> 1) + 1) / 2) * ((a.Wo - (c & 1) + 1) / 2);
+            a.cls_start[c] = acc;
+            acc += (int)((mc + bm - 1) / bm);
+        }
+        a.cls_start[4] = acc;
+        a.tiles_m = acc;
+    } else {
+        a.tiles_m = (a.M + bm - 1) / bm;
+        for (int c = 0; c < 5; ++c) a.cls_start[c] = 0;
+    }
+    if (slices > steps) slices = steps;
+    if (slices < 1) slices = 1;
+    a.slice_units = slices > 1 ? (steps + slices - 1) / slices * 8 : 0;
+    if (slices > 1) slices = (steps * 8 + a.slice_units - 1) / a.slice_units;          // no empty trailing slice
+    a.slices = slices;
+    a.ws = slices > 1 ? ws : nullptr;
+    a.k_slice = 0;
+    a.cin_magic = (unsigned)(((1ull << 32) + (unsigned)cbu - 1) / (unsigned)cbu);
+    a.n_major = (9ll * a.Cout > a.M) ? 1 : 0;
+    return a.tiles_m * a.tiles_n * slices;
+}
+
+bool igemm2_group_ok(const ConvArgs* a, int n, int dtype) {
+    if (n < 2 || n > FS_MAX_GROUP || g_igemm2_mode == 0) return false;
+    const int es = elem_size(dtype);
+    for (int i = 0; i < n; ++i)
+        if (!igemm2_qualifies(a[i], es) || (a[i].flags & FS_CONV_ACCUM)) return false;
+    return true;
+}
+
+bool igemm2_group_launch(hipStream_t st, ConvArgs* a, int n, int dtype) {
+    if (!igemm2_group_ok(a, n, dtype)) return false;
+    const int es = elem_size(dtype);
+    // one tile shape for the whole group: the one that stages the fewest bytes (the group fills the chip, the fill rate is the bound)
+    static const int cand[4] = {0, 5, 6, 4};
+    int cfg = 0;
+    double best = 1e300;
+    for (int ci = 0; ci < 4; ++ci) {
+        const int bm = CFG2[cand[ci]].bm, bn = CFG2[cand[ci]].bn;
+        double bytes = 0;
+        for (int i = 0; i < n; ++i) {
+            const double steps = (a[i].R * a[i].S * (a[i].Cin * es / 16) + 7) / 8 * ((a[i].flags & FS_CONV_TRANSPOSED) ? 0.25 : 1.0);
+            bytes += (double)igemm2_tiles_m(a[i], bm) * ((a[i].Cout + bn - 1) / bn) * (steps + 6.0) * (bm + bn);     // + 6: a block's fixed cost
+        }
+        if (bytes < best) { best = bytes; cfg = cand[ci]; }
+    }
+    ConvGroupArgs grp;
+    grp.n = n;
+    int grid = 0;
+    for (int i = 0; i < n; ++i) {
+        grp.p[i] = a[i];
+        grp.blk_start[i] = grid;
+        grid += igemm2_configure(grp.p[i], es, CFG2[cfg].bm, CFG2[cfg].bn, 1, nullptr);
+    }
+    for (int i = n; i <= FS_MAX_GROUP; ++i) grp.blk_start[i] = grid;
+    if (dtype == FS_F32) launch2_group<float>(st, grp, cfg, grid);
+    else launch2_group<bf16_t>(st, grp, cfg, grid);
+    return true;
+}
+
 bool igemm2_launch(hipStream_t st, ConvArgs& a, int dtype, int force_cfg, float* ws, long long ws_bytes, bool defer_reduce, int* slices_out) {
     // force_cfg: -1 heuristic; -2 conv_igemm.hip's heuristic (this kernel off); 0..99 conv_igemm.hip's configurations; 100 + c forces
     // configuration c of CFG2 and 1000 * s + 100 + c additionally s K slices (s = 1: no split) - tests and tools/conv_sweep.py
@@ -462,23 +575,13 @@ bool igemm2_launch(hipStream_t st, ConvArgs& a, int dtype, int force_cfg, float*
     if (force_cfg >= 1000) force_cfg %= 1000;
     if (force_cfg < 0 && g_igemm2_mode == 0) return false;
     const int es = elem_size(dtype);
-    if (a.vr_H > 0 || (a.flags & CONV_BIG_OPERANDS) || a.k_jump < 0 || a.n_jump < 0) return false;
-    if ((a.Cin * es) % 16 != 0 || a.R * a.S > 9) return false;
+    if (!igemm2_qualifies(a, es)) return false;
     const bool transposed = (a.flags & FS_CONV_TRANSPOSED) != 0;
-    if ((long long)a.Cin * es * a.R * a.S / 16 >= 65536) return false;
-    const int batch = a.M / a.HoWo;
     const int cbu = a.Cin * es / 16;
     const int taps = a.R * a.S;
     const int steps = (taps * cbu + 7) / 8;                       // 128-byte stages of the whole contraction
     const bool can_split = ws && !transposed && !(a.flags & (FS_CONV_ACCUM | CONV_SCALAR_STORE)) && a.Cout % (16 / es) == 0 &&
                            a.Cout / (16 / es) <= 256;
-    // tiles along M of a block height (class mode: summed over the four output-parity classes)
-    auto tiles_m_of = [&](int bm) {
-        if (!transposed) return (a.M + bm - 1) / bm;
-        int acc = 0;
-        for (int c = 0; c < 4; ++c) acc += (int)(((long long)batch * ((a.Ho - (c >> 1) + 1) / 2) * ((a.Wo - (c & 1) + 1) / 2) + bm - 1) / bm);
-        return acc;
-    };
     int cfg, slices = 1;
     if (force_cfg >= 100) {
         cfg = force_cfg - 100;
@@ -502,7 +605,7 @@ bool igemm2_launch(hipStream_t st, ConvArgs& a, int dtype, int force_cfg, float*
         cfg = 0;
         for (int ci = 0; ci < 4; ++ci) {
             const int bm = CFG2[cand[ci]].bm, bn = CFG2[cand[ci]].bn;
-            const double tiles = (double)tiles_m_of(bm) * ((a.Cout + bn - 1) / bn);
+            const double tiles = (double)igemm2_tiles_m(a, bm) * ((a.Cout + bn - 1) / bn);
             for (int sl = 1; sl <= 8; sl *= 2) {
                 if (sl > 1 && (!can_split || steps / sl < 2 || (long long)sl * a.M * a.Cout * 4 > ws_bytes)) break;
                 const double st = (S + sl - 1) / sl, rows = bm + bn, share = tiles * sl > 256 ? tiles * sl / 256.0 : 1.0;
@@ -518,46 +621,14 @@ bool igemm2_launch(hipStream_t st, ConvArgs& a, int dtype, int force_cfg, float*
         }
     }
     const int bm = cfg >= 23 ? 32 : cfg >= 20 ? 64 : CFG2[cfg].bm, bn = cfg >= 23 ? 32 : cfg >= 20 ? 64 : CFG2[cfg].bn;
-    a.tiles_n = (a.Cout + bn - 1) / bn;
-    int flags = a.flags;
-    if (transposed) {          // exact stride-2 data gradient: one group of tiles per output-parity class
-        flags |= CONV_CLASSES;
-        int acc = 0;
-        for (int c = 0; c < 4; ++c) {
-            const int ph = c >> 1, pw = c & 1;
-            const long long mc = (long long)batch * ((a.Ho - ph + 1) / 2) * ((a.Wo - pw + 1) / 2);
-            a.cls_start[c] = acc;
-            acc += (int)((mc + bm - 1) / bm);
-        }
-        a.cls_start[4] = acc;
-        a.tiles_m = acc;
-    } else {
-        a.tiles_m = (a.M + bm - 1) / bm;
-        for (int c = 0; c < 5; ++c) a.cls_start[c] = 0;
-    }
-    const long long ntiles = (long long)a.tiles_m * a.tiles_n;
     // cross-block split-K: fp32 slabs [slices][M][Cout] in the caller's workspace, summed by splitk_reduce / the BatchNorm kernel
-    if (slices > steps) slices = steps;
-    if (slices < 1) slices = 1;
     while (slices > 1 && (long long)slices * a.M * a.Cout * 4 > ws_bytes) --slices;
-    a.slices = slices;
-    a.slice_units = slices > 1 ? (steps + slices - 1) / slices * 8 : 0;
-    if (slices > 1) {          // no empty trailing slice
-        slices = (steps * 8 + a.slice_units - 1) / a.slice_units;
-        a.slices = slices;
-    }
-    a.ws = slices > 1 ? ws : nullptr;
-    a.k_slice = 0;
-    const unsigned saved_magic = a.cin_magic;
-    a.cin_magic = (unsigned)(((1ull << 32) + (unsigned)cbu - 1) / (unsigned)cbu);
-    a.n_major = (9ll * a.Cout > a.M) ? 1 : 0;
-    const int saved_flags = a.flags;
-    a.flags = flags;
-    const int grid = (int)(ntiles * slices);
-    if (dtype == FS_F32) launch2<float>(st, a, cfg, grid);
-    else launch2<bf16_t>(st, a, cfg, grid);
-    a.flags = saved_flags;
-    a.cin_magic = saved_magic;
+    ConvArgs k = a;                                  // the launch fields go into a copy: `a` stays usable for conv_igemm.hip's kernels
+    const int grid = igemm2_configure(k, es, bm, bn, slices, ws);
+    slices = k.slices;
+    if (dtype == FS_F32) launch2<float>(st, k, cfg, grid);
+    else launch2<bf16_t>(st, k, cfg, grid);
+    a.slices = slices;                               // (launch_splitk_reduce reads M / Cout / y / scale ... of `a`)
     if (slices > 1) {
         if (defer_reduce) {
             if (slices_out) *slices_out = slices;

@@ -6,7 +6,8 @@
 // the kernel.  These entry points keep the per-module host work to one FFI crossing: descriptor derivation for the
 // data-gradient conv, the BN bookkeeping (running statistics, num_batches_tracked) and the parameter-gradient
 // accumulation all happen here or inside the kernels.
-#include "common.h"
+#include <string.h>
+#include "conv_igemm.h"
 
 // Maps up to this many pixels per group take the one-launch column-owner BatchNorm (bn_col.hip).  Measured on MI355X
 // (tools/bn_micro.py, bf16, launch + kernel): 96 px 6.3 vs 7.2 us for the two grid-wide launches, 384 px 7.6 vs 7.3, 1536 px
@@ -149,6 +150,144 @@ extern "C" fs_status fs_conv_bn_act_train_bwd(void* stream, const fs_conv_desc* 
         g.flags = d->stride == 2 ? FS_CONV_TRANSPOSED : 0;
         s = fs_conv2d_fwd_ws(stream, &g, dz, w_flip, nullptr, nullptr, dx, nullptr, workspace, workspace_bytes);
         if (s != FS_OK) return s;
+    }
+    return FS_OK;
+}
+
+// ---- grouped forms (program.hip's lockstep executor) ---------------------------------------------------------------------------------
+// n units at the same position of n MixedOp launch programs: their convolutions go out as ONE launch (conv_igemm2.hip's grouped kernel),
+// their weight gradients as one and their data gradients as one; the BatchNorm kernels follow one by one.  Same arithmetic as the
+// single-unit entry points above except that no convolution is split over K (a group fills the chip without it).
+fs_status fs::unit_fwd_group(void* stream, const UnitFwdCall* u, int n) {
+    FS_REQUIRE(n >= 1 && n <= FS_MAX_GROUP, FS_ERR_INVALID, "unit_fwd_group: %d units", n);
+    fs_conv_desc c[FS_MAX_GROUP];
+    const fs_conv_desc* cp[FS_MAX_GROUP];
+    ConvArgs args[FS_MAX_GROUP];
+    int mode[FS_MAX_GROUP];          // 0: one-launch BatchNorm of a small map, 1: separate statistics pass, 2: statistics in the conv epilogue
+    for (int i = 0; i < n; ++i) {
+        const UnitFwdCall& q = u[i];
+        FS_REQUIRE(q.d && q.x && q.w && q.stats && q.saved && q.z && q.y, FS_ERR_INVALID, "fs_conv_bn_act_train_fwd: null argument");
+        c[i] = *q.d;
+        c[i].flags &= ~(FS_CONV_RELU | FS_CONV_RELU_TAIL);
+        c[i].k_seg = c[i].k_jump = 0;
+        cp[i] = &c[i];
+        const long long count = (long long)q.d->N * q.d->Ho * q.d->Wo;
+        const int groups = q.d->bn_groups > 1 ? q.d->bn_groups : 1;
+        FS_REQUIRE(q.d->N % groups == 0, FS_ERR_INVALID, "fs_conv_bn_act_train_fwd: batch %d is not %d equal groups", q.d->N, groups);
+        mode[i] = count / groups <= BN_COL_MAX_PIXELS ? 0 : (groups > 1 || (q.ws && fs::g_deterministic)) ? 1 : 2;
+        const fs_status s = conv_prepare(&c[i], q.x, q.w, nullptr, nullptr, q.z, mode[i] == 2 ? q.stats : nullptr, &args[i]);
+        if (s != FS_OK) return s;
+    }
+    fs_status s = conv_launch_group(stream, cp, args, n);
+    if (s != FS_OK) return s;
+    for (int i = 0; i < n; ++i) {
+        const UnitFwdCall& q = u[i];
+        const fs_conv_desc* d = q.d;
+        const int C = d->Cout;
+        const long long count = (long long)d->N * d->Ho * d->Wo;
+        const int groups = d->bn_groups > 1 ? d->bn_groups : 1;
+        if (mode[i] == 0)
+            s = fs_bn_group_fwd(stream, count, C, groups, q.z, d->y_cs, nullptr, 1, q.gamma, q.beta, q.eps, q.momentum, q.running_mean,
+                                q.running_var, q.num_batches_tracked, q.saved, q.y, d->y_cs, d->dtype, unit_relu(d, true));
+        else if (mode[i] == 1)
+            s = fs_bn_act_train_fwd(stream, count, C, groups, q.z, d->y_cs, q.gamma, q.beta, q.eps, q.momentum, q.running_mean, q.running_var,
+                                    q.num_batches_tracked, q.stats, q.saved, q.y, d->y_cs, d->dtype, unit_relu(d, true), q.ws, q.ws_bytes);
+        else
+            s = fs_bn_train_apply(stream, count, C, q.z, d->y_cs, q.stats, q.gamma, q.beta, q.eps, q.momentum, q.running_mean, q.running_var,
+                                  q.num_batches_tracked, q.saved, q.y, d->y_cs, d->dtype, unit_relu(d, true));
+        if (s != FS_OK) return s;
+    }
+    return FS_OK;
+}
+
+fs_status fs::unit_bwd_group(void* stream, const UnitBwdCall* u, int n) {
+    FS_REQUIRE(n >= 1 && n <= FS_MAX_GROUP, FS_ERR_INVALID, "unit_bwd_group: %d units", n);
+    fs_status s;
+    // 1. BatchNorm backward of every unit (dz)
+    for (int i = 0; i < n; ++i) {
+        const UnitBwdCall& q = u[i];
+        const fs_conv_desc* d = q.d;
+        FS_REQUIRE(d && q.z && q.dy && q.saved && q.gamma && q.red && q.dz, FS_ERR_INVALID, "fs_conv_bn_act_train_bwd: null argument");
+        const int relu = unit_relu(d);
+        FS_REQUIRE(!relu || q.y, FS_ERR_INVALID, "fs_conv_bn_act_train_bwd: ReLU unit needs its output y");
+        const int C = d->Cout;
+        const long long pixels = (long long)d->N * d->Ho * d->Wo;
+        const float* mean = q.saved;
+        const float* invstd = q.saved + C;
+        const int groups = d->bn_groups > 1 ? d->bn_groups : 1;
+        if (pixels / groups <= BN_COL_MAX_PIXELS || groups > 1) {
+            s = fs_bn_act_train_bwd(stream, pixels, C, groups, q.z, d->y_cs, q.dy, q.dy_cs, q.y, d->y_cs, q.saved, q.gamma, q.red, d->dtype, relu,
+                                    q.dz, C, q.dgamma_acc, q.dbeta_acc, q.ws, q.ws_bytes);
+            if (s != FS_OK) return s;
+        } else {
+            s = fs_bn_bwd_reduce_ws(stream, pixels, C, 1, q.z, d->y_cs, q.dy, q.dy_cs, q.y, d->y_cs, mean, invstd, 0, d->dtype, relu, q.red, q.ws,
+                                    q.ws_bytes);
+            if (s != FS_OK) return s;
+            s = fs_bn_bwd_apply(stream, pixels, C, q.z, d->y_cs, q.dy, q.dy_cs, q.y, d->y_cs, mean, invstd, q.gamma, q.red, pixels, d->dtype, relu,
+                                q.dz, C, q.dgamma_acc, q.dbeta_acc);
+            if (s != FS_OK) return s;
+        }
+    }
+    // 2. weight gradients: one launch
+    {
+        fs_conv_desc w[FS_MAX_GROUP];
+        const fs_conv_desc* wp[FS_MAX_GROUP];
+        const void* xs[FS_MAX_GROUP];
+        const void* dzs[FS_MAX_GROUP];
+        float* dws[FS_MAX_GROUP];
+        long long so[FS_MAX_GROUP], si[FS_MAX_GROUP], st[FS_MAX_GROUP];
+        int m = 0;
+        for (int i = 0; i < n; ++i) {
+            const UnitBwdCall& q = u[i];
+            if (!q.dw) continue;
+            FS_REQUIRE(q.x, FS_ERR_INVALID, "fs_conv_bn_act_train_bwd: weight gradient needs x");
+            w[m] = *q.d;
+            w[m].flags = 0;
+            w[m].y_cs = q.d->Cout;
+            wp[m] = &w[m];
+            xs[m] = q.x; dzs[m] = q.dz; dws[m] = q.dw;
+            so[m] = q.o_stride; si[m] = q.i_stride; st[m] = q.t_stride;
+            ++m;
+        }
+        if (m) {
+            s = wgrad_launch_group(stream, m, wp, xs, dzs, dws, so, si, st, u[0].ws, u[0].ws_bytes);
+            if (s != FS_OK) return s;
+        }
+    }
+    // 3. data gradients: one launch (convolutions of dz with the rotated, IO-transposed filters)
+    {
+        fs_conv_desc g[FS_MAX_GROUP];
+        const fs_conv_desc* gp[FS_MAX_GROUP];
+        ConvArgs args[FS_MAX_GROUP];
+        int m = 0;
+        for (int i = 0; i < n; ++i) {
+            const UnitBwdCall& q = u[i];
+            if (!q.dx) continue;
+            FS_REQUIRE(q.w_flip, FS_ERR_INVALID, "fs_conv_bn_act_train_bwd: data gradient needs the flipped filter pack");
+            const fs_conv_desc* d = q.d;
+            fs_conv_desc& t = g[m];
+            memset(&t, 0, sizeof(t));
+            t.w_os = q.wf_os; t.w_ts = q.wf_ts;
+            if (d->n_seg > 0) {
+                t.k_seg = d->n_seg;
+                t.k_jump = d->k_jump;
+            }
+            t.N = d->N; t.H = d->Ho; t.W = d->Wo; t.Cin = d->Cout;
+            t.Cout = d->Cin; t.R = d->R; t.S = d->S;
+            t.stride = 1; t.pad = d->R - 1 - d->pad;
+            t.Ho = d->H; t.Wo = d->W;
+            t.x_cs = d->Cout; t.y_cs = q.dx_cs;
+            t.dtype = d->dtype;
+            t.flags = d->stride == 2 ? FS_CONV_TRANSPOSED : 0;
+            gp[m] = &t;
+            s = conv_prepare(&t, q.dz, q.w_flip, nullptr, nullptr, q.dx, nullptr, &args[m]);
+            if (s != FS_OK) return s;
+            ++m;
+        }
+        if (m) {
+            s = conv_launch_group(stream, gp, args, m);
+            if (s != FS_OK) return s;
+        }
     }
     return FS_OK;
 }

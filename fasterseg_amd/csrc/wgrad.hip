@@ -28,6 +28,14 @@ struct WgradArgs {
     float* part;              // deterministic mode: [tile][slab][4 waves][16][64] fp32 partial tiles (null: fp32 atomics)
     unsigned int* counters;   // [tile] arrival counters, zero on entry, left zero
     int slabs;
+    int grid_y, grid_z;       // tiles_co * tiles_ci, taps (the grouped launch linearises (slab, tile, tap))
+};
+
+constexpr int WG_MAX_GROUP = 8;
+struct WgradGroupArgs {       // n weight gradients as ONE launch: see conv_igemm2.hip's grouped kernel
+    int n;
+    int blk_start[WG_MAX_GROUP + 1];
+    WgradArgs p[WG_MAX_GROUP];
 };
 
 // Pixels staged per iteration.  Every iteration is one dependent global -> LDS -> MFMA round trip (~1 us of load latency that the
@@ -44,7 +52,7 @@ template <typename T> struct Stage { typedef float elem; static constexpr int pi
 template <> struct Stage<bf16_t> { typedef bf16_t elem; static constexpr int pitch = PITCH16; };
 
 template <typename T>
-__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
+__device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int bx, const int by, const int bz, const int gy) {
     constexpr int VEC = Elem<T>::VEC;
     constexpr int KC = Chunk<T>::KC;
     constexpr int VR = BCH / VEC;                 // vectors per staged row
@@ -57,11 +65,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int tile_co = blockIdx.y / p.tiles_ci, tile_ci = blockIdx.y % p.tiles_ci;
+    const int tile_co = by / p.tiles_ci, tile_ci = by % p.tiles_ci;
     const int co0 = tile_co * BCH, ci0 = tile_ci * BCH;
-    const int tap = blockIdx.z;
+    const int tap = bz;
     const int tr = tap / p.S, ts = tap - tr * p.S;
-    const long long m_begin = blockIdx.x * p.slab;
+    const long long m_begin = bx * p.slab;
     long long m_end = m_begin + p.slab;
     if (m_end > p.M) m_end = p.M;
 
@@ -154,8 +162,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
     // kernel).  Launches that touch one gradient tensor are ordered by their stream.
     if (p.part != nullptr && p.slabs > 1) {
         __shared__ int s_last;
-        const unsigned int tile = blockIdx.z * gridDim.y + blockIdx.y;
-        float* mine = p.part + ((long long)tile * p.slabs + blockIdx.x) * (BCH * BCH);
+        const unsigned int tile = bz * gy + by;
+        float* mine = p.part + ((long long)tile * p.slabs + bx) * (BCH * BCH);
 #pragma unroll
         for (int r = 0; r < 16; ++r) store_coherent(mine + (wave * 16 + r) * 64 + lane, acc[r]);
         if (!arrive_last(&p.counters[tile], (unsigned int)p.slabs, &s_last)) return;
@@ -185,6 +193,24 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
     }
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
+    wgrad_body<T>(p, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.y);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_group_kernel(WgradGroupArgs g) {
+    const int bid = (int)blockIdx.x;
+    int i = 0;
+#pragma unroll
+    for (int k = 1; k < WG_MAX_GROUP; ++k) i += (k < g.n && bid >= g.blk_start[k]) ? 1 : 0;
+    const WgradArgs& p = g.p[i];
+    const int l = bid - g.blk_start[i];
+    const int gx = p.slabs;
+    const int bx = l % gx, r = l / gx;
+    wgrad_body<T>(p, bx, r % p.grid_y, r / p.grid_y, p.grid_y);
+}
+
 }  // namespace fs
 
 using namespace fs;
@@ -211,8 +237,8 @@ extern "C" fs_status fs_conv2d_wgrad_ws(void* stream, const fs_conv_desc* d, con
     return wgrad_impl(stream, d, x, dy, dw, o_stride, i_stride, t_stride, workspace, workspace_bytes);
 }
 
-static fs_status wgrad_impl(void* stream, const fs_conv_desc* d, const void* x, const void* dy, float* dw_packed, long long o_stride,
-                            long long i_stride, long long t_stride, void* workspace, long long workspace_bytes) {
+static fs_status wgrad_prepare(const fs_conv_desc* d, const void* x, const void* dy, float* dw_packed, long long o_stride,
+                               long long i_stride, long long t_stride, void* workspace, long long workspace_bytes, WgradArgs* out, dim3* grid_out) {
     FS_REQUIRE(d && x && dy && dw_packed, FS_ERR_INVALID, "fs_conv2d_wgrad: null argument");
     FS_REQUIRE(d->dtype == FS_F32 || d->dtype == FS_BF16, FS_ERR_INVALID, "fs_conv2d_wgrad: bad dtype");
     const int vec = vec_elems(d->dtype);
@@ -222,7 +248,7 @@ static fs_status wgrad_impl(void* stream, const fs_conv_desc* d, const void* x, 
                "fs_conv2d_wgrad: bad channel strides (%d,%d)", d->x_cs, d->y_cs);
     FS_REQUIRE(aligned16(x) && aligned16(dy), FS_ERR_INVALID, "fs_conv2d_wgrad: operands must be 16-byte aligned");
     FS_REQUIRE(!(d->flags & FS_CONV_TRANSPOSED), FS_ERR_UNSUPPORTED, "fs_conv2d_wgrad: transposed descriptor");
-    WgradArgs a;
+    WgradArgs& a = *out;
     a.x = (const unsigned char*)x;
     a.dy = (const unsigned char*)dy;
     a.dw = dw_packed;
@@ -272,8 +298,57 @@ static fs_status wgrad_impl(void* stream, const fs_conv_desc* d, const void* x, 
     a.slab = slab;
     dim3 grid((unsigned)((M + slab - 1) / slab), (unsigned)(tiles_co * a.tiles_ci), (unsigned)taps);
     a.slabs = (int)grid.x;
+    a.grid_y = (int)grid.y;
+    a.grid_z = (int)grid.z;
+    *grid_out = grid;
+    return FS_OK;
+}
+
+static fs_status wgrad_impl(void* stream, const fs_conv_desc* d, const void* x, const void* dy, float* dw_packed, long long o_stride,
+                            long long i_stride, long long t_stride, void* workspace, long long workspace_bytes) {
+    WgradArgs a;
+    dim3 grid;
+    const fs_status ps = wgrad_prepare(d, x, dy, dw_packed, o_stride, i_stride, t_stride, workspace, workspace_bytes, &a, &grid);
+    if (ps != FS_OK) return ps;
     FS_CENSUS(FS_CENSUS_WGRAD, d);
     if (d->dtype == FS_F32) FS_LAUNCH((wgrad_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, a);
     else FS_LAUNCH((wgrad_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("fs_conv2d_wgrad");
+}
+
+// n weight gradients (fs_conv2d_wgrad_ws calls of one dtype) as ONE launch; fp32 atomics into the gradients (the ordered slab
+// reduction of the bit-reproducible mode needs per-launch counters: that mode launches them one by one)
+fs_status fs::wgrad_launch_group(void* stream, int n, const fs_conv_desc* const* d, const void* const* x, const void* const* dy, float* const* dw,
+                                 const long long* o_stride, const long long* i_stride, const long long* t_stride, void* workspace,
+                                 long long workspace_bytes) {
+    if (n <= 0) return FS_OK;
+    static const bool no_group = getenv("FS_GROUP_NOWGRAD") != nullptr;         // (debugging aid: grouped weight gradients off)
+    bool group = n > 1 && n <= WG_MAX_GROUP && !g_deterministic && !no_group;
+    for (int i = 1; i < n && group; ++i) group = d[i]->dtype == d[0]->dtype;
+    if (!group) {
+        for (int i = 0; i < n; ++i) {
+            const fs_status st = wgrad_impl(stream, d[i], x[i], dy[i], dw[i], o_stride[i], i_stride[i], t_stride[i], workspace, workspace_bytes);
+            if (st != FS_OK) return st;
+        }
+        return FS_OK;
+    }
+    WgradGroupArgs g;
+    g.n = n;
+    int total = 0;
+    double share[WG_MAX_GROUP], sum = 0;
+    for (int i = 0; i < n; ++i) {
+        dim3 grid;
+        const fs_status ps = wgrad_prepare(d[i], x[i], dy[i], dw[i], o_stride[i], i_stride[i], t_stride[i], nullptr, 0, &g.p[i], &grid);
+        if (ps != FS_OK) return ps;
+        g.blk_start[i] = total;
+        total += (int)(grid.x * grid.y * grid.z);
+        share[i] = (double)d[i]->N * d[i]->Ho * d[i]->Wo * d[i]->Cout * d[i]->Cin * d[i]->R * d[i]->S;
+        sum += share[i];
+    }
+    for (int i = n; i <= WG_MAX_GROUP; ++i) g.blk_start[i] = total;
+    for (int i = 0; i < n; ++i) share[i] /= sum;
+    CensusGroupScope scope(FS_CENSUS_WGRAD, d, share, n);
+    if (d[0]->dtype == FS_F32) FS_LAUNCH((wgrad_group_kernel<float>), dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, g);
+    else FS_LAUNCH((wgrad_group_kernel<bf16_t>), dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, g);
+    return check_launch("fs_conv2d_wgrad (group)");
 }

@@ -770,6 +770,82 @@ def mixed_op_program(x, coef, prog):
     return _MixedOpProgram.apply(x, coef, prog)
 
 
+class _MixedOpProgramGroup(torch.autograd.Function):
+    """k MixedOps of one supernet layer (they only depend on the previous layer, reference model_search.py:310-333) replayed in
+    LOCKSTEP from their launch programs (fs_exec_program_group): the convolutions, weight gradients and data gradients at the same
+    position of the k programs are one grouped launch each.  One autograd node for the k outputs, so backward is grouped as well."""
+
+    @staticmethod
+    def forward(ctx, progs, *tensors):
+        from . import program
+        k = len(progs)
+        assert len(tensors) == 2 * k
+        outs, saved, slots, scratch = [], [], [], []
+        for i, prog in enumerate(progs):
+            x, coef = tensors[2 * i], tensors[2 * i + 1]
+            c = coef.detach()
+            if c.dtype != torch.float32 or not c.is_contiguous():
+                c = c.float().contiguous()
+            dev = x.device
+            save = torch.empty(prog.save_bytes, dtype=torch.uint8, device=dev)
+            tmp = torch.empty(prog.tmpf_bytes, dtype=torch.uint8, device=dev)
+            N, C, H, W = prog.out_shape
+            out = torch.empty_strided((N, C, H, W), (H * W * C, 1, W * C, C), dtype=x.dtype, device=dev)
+            slots.append((None, x.data_ptr(), c.data_ptr(), out.data_ptr(), save.data_ptr(), None, None, None, tmp.data_ptr(),
+                          K.stream_workspace(dev)[0]))
+            outs.append(out)
+            saved += [x, c, save]
+            scratch.append(tmp)                   # forward scratch: alive until the launches are enqueued (stream-ordered reuse after)
+        program.run_group(progs, False, slots)
+        del scratch
+        ctx.progs = progs
+        ctx.save_for_backward(*saved)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        from . import program
+        progs = ctx.progs
+        saved = ctx.saved_tensors
+        k = len(progs)
+        slots, tmps, gxs = [], [], []
+        for i, prog in enumerate(progs):
+            x, c, save = saved[3 * i], saved[3 * i + 1], saved[3 * i + 2]
+            N, C, H, W = prog.out_shape
+            dy = dys[i]
+            if not (K.is_nhwc(dy, x.dtype) and K.channel_stride(dy) == C):          # the program reads a dense gradient
+                dy = K.copy_channels(as_nhwc(dy, x.dtype), K.empty_nhwc(N, C, H, W, x.dtype, x.device))
+            tmp = torch.empty(prog.tmpb_bytes, dtype=torch.uint8, device=x.device)
+            gx = None
+            if prog.need_x:
+                n, ci, h, w = x.shape
+                gx = torch.empty_strided((n, ci, h, w), (h * w * ci, 1, w * ci, ci), dtype=x.dtype, device=x.device)
+            slots.append((None, x.data_ptr(), c.data_ptr(), None, save.data_ptr(), dy.data_ptr(), tmp.data_ptr(),
+                          gx.data_ptr() if gx is not None else None, None, K.stream_workspace(x.device)[0]))
+            tmps.append((tmp, dy))
+            gxs.append(gx)
+        program.run_group(progs, True, slots)
+        grads = [None]
+        sink = _grad_sink
+        for i, prog in enumerate(progs):
+            for p in prog.touched:
+                sink.touched(p)
+            gc = None
+            if prog.need_coef:
+                c = saved[3 * i + 1]
+                gc = tmps[i][0][prog.gcoef_off:prog.gcoef_off + 4 * c.numel()].view(torch.float32).reshape(c.shape)
+            grads += [gxs[i], gc]
+        return tuple(grads)
+
+
+def mixed_op_program_group(xs, coefs, progs):
+    """Outputs of k MixedOp programs of equal `signature` executed in lockstep (1 <= k <= program.MAX_GROUP)."""
+    flat = []
+    for x, c in zip(xs, coefs):
+        flat += [x, c]
+    return _MixedOpProgramGroup.apply(tuple(progs), *flat)
+
+
 def weighted_sum(xs, coef):
     """sum_k coef[k] * xs[k] for NHWC feature maps and a device-resident coefficient vector (len(xs) <= 8)."""
     xs = [as_nhwc(t) for t in xs]

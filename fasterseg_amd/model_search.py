@@ -133,6 +133,17 @@ def _eval(op, x, alpha, ratios, groups):
 _EAGER_LANES = int(os.environ.get("FS_EAGER_LANES", "4"))     # measured on C3: 1 lane 130.6 ms, 4: 120.0, 6: 122.1, 10: 134.2
 
 
+# The MixedOps of a layer whose launch programs have the same command structure are replayed in LOCKSTEP by fs_exec_program_group: the
+# convolutions (weight / data gradients) at the same position of the programs are ONE grouped launch each - the step is the sum of its
+# kernel durations and every ~10 us convolution pays ~4 us of ramp-up + boundary.  FS_GROUP_PROGRAMS=0: one program per stream lane.
+_GROUP_PROGRAMS = bool(int(os.environ.get("FS_GROUP_PROGRAMS", "1")))
+# Inside a hipGraph capture the lockstep calls are OFF by default (ROCm 7.2): on side lanes hipStreamEndCapture crashes as soon as a
+# k > 1 lockstep node is captured, and with the launch programs on the capture's origin stream instead (grouped OR one by one - the
+# round-3 _MixedOpProgram node shows it too) the fifth replay of the graph produces inf / NaN gradients (tools/debug_group_nan.py).
+# The captured fixed-width passes therefore keep one program per lane; the eager (sampled-width) passes are grouped.
+_GROUP_CAPTURE = bool(int(os.environ.get("FS_GROUP_CAPTURE", "0")))
+
+
 def _run_tasks(tasks):
     """tasks: [(mixed_op, x, alpha, ratios, bn_groups)] -> outputs.  While capturing, every primitive of every task runs on its own
     stream; the alpha-weighted sums follow on the capturing stream after the join.  Eager training passes put whole MixedOp
@@ -147,8 +158,11 @@ def _run_tasks(tasks):
     if not capturing:
         pool = pool[:_EAGER_LANES]
     used, slot, pending = [], 0, []
+    grouped = []                 # (index into pending, x, coef, prog) of the tasks that run from launch programs
 
     def lane_for(k):
+        if not pool:                                       # FS_LAYER_LANES=1: everything on the current stream
+            return main
         lane = pool[k % len(pool)]
         if lane not in used:
             lane.wait_stream(main)                         # fork: the previous layer's outputs are complete on `main`
@@ -161,6 +175,10 @@ def _run_tasks(tasks):
         if _PROGRAMS and (_CAPTURE_PROGRAMS or not capturing) and op.training and torch.is_grad_enabled():
             with FN.bn_groups(groups):
                 prog = op._program(FN.as_nhwc(x), coef, widths[0], widths[1])
+        if prog is not None and _GROUP_PROGRAMS and (not capturing or _GROUP_CAPTURE):
+            grouped.append((len(pending), FN.as_nhwc(x), coef, prog))
+            pending.append(None)
+            continue
         if prog is not None:          # the whole MixedOp (five primitives, their sum, and in backward the sum of the five input
             with torch.cuda.stream(lane_for(slot)):        # gradients) as one launch program on one lane
                 pending.append((FN.mixed_op_program(FN.as_nhwc(x), coef, prog), None))
@@ -176,6 +194,22 @@ def _run_tasks(tasks):
                 outs.append(prim(x))
             slot += 1
         pending.append((outs, coef))
+    if grouped:
+        from .program import MAX_GROUP
+        buckets = {}
+        for item in grouped:
+            buckets.setdefault((item[3].signature, item[1].dtype), []).append(item)
+        for items in buckets.values():
+            for lo in range(0, len(items), MAX_GROUP):
+                chunk = items[lo:lo + MAX_GROUP]
+                if capturing:          # FS_GROUP_CAPTURE=1 (see above): on the capturing stream itself
+                    outs = FN.mixed_op_program_group([c[1] for c in chunk], [c[2] for c in chunk], [c[3] for c in chunk])
+                else:
+                    with torch.cuda.stream(lane_for(slot)):    # one lockstep call per bucket, buckets side by side on the lanes
+                        outs = FN.mixed_op_program_group([c[1] for c in chunk], [c[2] for c in chunk], [c[3] for c in chunk])
+                    slot += 1
+                for c, o in zip(chunk, outs):
+                    pending[c[0]] = (o, None)
     for lane in used:
         main.wait_stream(lane)                             # one join per layer
     return [outs if coef is None else FN.weighted_sum(outs, coef) for outs, coef in pending]

@@ -150,6 +150,10 @@ class MixedOpProgram:
         self.need_x, self.need_coef, self.gcoef_off = need_x, need_coef, gcoef_off
         self.guard = guard[:2] + guard[-2:]   # (tensor, data_ptr) samples of the storage the program hard-codes
         self.n_launches = (len(fwd.words), len(bwd.words))
+        # command structure (op + argument count per command, both directions): programs with equal signatures can be replayed in
+        # lockstep by fs_exec_program_group, their convolutions going out as grouped launches
+        self.signature = (tuple((op & 0xffff, len(args)) for op, args in fwd.words), tuple(sorted(fwd.sizes)),
+                          tuple((op & 0xffff, len(args)) for op, args in bwd.words), tuple(sorted(bwd.sizes)))
 
     def valid(self):
         return all(t.data_ptr() == p and (v is None or t._version == v) for t, p, v in self.guard)
@@ -157,6 +161,25 @@ class MixedOpProgram:
     def run(self, words, n, blob, slots):
         arr = (ctypes.c_void_p * N_SLOTS)(*slots)
         K.call("fs_exec_program", K._stream(), words, n, blob, arr, N_SLOTS)
+
+
+MAX_GROUP = 8          # FS_MAX_GROUP of csrc/conv_igemm.h: programs per lockstep call
+
+
+def run_group(progs, backward, slot_lists):
+    """fs_exec_program_group: the forward (or backward) lists of `progs` (equal signatures) in lockstep on the current stream."""
+    k = len(progs)
+    assert 1 <= k <= MAX_GROUP and len(slot_lists) == k
+    lists = [(p.b_words, p.b_n, p.b_blob) if backward else (p.f_words, p.f_n, p.f_blob) for p in progs]
+    words = (ctypes.c_void_p * k)(*[ctypes.addressof(w) for w, _, _ in lists])
+    counts = (ctypes.c_longlong * k)(*[n for _, n, _ in lists])
+    blobs = (ctypes.c_void_p * k)(*[ctypes.addressof(b) for _, _, b in lists])
+    flat = []
+    for sl in slot_lists:
+        assert len(sl) == N_SLOTS
+        flat.extend(sl)
+    slots = (ctypes.c_void_p * (k * N_SLOTS))(*flat)
+    K.call("fs_exec_program_group", K._stream(), k, words, counts, blobs, slots, N_SLOTS)
 
 
 # ---------------------------------------------------------------------------------------------------

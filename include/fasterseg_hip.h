@@ -88,7 +88,7 @@ typedef struct fs_resize_desc {
 const char* fs_last_error(void);
 /* ABI revision of this header; fs_version() returns the one the library was built from.  Bindings check both this and
  * fs_struct_size() when they load the library (fasterseg_amd/_lib.py) - a stale .so must not be used silently. */
-#define FS_ABI_VERSION 206
+#define FS_ABI_VERSION 207
 int fs_version(void);
 /* Bit-reproducible mode (default off; FS_DETERMINISTIC=1 in the environment turns it on at load): every cross-block reduction that
  * otherwise uses float atomics - the pixel slabs of fs_conv2d_wgrad_ws, BatchNorm statistics and parameter gradients of maps above
@@ -499,6 +499,15 @@ fs_status fs_exec_program(void* stream, const long long* words, long long n_word
  * host cost per kernel node is higher.  Events are created / destroyed with fs_event_create / fs_event_destroy. */
 fs_status fs_exec_program_streams(void* const* streams, int n_streams, const long long* words, long long n_words,
                                   const unsigned char* blob, void* const* slots, int n_slots);
+/* Lockstep form: k programs (<= 8) of IDENTICAL command structure - the MixedOps of one supernet layer, which only depend on the
+ * previous layer (search/model_search.py:310-333) - issued on one stream, command j of all programs together.  Where that command is a
+ * conv->BN unit (forward or backward), a bare convolution or a weight gradient, the k convolutions / weight gradients / data gradients go
+ * out as ONE launch each: their arguments travel as kernel arguments and every workgroup finds its problem itself (a supernet step is
+ * the sum of its kernel durations, and a 10 us convolution on 100-600 workgroups pays ~4 us of ramp-up + boundary whatever its size).
+ * words / n_words / blobs: k entries; slots: k * n_slots pointers (program i uses slots[i * n_slots ...]).  Same arithmetic as k
+ * fs_exec_program calls except that grouped convolutions are never split over K. */
+fs_status fs_exec_program_group(void* stream, int k, const long long* const* words, const long long* n_words,
+                                const unsigned char* const* blobs, void* const* slots, int n_slots);
 void* fs_event_create(void);
 void fs_event_destroy(void* event);
 

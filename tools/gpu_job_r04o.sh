@@ -1,0 +1,5 @@
+#!/bin/bash
+export TMPDIR=/tmp
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+t() { echo "== $*"; env "$@" timeout 300 python -W ignore tools/debug_group_nan.py graph 2>&1 | grep -E "^step|Error" | awk '{print $2, $4, $6}' | tr '\n' ';'; echo; }
+t FS_GROUP_SINGLE_NODE=1 FS_GROUP_OFF_EAGER=1
