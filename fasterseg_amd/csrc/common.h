@@ -112,7 +112,9 @@ __device__ __forceinline__ bool arrive_last(unsigned int* counter, unsigned int 
     __builtin_amdgcn_s_waitcnt(0);                 // this thread's stores have left the CU
     __syncthreads();
     if (threadIdx.x == 0)
-        *flag = (__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) == expected - 1u) ? 1 : 0;
+        // acquire as well as release: the last block's reads of the other blocks' partials are ordered behind this arrival by the
+        // memory model, not only by the sc1 accesses of today's hardware
+        *flag = (__hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == expected - 1u) ? 1 : 0;
     __syncthreads();
     return *flag != 0;
 }

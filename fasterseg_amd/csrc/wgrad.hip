@@ -7,9 +7,8 @@
 //   fp32: v_mfma_f32_32x32x2_f32 operands are single ds_read_b32 per lane (lanes 0-31 = 32 consecutive channels of pixel
 //         k, lanes 32-63 of pixel k+1: conflict free); exact fp32 products.
 //   bf16: tiles stay bf16 in LDS and feed v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate); an operand is 8 consecutive
-//         PIXELS of one channel, i.e. a column of the staged tile, gathered with 8 ds_read_u16 (row pitch 144 B: the two
-//         half-waves land on disjoint banks).  The kernel is then LDS-issue bound, still several times faster than
-//         widening to fp32.
+//         PIXELS of one channel, i.e. a column of the staged tile: two ds_read_b64_tr_b16 (gfx950's 16-bit transpose read) per
+//         operand - round 3 gathered it with eight ds_read_u16 and was LDS-issue bound.
 #include "common.h"
 
 namespace fs {
@@ -46,7 +45,8 @@ template <> struct Chunk<bf16_t> { static constexpr int KC = 128; };
 constexpr int SLAB_MIN_PIXELS = 256;     // a slab shorter than this is launch overhead
 constexpr int BCH = 64;     // channels per block tile (both operands)
 constexpr int PITCH = BCH + 4;
-constexpr int PITCH16 = BCH + 8;     // bf16 tile: 144-byte rows
+constexpr int PITCH16 = BCH + 32;    // bf16 tile: 192-byte rows - the four pixel rows x two 16-channel halves a half-wave's transpose
+                                     // reads touch (rows 0,192,128,64 mod 256 B, halves +32 B) fall on eight distinct 32-byte bank slots
 
 template <typename T> struct Stage { typedef float elem; static constexpr int pitch = PITCH; };
 template <> struct Stage<bf16_t> { typedef bf16_t elem; static constexpr int pitch = PITCH16; };
@@ -133,17 +133,23 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int bx, con
             __syncthreads();
             if (mc + KC < m_end) load_chunk(mc + KC);
             if (NATIVE) {
-                // operand = 8 consecutive pixels (k) of one channel: a strided column of the [pixel][channel] tile
-                const bf16_t* pa = reinterpret_cast<const bf16_t*>(&sA[(lane >> 5) * 8][wm * 32 + (lane & 31)]);
-                const bf16_t* pb = reinterpret_cast<const bf16_t*>(&sB[(lane >> 5) * 8][wn * 32 + (lane & 31)]);
+                // operand = 8 consecutive pixels (k) of one channel = a COLUMN of the [pixel][channel] tile: two ds_read_b64_tr_b16 (the
+                // 16-bit transpose read of gfx950: within a 16-lane group lane t supplies row t >> 2, column quad t & 3 of a [4][16] block
+                // and receives column t of it - tools/probes/tr16_probe.hip) instead of eight ds_read_u16 and their packing
+                typedef __attribute__((ext_vector_type(4))) short s16x4;
+                typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+                const int g = lane >> 4, t = lane & 15;
+                const bf16_t* pa = reinterpret_cast<const bf16_t*>(&sA[(g >> 1) * 8 + (t >> 2)][wm * 32 + (g & 1) * 16 + (t & 3) * 4]);
+                const bf16_t* pb = reinterpret_cast<const bf16_t*>(&sB[(g >> 1) * 8 + (t >> 2)][wn * 32 + (g & 1) * 16 + (t & 3) * 4]);
 #pragma unroll
                 for (int k = 0; k < KC; k += 16) {
-                    u32x4 a, b;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        a[j] = (uint32_t)pa[(k + 2 * j) * LP] | ((uint32_t)pa[(k + 2 * j + 1) * LP] << 16);
-                        b[j] = (uint32_t)pb[(k + 2 * j) * LP] | ((uint32_t)pb[(k + 2 * j + 1) * LP] << 16);
-                    }
+                    const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(pa + k * LP));
+                    const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(pa + (k + 4) * LP));
+                    const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(pb + k * LP));
+                    const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(pb + (k + 4) * LP));
+                    typedef __attribute__((ext_vector_type(8))) short s16x8;
+                    const s16x8 a = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    const s16x8 b = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc,
                                                                   0, 0, 0);
                 }

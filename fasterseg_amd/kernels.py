@@ -544,6 +544,11 @@ def cat_channels(tensors):
     return out
 
 
+def deterministic_on():
+    """Is the library in its bit-reproducible mode (fs_set_deterministic / FS_DETERMINISTIC=1)?"""
+    return bool(_lib.lib().fs_get_deterministic())
+
+
 class deterministic:
     """with deterministic(): ...  -  bit-reproducible mode of the library for the duration (fs_set_deterministic): ordered partial sums
     instead of float atomics in the weight-gradient slabs and the BatchNorm reductions of large maps (slower, see the header)."""

@@ -19,6 +19,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import functional as FN
+from . import kernels as K
 from .genotypes import PRIMITIVES
 from .operations import *            # noqa: F401,F403
 from .operations import OPS, BasicResidual2x, ConvNorm
@@ -141,7 +142,10 @@ _GROUP_PROGRAMS = bool(int(os.environ.get("FS_GROUP_PROGRAMS", "1")))
 # k > 1 lockstep node is captured, and with the launch programs on the capture's origin stream instead (grouped OR one by one - the
 # round-3 _MixedOpProgram node shows it too) the fifth replay of the graph produces inf / NaN gradients (tools/debug_group_nan.py).
 # The captured fixed-width passes therefore keep one program per lane; the eager (sampled-width) passes are grouped.
-_GROUP_CAPTURE = bool(int(os.environ.get("FS_GROUP_CAPTURE", "0")))
+_GROUP_CAPTURE = int(os.environ.get("FS_GROUP_CAPTURE", "0"))       # 1: on the origin stream, 2: every bucket on ONE side lane
+
+
+_RECORD_STREAM = bool(int(os.environ.get("FS_RECORD_STREAM", "1")))
 
 
 def _run_tasks(tasks):
@@ -151,7 +155,10 @@ def _run_tasks(tasks):
     on_gpu = len(tasks) > 1 and tasks[0][1].is_cuda
     capturing = on_gpu and torch.cuda.is_current_stream_capturing()
     eager_lanes = (on_gpu and not capturing and _EAGER_LANES > 1 and _PROGRAMS and torch.is_grad_enabled() and tasks[0][0].training)
-    if not ((capturing and _LAYER_LANES > 1) or eager_lanes):
+    # bit-reproducible mode: the ordered slab reduction of the weight gradient finishes with a plain read-modify-write of the gradient,
+    # which needs the launches that touch one tensor stream-ordered (the same cell._op on two lanes would race: ADVICE r3) - no lanes
+    ordered = on_gpu and K.deterministic_on()
+    if ordered or not ((capturing and _LAYER_LANES > 1) or eager_lanes):
         return [_eval(op, x, alpha, ratios, g) for op, x, alpha, ratios, g in tasks]
     main = torch.cuda.current_stream()
     pool = layer_lanes(main)
@@ -159,6 +166,13 @@ def _run_tasks(tasks):
         pool = pool[:_EAGER_LANES]
     used, slot, pending = [], 0, []
     grouped = []                 # (index into pending, x, coef, prog) of the tasks that run from launch programs
+    crossing = []                # (tensor, lane) of eager passes: inputs made on `main` and read on a lane, outputs made on a lane
+
+    def hand_over(t, lane):
+        """Caching-allocator bookkeeping of a tensor that crosses streams in an eager pass: without it the block returns to
+        its home stream's pool when the last reference dies and can be rewritten while the other stream's kernels still read it."""
+        if _RECORD_STREAM and not capturing and torch.is_tensor(t) and t.is_cuda and lane is not main:
+            t.record_stream(lane)
 
     def lane_for(k):
         if not pool:                                       # FS_LAYER_LANES=1: everything on the current stream
@@ -180,8 +194,14 @@ def _run_tasks(tasks):
             pending.append(None)
             continue
         if prog is not None:          # the whole MixedOp (five primitives, their sum, and in backward the sum of the five input
-            with torch.cuda.stream(lane_for(slot)):        # gradients) as one launch program on one lane
-                pending.append((FN.mixed_op_program(FN.as_nhwc(x), coef, prog), None))
+            lane = lane_for(slot)                          # gradients) as one launch program on one lane
+            xn = FN.as_nhwc(x)
+            hand_over(xn, lane)
+            hand_over(coef, lane)
+            with torch.cuda.stream(lane):
+                out = FN.mixed_op_program(xn, coef, prog)
+            crossing.append((out, lane))
+            pending.append((out, None))
             slot += 1
             continue
         if not capturing:             # no program (nothing to differentiate, gradients outside the sink): per-module path, in place
@@ -202,16 +222,28 @@ def _run_tasks(tasks):
         for items in buckets.values():
             for lo in range(0, len(items), MAX_GROUP):
                 chunk = items[lo:lo + MAX_GROUP]
-                if capturing:          # FS_GROUP_CAPTURE=1 (see above): on the capturing stream itself
+                if capturing and _GROUP_CAPTURE == 2:
+                    with torch.cuda.stream(lane_for(0)):
+                        outs = FN.mixed_op_program_group([c[1] for c in chunk], [c[2] for c in chunk], [c[3] for c in chunk])
+                elif capturing:        # FS_GROUP_CAPTURE=1 (see above): on the capturing stream itself
                     outs = FN.mixed_op_program_group([c[1] for c in chunk], [c[2] for c in chunk], [c[3] for c in chunk])
                 else:
-                    with torch.cuda.stream(lane_for(slot)):    # one lockstep call per bucket, buckets side by side on the lanes
+                    lane = lane_for(slot)                   # one lockstep call per bucket, buckets side by side on the lanes
+                    for c in chunk:
+                        hand_over(c[1], lane)
+                        hand_over(c[2], lane)
+                    with torch.cuda.stream(lane):
                         outs = FN.mixed_op_program_group([c[1] for c in chunk], [c[2] for c in chunk], [c[3] for c in chunk])
+                    crossing.extend((o, lane) for o in outs)
                     slot += 1
                 for c, o in zip(chunk, outs):
                     pending[c[0]] = (o, None)
     for lane in used:
         main.wait_stream(lane)                             # one join per layer
+    if _RECORD_STREAM and not capturing:
+        for t, lane in crossing:                           # made on a lane, consumed (and eventually freed) on `main`
+            if lane is not main:
+                t.record_stream(main)
     return [outs if coef is None else FN.weighted_sum(outs, coef) for outs, coef in pending]
 
 

@@ -21,13 +21,20 @@ _TENSOR = np.dtype([("p", "<u8"), ("g_off", "<i8"), ("numel", "<i8"), ("I", "<i4
 
 
 class FlatSGD:
-    def __init__(self, sync, lr, momentum=0.9, weight_decay=0.0, max_norm=None, pack_dtype=None):
+    def __init__(self, sync, lr, momentum=0.9, weight_decay=0.0, max_norm=None, pack_dtype=None, unused="skip"):
         """pack_dtype (torch.float32 / torch.bfloat16): also keep RESIDENT packed copies of every conv filter in that dtype -
         the [O][R][S][I] pack the forward conv reads and the rotated [I][R][S][O] pack of the data-gradient conv - rewritten
         by the update kernel itself, so train-mode convs read (slices of) them in place instead of re-packing a filter on
         every forward and backward (two fs_pack_weight launches per conv per pass: ~10 % of a supernet step's GPU time)."""
         self.sync = sync
         self.lr, self.momentum, self.weight_decay, self.max_norm = lr, momentum, weight_decay, max_norm
+        # unused: what happens to a parameter that receives no gradient in a step.  "skip" = torch >= 2.0 (zero_grad(set_to_none=True):
+        # .grad is None, the optimizer passes over it).  "decay" = the reference's pinned torch 1.1 (search/train_search.py:244-250):
+        # zero_grad() leaves a zero-filled .grad on every parameter that was touched ONCE, which therefore keeps decaying and coasting on
+        # its momentum.  Pinned to a trajectory of the reference by tests/test_train_parity_gpu.py (fixture optimizer_trajectory.npz).
+        assert unused in ("skip", "decay")
+        self.unused = unused
+        self._ever_touched = None
         params = sync.params
         dev = sync.flat.device
         if dev.type != "cuda":
@@ -101,6 +108,9 @@ class FlatSGD:
             self.last_norm = sync.flat.norm()                 # slices of untouched parameters are zero
             scale = torch.clamp(self.max_norm / (self.last_norm + 1e-6), max=1.0)
         touched = sync._touched
+        if self.unused == "decay":
+            ever = self._ever_touched or [False] * len(touched)
+            touched = self._ever_touched = [a or b for a, b in zip(ever, touched)]
         if touched != self._last_touched:
             self.touched_dev.copy_(torch.tensor(touched, dtype=torch.uint8))
             self._last_touched = list(touched)

@@ -153,7 +153,7 @@ class SupernetStep:
         self.sync = FlatGradientSync(self.weights, bucket_mb=128)
         # train_search.py:94-98 SGD + :249 clip_grad_norm_(5), one launch over the flat buffers
         self.optimizer = FlatSGD(self.sync, cfg.lr, cfg.momentum, cfg.weight_decay, max_norm=cfg.grad_clip,
-                                 pack_dtype=compute_dtype)
+                                 pack_dtype=compute_dtype, unused=os.environ.get("FS_SGD_UNUSED", "skip"))
         # Width sampling (np.random.choice for "random", torch.rand for the Gumbel noise) runs on the host RNGs: every rank must
         # draw the SAME sub-network, or a parameter would be updated on one rank and skipped (grad=None) on another.  Rank 0's
         # seed wins, whatever the others were given.
@@ -268,6 +268,8 @@ class SupernetStep:
         self.static = {ph: (i.clone(), t.clone()) for ph, (i, t) in batches.items()}
         self.graphs = {}
         self._graph_arenas = []
+        from . import kernels as K_
+        self._captured_deterministic = K_.deterministic_on()        # baked into the captured launches
         from . import model_search
         side = torch.cuda.Stream()
         lanes = model_search.branch_lanes(side)   # MixedOp forks its five primitives onto these inside the capture
@@ -328,6 +330,10 @@ class SupernetStep:
             if self.architect is not None:
                 batches["a"] = (imgs_search, target_search)
             self._capture(batches)
+        if K.deterministic_on() != self._captured_deterministic:
+            raise RuntimeError("fasterseg_amd: the bit-reproducible mode was switched %s after this SupernetStep captured its hipGraphs; the "
+                               "captured launches keep the mode of the capture - set it (kernels.deterministic / FS_DETERMINISTIC=1) "
+                               "BEFORE the first step, or build a new SupernetStep" % ("on" if K.deterministic_on() else "off"))
         loss_arch = None
         if self.architect is not None:                       # Architect.step (architect.py:34-47), pass by pass
             self._set_phase("a")

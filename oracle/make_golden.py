@@ -562,12 +562,82 @@ def gen_eval():
     print("eval fixtures:", sorted(store))
 
 
+# 7c. the weight-update loop of the search (search/train_search.py:244-250: zero_grad -> `_loss` -> backward ->
+#     clip_grad_norm_(model.parameters(), 5) -> SGD(lr, momentum 0.9, weight decay 5e-4) -> zero_grad), three steps on one batch.
+#     Two trajectories: "zeros" = the reference's pinned torch 1.1, whose zero_grad() leaves zero-filled .grad tensors behind, so a
+#     parameter that was touched once keeps decaying / coasting on its momentum in steps that do not use it; "none" = today's torch
+#     (zero_grad(set_to_none=True)): unused parameters are skipped.  The clip norm covers model.parameters(), i.e. alpha / beta /
+#     ratio too; the norm over the network weights alone is stored beside it.
+TRAJ_KEYS = ("stem.0.0.conv.0.weight", "stem.0.1.conv1.weight", "cells.0.0._op._ops.1.conv1.weight", "cells.1.0._op._ops.3.conv2.weight",
+             "cells.1.1._op._ops.2.bn1.bn.4.weight", "cells.2.1.downsample._ops.0.conv2.weight", "cells.3.2._op._ops.4.bn2.bn.4.bias",
+             "cells.4.1._op._ops.4.conv1.weight", "cells.5.0._op._ops.1.bn1.bn.0.weight", "refine32.0.0.conv.0.weight",
+             "head0.0.conv_1x1.weight", "head02.0.conv_1x1.bias", "head12.0.conv_3x3.conv.weight")
+
+
+def gen_optimizer_trajectory(steps=3):
+    store = {}
+    with ref_loader.reference("search"):
+        import model_search
+        real_cuda = torch.Tensor.cuda
+        torch.Tensor.cuda = lambda self, *a, **k: self
+        try:
+            crit = torch.nn.CrossEntropyLoss(ignore_index=255)
+            x = seeded_input((2, 3, 128, 256), 31)
+            g = torch.Generator().manual_seed(32)
+            target = torch.randint(0, 19, (2, 16, 32), generator=g)
+            target[torch.rand(2, 16, 32, generator=g) < 0.05] = 255
+            finals = {}
+            for sem in ("zeros", "none", "none_fp32"):          # none_fp32: the reference's OWN fp32 run (its distance from fp64 = the yardstick)
+                net = model_search.Network_Multi_Path(criterion=crit, **SUPERNET_CFG)
+                sd = seeded_state(net.state_dict(), 777)
+                for k in list(sd):
+                    if k.split("_")[0] in ("alpha", "beta", "ratio"):
+                        sd[k] = sd[k] * 5.0
+                net.load_state_dict(sd)
+                dt = torch.float32 if sem.endswith("fp32") else torch.float64
+                net = net.to(dt).train()                   # fp64: the trajectory itself, not a rounding study
+                net.arch_idx = 0
+                parameters = []
+                for part in (net.stem, net.cells, net.refine32, net.refine16, net.head0, net.head1, net.head2, net.head02, net.head12):
+                    parameters += list(part.parameters())                                  # train_search.py:84-94
+                optimizer = torch.optim.SGD(parameters, lr=2e-2, momentum=0.9, weight_decay=5e-4)   # config_search.py:57-58,90
+                wid = {id(p) for p in parameters}
+                names = dict(net.named_parameters())
+                assert all(k in names for k in TRAJ_KEYS), [k for k in TRAJ_KEYS if k not in names]
+                for step in range(steps):
+                    np.random.seed(100 + step)
+                    torch.manual_seed(200 + step)
+                    optimizer.zero_grad(set_to_none=(sem != "zeros"))
+                    loss = net._loss(x.to(dt), target, True)
+                    loss.backward()
+                    w_norm = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in net.parameters() if p.grad is not None and id(p) in wid))
+                    total = torch.nn.utils.clip_grad_norm_(net.parameters(), 5)             # train_search.py:249
+                    optimizer.step()
+                    store["%s/loss%d" % (sem, step)] = np.array([float(loss.detach())])
+                    store["%s/norm_all%d" % (sem, step)] = np.array([float(total)])
+                    store["%s/norm_weights%d" % (sem, step)] = np.array([float(w_norm)])
+                    store["%s/touched%d" % (sem, step)] = np.array([sum(1 for p in parameters if p.grad is not None and float(p.grad.abs().sum()) > 0)])
+                    print("trajectory", sem, step, float(loss.detach()), float(total), float(w_norm))
+                finals[sem] = {k: names[k].detach().double().clone() for k in TRAJ_KEYS}
+                if not sem.endswith("fp32"):
+                    for k in TRAJ_KEYS:
+                        _put(store, "%s/final/%s" % (sem, k), names[k].detach().float())
+            for k in TRAJ_KEYS:       # relative error of the reference's fp32 UPDATE (final - initial) against its fp64 one
+                init = sd[k].double()
+                du64, du32 = finals["none"][k] - init, finals["none_fp32"][k] - init
+                store["ref_fp32_update_err/" + k] = np.array([float((du32 - du64).norm() / (du64.norm() + 1e-30))])
+                print("reference fp32 vs fp64 update", k, float(store["ref_fp32_update_err/" + k][0]))
+        finally:
+            torch.Tensor.cuda = real_cuda
+    np.savez_compressed(os.path.join(GOLD, "optimizer_trajectory.npz"), **store)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(max(1, os.cpu_count() or 1))
-    which = sys.argv[1:] or ["arch", "decode", "ops", "nets", "student_step", "lut", "loss", "supernet", "supernet_l16", "eval"]
+    which = sys.argv[1:] or ["arch", "decode", "ops", "nets", "student_step", "lut", "loss", "supernet", "supernet_l16", "eval", "trajectory"]
     for w in which:
-        {"arch": gen_arch, "decode": gen_decode_cases, "ops": gen_ops, "nets": gen_nets, "lut": gen_lut, "loss": gen_loss, "supernet": gen_supernet, "supernet_l16": gen_supernet_l16, "eval": gen_eval, "student_step": gen_student_step}[w]()
+        {"arch": gen_arch, "decode": gen_decode_cases, "ops": gen_ops, "nets": gen_nets, "lut": gen_lut, "loss": gen_loss, "supernet": gen_supernet, "supernet_l16": gen_supernet_l16, "eval": gen_eval, "student_step": gen_student_step, "trajectory": gen_optimizer_trajectory}[w]()
 
 
 if __name__ == "__main__":

@@ -97,7 +97,15 @@ def test_engine_class_map(shape, dtype, monkeypatch):
     assert classes.dtype == torch.uint8 and tuple(classes.shape) == (shape[0], shape[2], shape[3])
     assert any(c["fn"] == "fs_bilinear_argmax" for c in eng.calls) and not any(c["family"] == "resize_nchw" for c in eng.calls)
     own = logits.argmax(1).to(torch.uint8)
-    assert torch.equal(classes, own), "class map differs from the arg-max of the engine's own logits in %d pixels" % int((classes != own).sum())
+    # the fused x8 up-sample + arg-max interpolates in a different operation order than the logits writer: a pixel may differ only where
+    # the two best classes are tied to the last bits (seen: 1 of 2 M pixels in fp32 once a conv kernel changed the logits by an ulp)
+    differs = classes != own
+    if bool(differs.any()):
+        top2 = logits.float().topk(2, dim=1).values
+        gap = (top2[:, 0] - top2[:, 1])[differs]
+        bar = (1e-4 if dtype == torch.float32 else 2e-2) * float(logits.float().abs().max())
+        assert int(differs.sum()) <= 8 and float(gap.max()) <= bar, \
+            "class map differs from the arg-max of the engine's own logits in %d pixels (largest top-2 gap there %.3e)" % (int(differs.sum()), float(gap.max()))
     ref = ref_eval.class_map(want[0].numpy())
     agree = (classes[0].cpu().numpy() == ref)
     if dtype == torch.float32:

@@ -231,3 +231,75 @@ def test_student_distill_step_as_benchmarked(dtype):
         assert cos_min >= 0.25 and all(c >= 0.99 for k, (c, _) in per.items() if k.startswith("heads8.conv_1x1")), per
     else:
         assert cos_min >= 0.999 and rel_max <= bar, per
+
+
+class _SmallSearch:
+    """The 6-layer supernet of the reference fixtures with the weight step's settings (config_search.py:57-58,71,90)."""
+    lr = 2e-2
+    momentum = 0.9
+    weight_decay = 5e-4
+    grad_clip = 5
+    arch_learning_rate = 3e-4
+    layers = 6
+    Fch = 12
+    width_mult_list = WML
+    prun_modes = ['max', 'arch_ratio']
+    stem_head_width = [(1, 1), (8. / 12, 8. / 12)]
+    latency_weight = [0, 1e-2]
+
+
+@pytest.mark.parametrize("unused", ["decay", "skip"])
+def test_weight_update_trajectory_matches_reference(unused):
+    """Three iterations of the reference's weight-update loop (search/train_search.py:244-250: `_loss` -> backward ->
+    clip_grad_norm_(model.parameters(), 5) -> SGD) on one batch, run by the UNMODIFIED reference in fp64 (oracle/make_golden.py
+    `trajectory`), against SupernetStep + FlatSGD in fp32.  "decay" = the reference's pinned torch 1.1 (zero-filled gradients of unused
+    parameters keep decaying them), "skip" = today's torch.  Checked: the three losses, the clip norm of every step, the final value of
+    13 tensors.  The clip norm here covers the network weights only (architecture parameters are frozen in the weight step): the
+    fixture holds both norms and the difference is asserted to be below 1e-3 relative - the deviation stated in DESIGN.md."""
+    from oracle.seeded import seeded_input, seeded_state
+    from fasterseg_amd.optim import FlatSGD
+    from fasterseg_amd.train_step import SupernetStep
+    store = load_npz("optimizer_trajectory.npz")
+    sem = "zeros" if unused == "decay" else "none"
+    st = SupernetStep(pretrain=True, cfg=_SmallSearch, compute_dtype=torch.float32, use_graphs=False)
+    sd = seeded_state(st.model.state_dict(), 777)
+    for k in list(sd):
+        if k.split("_")[0] in ("alpha", "beta", "ratio"):
+            sd[k] = sd[k] * 5.0
+    st.model.load_state_dict({k: v.cuda() for k, v in sd.items()})
+    st.optimizer = FlatSGD(st.sync, _SmallSearch.lr, _SmallSearch.momentum, _SmallSearch.weight_decay, max_norm=_SmallSearch.grad_clip,
+                           pack_dtype=torch.float32, unused=unused)
+    st._prewarmed = True
+    x = seeded_input((2, 3, 128, 256), 31).cuda()
+    g = torch.Generator().manual_seed(32)
+    target = torch.randint(0, 19, (2, 16, 32), generator=g)
+    target[torch.rand(2, 16, 32, generator=g) < 0.05] = 255
+    target = target.cuda()
+    st.model.arch_idx = 0
+    for step in range(3):
+        np.random.seed(100 + step)
+        torch.manual_seed(200 + step)
+        loss, _ = st.step(x, target)
+        want = float(store["%s/loss%d" % (sem, step)][0])
+        assert abs(float(loss) - want) <= 2e-3 * abs(want), (step, float(loss), want)
+        norm_w, norm_all = float(store["%s/norm_weights%d" % (sem, step)][0]), float(store["%s/norm_all%d" % (sem, step)][0])
+        assert abs(norm_all - norm_w) <= 1e-3 * norm_all              # what excluding alpha / beta / ratio from the clip norm changes
+        assert abs(float(st.optimizer.last_norm) - norm_w) <= 2e-2 * norm_w, (step, float(st.optimizer.last_norm), norm_w)
+    params = dict(st.model.named_parameters())
+    worst = 0.0
+    names = sorted({k[len(sem) + 7:].split("@")[0] for k in store.keys() if k.startswith(sem + "/final/")})
+    assert len(names) == 13
+    for name in names:
+        want_np, stride = golden_get(store, "%s/final/%s" % (sem, name))            # big tensors are stored as flat[::stride]
+        want = torch.from_numpy(np.asarray(want_np)).float().reshape(-1)
+        got = params[name].detach().float().cpu().reshape(-1)[::stride]
+        # compare the UPDATE (final - initial), which is what the optimizer computed
+        init = sd[name].float().reshape(-1)[::stride]
+        du_want, du_got = want - init, got - init
+        rel = float((du_got - du_want).norm() / (du_want.norm() + 1e-12))
+        worst = max(worst, rel)
+        # yardstick: what the reference's own fp32 run of the same three steps loses against its fp64 run on this tensor (7 % for
+        # the stem, 1e-3 next to the heads: tiny-batch BatchNorm amplifies fp32 rounding, DESIGN.md 4)
+        ref32 = float(store["ref_fp32_update_err/" + name][0])
+        assert rel <= 3.0 * ref32 + 2e-2, (name, rel, ref32)
+    print("trajectory %s: worst relative error of an update vs the reference's fp64 run %.3e" % (unused, worst))
