@@ -166,7 +166,8 @@ def parallelism(world, backend, what):
 def frame_traffic(family, dtype):
     """HBM bytes per launch of a kernel family of the C2 frame: profiles/r03_c2_pmc_frame.json (tools/pmc_frame.py: FETCH_SIZE / WRITE_SIZE
     passes over plan-order frames, conv3x3 and conv1x1 separately), else the round-2 table; None when there is no measurement."""
-    for name, get in (("r03_c2_pmc_frame.json", lambda d: d.get(family, {}).get("hbm_bytes_per_launch")),
+    for name, get in (("r04_c2_pmc_frame.json", lambda d: d.get(family, {}).get("hbm_bytes_per_launch")),
+                      ("r03_c2_pmc_frame.json", lambda d: d.get(family, {}).get("hbm_bytes_per_launch")),
                       ("pmc_traffic.json", lambda d: d.get(dtype, {}).get(family))):
         path = os.path.join(ROOT, "profiles", name)
         if dtype == "bf16" and os.path.exists(path):
@@ -182,7 +183,9 @@ def frame_traffic(family, dtype):
 
 def step_traffic(workload, kernels):
     """HBM bytes per launch of the given kernels of a train step from profiles/r03_<workload>_pmc.json (tools/pmc_table.py), or None."""
-    path = os.path.join(ROOT, "profiles", "r03_%s_pmc.json" % workload)
+    path = os.path.join(ROOT, "profiles", "r04_%s_pmc.json" % workload)
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", "r03_%s_pmc.json" % workload)
     if not os.path.exists(path):
         return None
     try:
@@ -195,7 +198,8 @@ def step_traffic(workload, kernels):
         return None
 
 
-STEP_FAMILY_KERNELS = {"conv_igemm (fwd + dgrad)": ("conv_igemm_kernel", "splitk_reduce_kernel"), "conv_wgrad": ("wgrad_kernel",),
+STEP_FAMILY_KERNELS = {"conv_igemm (fwd + dgrad)": ("conv_igemm_kernel", "conv_igemm2_kernel", "conv_igemm2_group_kernel", "splitk_reduce_kernel"),
+                       "conv_wgrad": ("wgrad_kernel", "wgrad_group_kernel"),
                        "conv3x3_halo": ("conv3x3_halo_kernel",)}
 
 

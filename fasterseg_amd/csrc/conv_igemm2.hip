@@ -577,6 +577,10 @@ bool igemm2_launch(hipStream_t st, ConvArgs& a, int dtype, int force_cfg, float*
     const int es = elem_size(dtype);
     if (!igemm2_qualifies(a, es)) return false;
     const bool transposed = (a.flags & FS_CONV_TRANSPOSED) != 0;
+    // bf16 maps of >= 64 k output pixels (the student step's 12 x 64 x 128 and larger): 1536+ row tiles fill the chip many times over,
+    // and conv_igemm.hip's 128-row register-staged tiles are 10-25 % faster there (r04v_c4_sweep_bf16.json: 70 vs 79 us at 64->64 on
+    // 12 x 128 x 256, 32.6 vs 41.8 us at 96->64 on 12 x 64 x 128; this kernel wins again from 24 k pixels down)
+    if (force_cfg < 0 && es == 2 && !transposed && a.M >= 65536) return false;
     const int cbu = a.Cin * es / 16;
     const int taps = a.R * a.S;
     const int steps = (taps * cbu + 7) / 8;                       // 128-byte stages of the whole contraction

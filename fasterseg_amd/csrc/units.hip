@@ -15,6 +15,16 @@
 // GB/s, so beyond a few hundred pixels the two grid-wide passes win and stay.
 static const long long BN_COL_MAX_PIXELS = 512;
 
+// The conv epilogue's statistics are one float atomic per channel address for every 32 output rows: M / 32 same-address atomics, which
+// the L2 serialises at ~20 ns each (tools/census_shapes.py c4, r04: a 32->32 conv on 12 x 64 x 128 pixels took 80 us with them, 12 us
+// without).  A separate pass over z (chan_reduce_kernel: >= 256 pixels per block, one atomic per channel per block) costs a launch
+// plus one read of the map, so the epilogue only keeps the statistics of maps where that is more than the atomics.
+static bool stats_in_epilogue(long long M, int C, int dtype) {
+    const double epilogue_us = (double)M / 32 * 0.02;
+    const double pass_us = 8.0 + (double)M * C * (dtype == FS_F32 ? 4 : 2) / 3.0e6;
+    return epilogue_us <= pass_us;
+}
+
 // the BN kernels' `relu` argument of a conv unit (common.h relu_at): bit 0 = apply, bits 8.. = first channel
 static inline int unit_relu(const fs_conv_desc* d, bool forward = false) {
     const int two = (forward && d->n_seg > 0) ? 2 : 0;      // a fused pair: two num_batches_tracked counters
@@ -84,8 +94,9 @@ extern "C" fs_status fs_conv_bn_act_train_fwd(void* stream, const fs_conv_desc* 
                                unit_relu(d, true));
     }
     // The conv epilogue's fused statistics are float atomics (run-to-run differences in the last bits of a mean) and per launch, not per
-    // group: grouped maps, and every map in bit-reproducible mode, take the separate reduction pass instead - one launch more.
-    if (groups > 1 || (workspace && fs::g_deterministic)) {
+    // group: grouped maps, every map in bit-reproducible mode, and maps large enough for the same-address atomics to cost more than a
+    // pass over z take the separate reduction pass instead - one launch more.
+    if (groups > 1 || (workspace && fs::g_deterministic) || !stats_in_epilogue(count, C, d->dtype)) {
         fs_status s = fs_conv2d_fwd_ws(stream, &c, x, w_packed, nullptr, nullptr, z, nullptr, workspace, workspace_bytes);
         if (s != FS_OK) return s;
         return fs_bn_act_train_fwd(stream, count, C, groups, z, d->y_cs, gamma, beta, eps, momentum, running_mean, running_var,
@@ -174,7 +185,8 @@ fs_status fs::unit_fwd_group(void* stream, const UnitFwdCall* u, int n) {
         const long long count = (long long)q.d->N * q.d->Ho * q.d->Wo;
         const int groups = q.d->bn_groups > 1 ? q.d->bn_groups : 1;
         FS_REQUIRE(q.d->N % groups == 0, FS_ERR_INVALID, "fs_conv_bn_act_train_fwd: batch %d is not %d equal groups", q.d->N, groups);
-        mode[i] = count / groups <= BN_COL_MAX_PIXELS ? 0 : (groups > 1 || (q.ws && fs::g_deterministic)) ? 1 : 2;
+        mode[i] = count / groups <= BN_COL_MAX_PIXELS ? 0
+                  : (groups > 1 || (q.ws && fs::g_deterministic) || !stats_in_epilogue(count, q.d->Cout, q.d->dtype)) ? 1 : 2;
         const fs_status s = conv_prepare(&c[i], q.x, q.w, nullptr, nullptr, q.z, mode[i] == 2 ? q.stats : nullptr, &args[i]);
         if (s != FS_OK) return s;
     }

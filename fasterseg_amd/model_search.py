@@ -145,6 +145,11 @@ _GROUP_PROGRAMS = bool(int(os.environ.get("FS_GROUP_PROGRAMS", "1")))
 _GROUP_CAPTURE = int(os.environ.get("FS_GROUP_CAPTURE", "0"))       # 1: on the origin stream, 2: every bucket on ONE side lane
 
 
+# SupernetStep.step(force_eager=True) - bench.py's census step - sets this: the fixed-width passes, which the timed steps replay from
+# hipGraphs, then issue the launches the capture would have recorded (ungrouped unless FS_GROUP_CAPTURE), so that the census times the
+# kernels of the timed steps and agrees with a rocprofv3 table of them.
+MIMIC_CAPTURE = False
+
 _RECORD_STREAM = bool(int(os.environ.get("FS_RECORD_STREAM", "1")))
 
 
@@ -189,7 +194,10 @@ def _run_tasks(tasks):
         if _PROGRAMS and (_CAPTURE_PROGRAMS or not capturing) and op.training and torch.is_grad_enabled():
             with FN.bn_groups(groups):
                 prog = op._program(FN.as_nhwc(x), coef, widths[0], widths[1])
-        if prog is not None and _GROUP_PROGRAMS and (not capturing or _GROUP_CAPTURE):
+        group = _GROUP_PROGRAMS and (not capturing or _GROUP_CAPTURE)
+        if MIMIC_CAPTURE and not capturing and not _SAMPLING_PASS:
+            group = group and bool(_GROUP_CAPTURE)
+        if prog is not None and group:
             grouped.append((len(pending), FN.as_nhwc(x), coef, prog))
             pending.append(None)
             continue

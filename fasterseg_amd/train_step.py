@@ -315,12 +315,15 @@ class SupernetStep:
         """One iteration.  force_eager=True issues every launch from the host (no hipGraph replay): same kernels, used by
         bench.py to take the launch census of a step."""
         from . import functional as FN
+        from . import model_search
         FN.set_compute_dtype(self.compute_dtype)
+        model_search.MIMIC_CAPTURE = bool(force_eager and self.use_graphs)
         try:
             if self.use_graphs and not force_eager:
                 return self._step_graphed(imgs, target, imgs_search, target_search)
             return self._step_eager(imgs, target, imgs_search, target_search)
         finally:
+            model_search.MIMIC_CAPTURE = False
             FN.set_compute_dtype(torch.float32)
 
     def _step_graphed(self, imgs, target, imgs_search, target_search):

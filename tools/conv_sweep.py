@@ -96,7 +96,19 @@ def main():
     ap.add_argument("--set", default="fwd,unit,dgrad,s2")
     ap.add_argument("--out", default=None)
     ap.add_argument("--quick", action="store_true", help="no forced slice counts")
+    ap.add_argument("--from-census", default=None, help="geometries = the 3x3 stride-1 launches of a tools/census_shapes.py --json table (top 14 by time)")
     args = ap.parse_args()
+    global FWD, S2
+    if args.from_census:
+        import re
+        table = json.load(open(args.from_census))
+        geo = []
+        for key, r in sorted(table.items(), key=lambda kv: -kv[1]["ms"]):
+            m = re.match(r"N(\d+) (\d+)x(\d+) (\d+)->(\d+) k(\d+) s(\d+) fl([0-9a-f]+)", key)
+            n, h, w, cin, cout, k, st, fl = [int(v, 16) if i == 7 else int(v) for i, v in enumerate(m.groups())]
+            if k == 3 and st == 1 and not fl & 0x2 and cin % 8 == 0 and (n, cin, cout, h, w) not in geo:
+                geo.append((n, cin, cout, h, w))
+        FWD, S2 = geo[:14], []
     dtypes = {"bf16": [torch.bfloat16], "fp32": [torch.float32], "both": [torch.bfloat16, torch.float32]}[args.dtype]
     sets = args.set.split(",")
     results = {}
