@@ -181,8 +181,10 @@ def frame_traffic(family, dtype):
     return None
 
 
-def step_traffic(workload, kernels):
-    """HBM bytes per launch of the given kernels of a train step from profiles/r03_<workload>_pmc.json (tools/pmc_table.py), or None."""
+def step_traffic(workload, kernels, launched=None):
+    """HBM bytes per launch of the given kernels of a train step from profiles/r0N_<workload>_pmc.json (tools/pmc_table.py: separate
+    FETCH_SIZE / WRITE_SIZE passes), or None - also when the committed PMC table does not cover the kernels the step launches NOW
+    (`launched`: name -> {"launches"} of the census step; a table taken with an older kernel would be a stale figure)."""
     path = os.path.join(ROOT, "profiles", "r04_%s_pmc.json" % workload)
     if not os.path.exists(path):
         path = os.path.join(ROOT, "profiles", "r03_%s_pmc.json" % workload)
@@ -191,6 +193,11 @@ def step_traffic(workload, kernels):
     try:
         with open(path) as f:
             d = json.load(f)
+        if launched:
+            ran = sum(v["launches"] for k, v in launched.items() if k in kernels)
+            covered = sum(v["launches"] for k, v in launched.items() if k in kernels and k in d)
+            if ran and covered < 0.9 * ran:
+                return None
         n = sum(d[k]["launches"] for k in kernels if k in d)
         b = sum(d[k]["launches"] * (d[k].get("hbm_read_bytes_per_launch", 0) + d[k].get("hbm_write_bytes_per_launch", 0)) for k in kernels if k in d)
         return int(b / n) if n else None
@@ -371,7 +378,7 @@ def _timed_census(args, world, rank, step_fn, extra_entries=(), workload=None):
         return None
     roof, families, kernels = census.roofline_timed(rec, args.dtype, PEAK_TFLOPS[args.dtype], PEAK_HBM_GBS, extra_entries)
     if roof is not None and workload and args.dtype == "bf16":
-        roof["traffic"] = step_traffic(workload, STEP_FAMILY_KERNELS.get(roof["kernel"], ()))
+        roof["traffic"] = step_traffic(workload, STEP_FAMILY_KERNELS.get(roof["kernel"], ()), kernels)
     return {"roofline": roof, "kernel_families": families, "kernels_in_step": kernels}
 
 

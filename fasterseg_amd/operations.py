@@ -10,6 +10,9 @@ fused HIP kernels (conv+BN-stats, BN-apply+ReLU, bilinear+ReLU) on NHWC tensors;
 The four residual ops share one implementation parameterised by (number of convs, zoomed or not) — the reference
 spells them out four times (operations.py:131-446).
 """
+import atexit
+import json
+import os
 import os.path as osp
 
 import numpy as np
@@ -27,20 +30,63 @@ __all__ = ['ConvNorm', 'BasicResidual1x', 'BasicResidual_downup_1x', 'BasicResid
 # Per-operator latency table with the reference's key grammar and on-disk format (operations.py:33-36):
 # a pickled dict str -> ms in ./latency_lookup_table.npy.  Entries produced here are hipEvent timings of these
 # kernels on MI355X (fasterseg_amd.latency), not TensorRT/1080Ti numbers.
+#
+# Persistence: the reference rewrites the whole pickled dict on every miss (operations.py:116-122) - quadratic while a search fills the
+# 667-key table.  Here a miss appends ONE line to `<table>.journal` (durable at once, O(1)); the `.npy` - the file the reference and
+# later processes load - is rewritten once, by flush_latency_table() (registered with atexit, callable earlier), and a journal left
+# behind by a killed process is merged at the next import.
 latency_lookup_table = {}
 table_file_name = "latency_lookup_table.npy"
-if osp.isfile(table_file_name):
-    latency_lookup_table = np.load(table_file_name, allow_pickle=True).item()
+_journal_dirty = False
+
+
+def _journal_name():
+    return table_file_name + ".journal"
+
+
+def _load_latency_table():
+    if osp.isfile(table_file_name):
+        latency_lookup_table.update(np.load(table_file_name, allow_pickle=True).item())
+    if osp.isfile(_journal_name()):
+        global _journal_dirty
+        with open(_journal_name()) as f:
+            for line in f:
+                line = line.strip()
+                if line:
+                    try:
+                        key, ms = json.loads(line)
+                    except ValueError:                      # torn last line of a killed writer
+                        continue
+                    latency_lookup_table[key] = ms
+                    _journal_dirty = True
+
+
+def flush_latency_table():
+    """Writes the table in the reference's format (one np.save) and retires the journal; a no-op when nothing was measured."""
+    global _journal_dirty
+    if not _journal_dirty:
+        return
+    np.save(table_file_name, dict(latency_lookup_table))
+    _journal_dirty = False
+    if osp.isfile(_journal_name()):
+        os.remove(_journal_name())
+
+
+_load_latency_table()
+atexit.register(flush_latency_table)
 
 
 def lookup_latency(name, measure):
-    """LUT hit, or measure + insert + persist the whole dict (operations.py:116-122)."""
+    """LUT hit, or measure + insert + journal the new entry (operations.py:116-122; see the persistence note above)."""
+    global _journal_dirty
     if name in latency_lookup_table:
         return latency_lookup_table[name]
     print("not found in latency_lookup_table:", name)
     latency = measure()
     latency_lookup_table[name] = latency
-    np.save(table_file_name, latency_lookup_table)
+    with open(_journal_name(), "a") as f:
+        f.write(json.dumps([name, float(latency)]) + "\n")
+    _journal_dirty = True
     return latency
 
 

@@ -27,7 +27,12 @@ def test_forward_latency_lookup_and_miss_path(tmp_path, monkeypatch):
     assert (lat, size) == (0.123, (64, 64, 128)) and calls == [(1, 32, 128, 256)]
     key = "BasicResidual2x_H128_W256_Cin32_Cout64_stride2_dilation1"
     assert operations.latency_lookup_table == {key: 0.123}
-    assert np.load("latency_lookup_table.npy", allow_pickle=True).item() == {key: 0.123}     # reference on-disk format
+    # a miss appends one journal line; the table file - the reference's on-disk format - is written once, by the flush (atexit)
+    assert not os.path.exists("latency_lookup_table.npy")
+    assert [json.loads(l) for l in open("latency_lookup_table.npy.journal")] == [[key, 0.123]]
+    operations.flush_latency_table()
+    assert np.load("latency_lookup_table.npy", allow_pickle=True).item() == {key: 0.123}
+    assert not os.path.exists("latency_lookup_table.npy.journal")
     op.forward_latency((32, 128, 256))
     assert len(calls) == 1                                                                      # second call is a hit
     # the zoomed-2x quirk: priced under the BasicResidual2x key (reference operations.py:426-431)
@@ -37,6 +42,34 @@ def test_forward_latency_lookup_and_miss_path(tmp_path, monkeypatch):
     s.set_ratio((4. / 12, 1.))
     with pytest.raises(AssertionError):
         s.forward_latency((96, 32, 64))          # c_in must equal int(C_in * ratio)
+
+
+def test_latency_table_persistence_is_one_save_and_survives_a_killed_process(tmp_path, monkeypatch):
+    """the reference rewrites the whole pickled dict on every miss (operations.py:116-122)."""
+    from fasterseg_amd import operations
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(operations, "latency_lookup_table", {})
+    saves = []
+    real_save = np.save
+    monkeypatch.setattr(np, "save", lambda *a, **k: (saves.append(a[0]), real_save(*a, **k))[1])
+    for i in range(50):
+        assert operations.lookup_latency("key_%d" % i, lambda i=i: 0.01 * i) == 0.01 * i
+    assert saves == [] and sum(1 for _ in open("latency_lookup_table.npy.journal")) == 50
+    operations.flush_latency_table()
+    operations.flush_latency_table()                       # nothing new: no second write
+    assert saves == ["latency_lookup_table.npy"]
+    assert np.load("latency_lookup_table.npy", allow_pickle=True).item() == {"key_%d" % i: 0.01 * i for i in range(50)}
+    # a process killed before its flush leaves the journal (possibly with a torn last line): the next import merges it
+    operations.lookup_latency("late", lambda: 1.5)
+    with open("latency_lookup_table.npy.journal", "a") as f:
+        f.write('["torn", 0.')
+    monkeypatch.setattr(operations, "latency_lookup_table", {})
+    monkeypatch.setattr(operations, "_journal_dirty", False)
+    operations._load_latency_table()
+    assert operations.latency_lookup_table["late"] == 1.5 and len(operations.latency_lookup_table) == 51
+    operations.flush_latency_table()
+    assert np.load("latency_lookup_table.npy", allow_pickle=True).item()["late"] == 1.5
+    assert not os.path.exists("latency_lookup_table.npy.journal")
 
 
 @pytest.mark.gpu

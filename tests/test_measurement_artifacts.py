@@ -89,3 +89,46 @@ def test_census_prices_stride2_data_gradients_at_their_algorithmic_work():
     assert census.conv_flops(dgrad) == census.conv_flops(fwd)
     dense = ConvDesc(3, 16, 32, 192, 96, 3, 3, 1, 1, 32, 64, 192, 96, 1, 0)
     assert census.conv_flops(dense) == 4 * census.conv_flops(dgrad)
+
+
+# ---- round 4: the compact line + its detail file, and the census step that mimics the captured passes ------------------------------
+def _bench_r04():
+    line, detail = os.path.join(PROFILES, "r04_bench_default.json"), os.path.join(PROFILES, "r04_bench_default_detail.json")
+    if not (os.path.exists(line) and os.path.exists(detail)):
+        pytest.skip("no committed round-4 bench line")
+    text = [l for l in open(line) if l.startswith('{"metric"')][-1]
+    return text, json.loads(text), json.load(open(detail))
+
+
+def test_r04_bench_line_is_small_gated_and_complete():
+    text, d, detail = _bench_r04()
+    assert len(text.strip()) < 4096                                           # the driver's parser gave up on round 3's 20 KB line
+    assert d["parity"]["pass"] and d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["unit"] == "frames/s"
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in d["roofline"]
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
+    for key in ("C3_supernet_pretrain", "C4_student_train", "C5_supernet_search"):
+        w = d["workloads"][key]
+        assert w["parity"]["pass"] and w["parity"]["rel_err"] <= 1e-2, key
+        assert w["steps"] == 20 and w["fp32_steps"] >= 10 and w["ms_per_step_fp32"] > w["ms_per_step"] > 0, key
+        assert 0 < w["roofline"]["frac"] < 1 and w["cpu_baseline"]["value"] > 0, key
+        assert "before" in detail["clocks"][key] and "after" in detail["clocks"][key], key     # rocm-smi clocks / power beside every run
+
+
+@pytest.mark.parametrize("key,table", [("C3_supernet_pretrain", "r04_c3_supernet_pretrain_bf16_kernel_stats.csv"),
+                                       ("C4_student_train", "r04_c4_student_train_bf16_kernel_stats.csv")])
+def test_r04_census_families_agree_with_the_profiler_tables_of_the_timed_steps(key, table):
+    """The census step issues what the timed steps replay (fixed-width passes ungrouped as captured, sampled-width passes grouped): its
+    family times must match a rocprofv3 --kernel-trace table of the timed steps taken on the same box to 6 % (measured 0.5-4 %)."""
+    _, _, detail = _bench_r04()
+    path = os.path.join(PROFILES, table)
+    if not os.path.exists(path):
+        pytest.skip("no profiler table")
+    prof = {}
+    for r in csv.DictReader(open(path)):
+        prof[_short(r["Name"])] = prof.get(_short(r["Name"]), 0.0) + float(r["MsPerStep"])
+    fam = detail[key]["kernel_families"]
+    for name, kernels in (("conv_igemm (fwd + dgrad)", ("conv_igemm_kernel", "conv_igemm2_kernel", "conv_igemm2_group_kernel", "splitk_reduce_kernel")),
+                          ("conv_wgrad", ("wgrad_kernel", "wgrad_group_kernel"))):
+        ms = sum(prof.get(k, 0.0) for k in kernels)
+        assert abs(fam[name]["ms_per_step"] / ms - 1.0) <= 0.06, (key, name, fam[name]["ms_per_step"], ms)
