@@ -246,34 +246,6 @@ __device__ __forceinline__ void igemm2_body(const ConvArgs& p, const int bid, co
             for (int j = 0; j < WN_T; ++j) f.b[kk][j] = *reinterpret_cast<const u32x4*>(st + b_frag[j] + f_slot[kk]);
         }
     };
-    // ABL == 4 (measurement build, codes 130+): the loads of a stage are not fired in one burst behind the barrier but one at a time in
-    // front of the MFMAs of each K sub-step - tools/probes/lds_dma_fill.hip measured 63 B/clk/CU for evenly paced LDS-DMA against 38-40
-    // for bursts of four per wave and 32 with the block barrier in front of the burst (profiles/r04_lds_dma_gather.csv)
-    auto fire_part = [&](int buf, int kk) {
-        unsigned char* dst = smem + buf * STAGE_BYTES + wave * 1024;
-#pragma unroll
-        for (int a = 0; a < A_SLOTS; ++a)
-            if (a * KU / SLOTS == kk) {
-                const uint32_t off = off_a[a];
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(dst + a * 4096), 16, off, 0, 0, 0);
-            }
-#pragma unroll
-        for (int b = 0; b < B_SLOTS; ++b)
-            if ((A_SLOTS + b) * KU / SLOTS == kk) {
-                const uint32_t off = off_b[b];
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(dst + (A_SLOTS + b) * 4096), 16, off, 0, 0, 0);
-            }
-    };
-    auto mma_fire = [&](const Frags& f, int buf) {
-#pragma unroll
-        for (int kk = 0; kk < KU; ++kk) {
-            fire_part(buf, kk);
-#pragma unroll
-            for (int i = 0; i < WM_T; ++i)
-#pragma unroll
-                for (int j = 0; j < WN_T; ++j) Mma<T>::run(f.a[kk][i], f.b[kk][j], acc[i][j]);
-        }
-    };
     auto mma = [&](const Frags& f) {
         if (ABL == 1) return;
 #pragma unroll
@@ -315,12 +287,14 @@ __device__ __forceinline__ void igemm2_body(const ConvArgs& p, const int bid, co
             wait_landed(nsteps - 2 - t);                           // stage t + 1 landed; up to NSTAGE - 2 newer ones stay in flight
             __builtin_amdgcn_s_barrier();                          // ... in every wave, and every wave holds stage t in registers
             asm volatile("" ::: "memory");
-            if (ABL != 4 && t + NSTAGE < nsteps) fire(buf_t);            // stage t's buffer is free
+            if (t + NSTAGE < nsteps) fire(buf_t);            // stage t's buffer is free
+            // ABL == 4 (measurement build, codes 130-133): the offsets of the NEXT stage's loads (LDS table look-ups + ~40 VALU) are
+            // generated here, under the MFMAs, instead of after them where their LDS latency lands on the next step's counted wait
+            if (ABL == 4 && t + NSTAGE + 1 < nsteps) gen(t + NSTAGE + 1);
             read_frags(nxt, buf_t + 1 == NSTAGE ? 0 : buf_t + 1);
         }
-        if (ABL == 4 && more && t + NSTAGE < nsteps) mma_fire(cur, buf_t);
-        else mma(cur);
-        if (t + NSTAGE + 1 < nsteps) gen(t + NSTAGE + 1);
+        mma(cur);
+        if (ABL != 4 && t + NSTAGE + 1 < nsteps) gen(t + NSTAGE + 1);
     };
     {
         int buf = 0;
@@ -490,7 +464,7 @@ template <typename T> static void launch2(hipStream_t st, const ConvArgs& a, int
         case 23: FS_LAUNCH((conv_igemm2_kernel<T, 1, 1, 4, 1, 1, 4, 1>), dim3((unsigned)grid), dim3(256), 0, st, a); break;   // ... of 32 x 32 K4
         case 24: FS_LAUNCH((conv_igemm2_kernel<T, 1, 1, 4, 1, 1, 4, 2>), dim3((unsigned)grid), dim3(256), 0, st, a); break;
         case 25: FS_LAUNCH((conv_igemm2_kernel<T, 1, 1, 4, 1, 1, 4, 3>), dim3((unsigned)grid), dim3(256), 0, st, a); break;
-        case 30: FS_LAUNCH((conv_igemm2_kernel<T, 2, 2, 1, 1, 1, 4, 4>), dim3((unsigned)grid), dim3(256), 0, st, a); break;   // paced loads: 64 x 64
+        case 30: FS_LAUNCH((conv_igemm2_kernel<T, 2, 2, 1, 1, 1, 4, 4>), dim3((unsigned)grid), dim3(256), 0, st, a); break;   // offsets generated under the MFMAs: 64 x 64
         case 31: FS_LAUNCH((conv_igemm2_kernel<T, 1, 1, 4, 1, 1, 4, 4>), dim3((unsigned)grid), dim3(256), 0, st, a); break;   // ... 32 x 32 K4
         case 32: FS_LAUNCH((conv_igemm2_kernel<T, 2, 1, 2, 1, 1, 4, 4>), dim3((unsigned)grid), dim3(256), 0, st, a); break;   // ... 64 x 32 K2
         case 33: FS_LAUNCH((conv_igemm2_kernel<T, 2, 2, 1, 2, 2, 3, 4>), dim3((unsigned)grid), dim3(256), 0, st, a); break;   // ... 128 x 128
@@ -657,7 +631,7 @@ bool igemm2_launch(hipStream_t st, ConvArgs& a, int dtype, int force_cfg, float*
             }
         }
     }
-    static const int PACED[4] = {0, 4, 5, 3};                    // codes 130-133: the tile of that configuration with paced loads
+    static const int PACED[4] = {0, 4, 5, 3};                    // codes 130-133: that configuration's tile, measurement variant ABL 4
     const int tile = cfg >= 30 ? PACED[cfg - 30] : cfg >= 23 ? 4 : cfg >= 20 ? 0 : cfg;
     const int bm = CFG2[tile].bm, bn = CFG2[tile].bn;
     // cross-block split-K: fp32 slabs [slices][M][Cout] in the caller's workspace, summed by splitk_reduce / the BatchNorm kernel

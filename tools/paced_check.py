@@ -1,4 +1,4 @@
-"""conv_igemm2 with paced loads (codes 130-133: one LDS-DMA in front of every K sub-step's MFMAs) against the burst-behind-the-barrier
+"""conv_igemm2 measurement variants (codes 130-133 = ABL 4 of csrc/conv_igemm2.hip) against the production
 kernel (100, 104, 105, 103): same bits, and the time per launch.  python tools/paced_check.py [fp32]"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

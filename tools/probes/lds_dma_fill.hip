@@ -79,18 +79,13 @@ __global__ __launch_bounds__(WAVES * 64) void gather_kernel(const unsigned char*
     };
 #pragma unroll
     for (int s = 0; s < AHEAD; ++s) issue(s);
-    int stage = AHEAD % NSTAGE;
-    for (int t = 0; t < steps; ++t) {
-        wait_vm<4 * (AHEAD - 1)>();
-        if (BARRIER) __builtin_amdgcn_s_barrier();
-        switch (stage) {                                                  // (the LDS address of an LDS-DMA is an M0 immediate per site)
-            case 0: issue(0); break;
-            case 1: issue(1); break;
-            case 2: issue(2); break;
-            case 3: issue(3); break;
-            default: issue(4); break;
+    for (int t = 0; t < steps; t += NSTAGE) {                            // (straight-line: the LDS address of an LDS-DMA is an M0 value per site)
+#pragma unroll
+        for (int u = 0; u < NSTAGE; ++u) {
+            wait_vm<4 * (AHEAD - 1)>();
+            if (BARRIER) __builtin_amdgcn_s_barrier();
+            issue((AHEAD + u) % NSTAGE);
         }
-        stage = stage + 1 == NSTAGE ? 0 : stage + 1;
     }
     wait_vm<0>();
     __syncthreads();
@@ -132,6 +127,43 @@ __global__ __launch_bounds__(WAVES * 64) void gather1_kernel(const unsigned char
     if (steps < 0) sink[threadIdx.x] = *(unsigned*)(smem + threadIdx.x * 4);
 }
 
+// Wave-private K-interleaved pipelines (the design DESIGN.md section 7.1 proposes): every wave owns a ring of 2 stages of LOADS 1-KB loads
+// (a whole 64 x 64 bf16 operand stage = 16), waits for ITS oldest stage only, "computes" for SLEEP x 64 clocks, re-issues the stage;
+// no block barrier anywhere.
+template <int WAVES, int LOADS, int SLEEP>
+__global__ __launch_bounds__(WAVES * 64) void private_kernel(const unsigned char* src, unsigned window, int private_window, unsigned pitch, int steps,
+                                                            unsigned* sink) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const unsigned char* base = src + (private_window ? (size_t)blockIdx.x * window : 0);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+    const unsigned rows = (window - 128) / pitch / (LOADS * 8) * (LOADS * 8);
+    unsigned row = (unsigned)(lane >> 3), k = (unsigned)wave * 128;            // wave w takes the K steps t = w (mod WAVES)
+    unsigned char* dst = smem + wave * (2 * LOADS * 1024);
+    auto issue = [&](int stage) {
+#pragma unroll
+        for (int i = 0; i < LOADS; ++i) {
+            const unsigned o = (row + i * 8) * pitch + k + (lane & 7) * 16;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + (stage * LOADS + i) * 1024), 16, o, 0, 0, 0);
+        }
+        k += WAVES * 128;
+        if (k + 128 > pitch) { k = (unsigned)wave * 128; row += LOADS * 8; if (row >= rows) row -= rows; }
+    };
+    issue(0);
+    issue(1);
+    for (int t = 0; t < steps; t += 2) {
+        wait_vm<LOADS>();
+        if (SLEEP) __builtin_amdgcn_s_sleep(SLEEP);
+        issue(0);
+        wait_vm<LOADS>();
+        if (SLEEP) __builtin_amdgcn_s_sleep(SLEEP);
+        issue(1);
+    }
+    wait_vm<0>();
+    __syncthreads();
+    if (steps < 0) sink[threadIdx.x] = *(unsigned*)(smem + threadIdx.x * 4);
+}
+
 struct Result { int waves, inflight, mode, grid, priv; unsigned window; double us, gbs_cu, bclk_cu; };
 
 struct GResult { int waves, ahead, barrier, grid; unsigned pitch, misalign, rowlen; double us, bclk_cu; };
@@ -156,7 +188,7 @@ static int run_gather(const unsigned char* src, unsigned pitch, unsigned misalig
         if (rep > 0 && ms < best) best = ms;
     }
     CK(hipGetLastError());
-    const double bytes = (double)WAVES * 4096 * (steps + AHEAD), us = best * 1e3 - 4.0;
+    const double bytes = (double)WAVES * 4096 * ((steps + AHEAD) / (AHEAD + 1) * (AHEAD + 1) + AHEAD), us = best * 1e3 - 4.0;
     GResult r = {WAVES, AHEAD, BARRIER, grid, pitch, misalign, rowlen, best * 1e3, bytes / (us * 1e-6) / 2.4e9};
     out.push_back(r);
     CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
@@ -227,6 +259,51 @@ static int run_gather1(const unsigned char* src, unsigned pitch, unsigned misali
     return 0;
 }
 
+template <int WAVES, int LOADS, int SLEEP>
+static int run_private(const unsigned char* src, unsigned pitch, int grid, unsigned* sink) {
+    const unsigned window = 256u << 10;
+    const int priv = grid <= 64;
+    const int steps = (int)((8u << 20) / (WAVES * LOADS * 1024)) - 2;
+    const size_t lds = (size_t)WAVES * 2 * LOADS * 1024 > 96 * 1024 ? (size_t)WAVES * 2 * LOADS * 1024 : 96 * 1024;
+    auto k = private_kernel<WAVES, LOADS, SLEEP>;
+    CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float best = 1e30f;
+    for (int rep = 0; rep < 4; ++rep) {
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(k, dim3(grid), dim3(WAVES * 64), lds, 0, src, window, priv, pitch, steps, sink);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep > 0 && ms < best) best = ms;
+    }
+    CK(hipGetLastError());
+    const double bytes = (double)WAVES * LOADS * 1024 * (steps / 2 * 2 + 2), us = best * 1e3 - 4.0;
+    printf("private,%d,%d,%d,%d,%u,%.1f,%.2f\n", grid, WAVES, LOADS, SLEEP, pitch, best * 1e3, bytes / (us * 1e-6) / 2.4e9);
+    CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
+    return 0;
+}
+
+static int private_main(const unsigned char* src, unsigned* sink) {
+    printf("private: grid,waves,loads_per_stage,sleep_x64clk,pitch,us,B_per_clk_per_cu\n");
+    for (int gi = 0; gi < 2; ++gi) {
+        const int grid = gi == 0 ? 64 : 256;
+        for (unsigned pitch = 768; pitch <= 1536; pitch += 768) {
+            if (run_private<4, 16, 0>(src, pitch, grid, sink)) return 1;
+            if (run_private<4, 16, 8>(src, pitch, grid, sink)) return 1;
+            if (run_private<4, 16, 15>(src, pitch, grid, sink)) return 1;
+            if (run_private<4, 8, 0>(src, pitch, grid, sink)) return 1;
+            if (run_private<4, 8, 8>(src, pitch, grid, sink)) return 1;
+            if (run_private<4, 4, 0>(src, pitch, grid, sink)) return 1;
+            if (run_private<4, 4, 4>(src, pitch, grid, sink)) return 1;
+            if (run_private<8, 8, 0>(src, pitch, grid, sink)) return 1;
+            if (run_private<8, 8, 15>(src, pitch, grid, sink)) return 1;
+        }
+    }
+    return 0;
+}
+
 static int gather_main(const unsigned char* src, unsigned* sink) {
     std::vector<GResult> out;
     const unsigned pat[7][3] = {{128, 0, 128}, {256, 0, 256}, {256, 64, 256}, {768, 0, 768}, {768, 64, 768}, {192, 0, 192}, {832, 0, 768}};
@@ -257,6 +334,7 @@ int main(int argc, char** argv) {
     unsigned char* src; unsigned* sink;
     CK(hipMalloc(&src, total)); CK(hipMemset(src, 1, total)); CK(hipMalloc(&sink, 4096 * 4));
     if (argc > 1 && argv[1][0] == 'g') return gather_main(src, sink);
+    if (argc > 1 && argv[1][0] == 'p') return private_main(src, sink);
     std::vector<Result> out;
     const unsigned windows[3] = {64u << 10, 1u << 20, 4u << 20};          // private 64 KB tiles (16 MB in all: L2-resident); private 1 MB (256 MB in all: MALL / HBM); one SHARED 4 MB bank (a filter bank every block reads)
     for (int wi = 0; wi < 3; ++wi) {
