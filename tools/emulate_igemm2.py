@@ -209,23 +209,24 @@ def run_case(N, Cin, H, W, Cout, k, stride, pad, BM, BN, slices=1, dgrad=False, 
     return err
 
 
+CASES = [
+    dict(N=1, Cin=32, H=9, W=11, Cout=40, k=3, stride=1, pad=1, BM=64, BN=64),
+    dict(N=2, Cin=16, H=7, W=9, Cout=24, k=3, stride=2, pad=1, BM=32, BN=32),
+    dict(N=1, Cin=48, H=6, W=8, Cout=72, k=3, stride=1, pad=1, BM=64, BN=64, slices=3),
+    dict(N=2, Cin=24, H=8, W=6, Cout=16, k=1, stride=2, pad=0, BM=32, BN=32),
+    dict(N=2, Cin=24, H=8, W=6, Cout=16, k=1, stride=2, pad=-1, BM=32, BN=32),
+    dict(N=1, Cin=8, H=5, W=7, Cout=8, k=3, stride=1, pad=1, BM=32, BN=32),
+    dict(N=1, Cin=40, H=12, W=10, Cout=136, k=3, stride=1, pad=1, BM=128, BN=64, slices=2),
+    # data gradients: stride 1 (plain), stride 2 by parity classes, even and odd maps, 1x1 with both FactorizedReduce offsets
+    dict(N=1, Cin=16, H=8, W=10, Cout=24, k=3, stride=1, pad=1, BM=64, BN=64, dgrad=True),
+    dict(N=2, Cin=16, H=8, W=12, Cout=24, k=3, stride=2, pad=1, BM=32, BN=32, dgrad=True),
+    dict(N=1, Cin=16, H=9, W=13, Cout=32, k=3, stride=2, pad=1, BM=64, BN=64, dgrad=True),
+    dict(N=2, Cin=24, H=8, W=6, Cout=16, k=1, stride=2, pad=0, BM=32, BN=32, dgrad=True),
+    dict(N=2, Cin=24, H=8, W=6, Cout=16, k=1, stride=2, pad=-1, BM=32, BN=32, dgrad=True),
+    dict(N=1, Cin=16, H=7, W=5, Cout=16, k=1, stride=2, pad=-1, BM=32, BN=32, dgrad=True),
+]
+
 if __name__ == "__main__":
-    cases = [
-        dict(N=1, Cin=32, H=9, W=11, Cout=40, k=3, stride=1, pad=1, BM=64, BN=64),
-        dict(N=2, Cin=16, H=7, W=9, Cout=24, k=3, stride=2, pad=1, BM=32, BN=32),
-        dict(N=1, Cin=48, H=6, W=8, Cout=72, k=3, stride=1, pad=1, BM=64, BN=64, slices=3),
-        dict(N=2, Cin=24, H=8, W=6, Cout=16, k=1, stride=2, pad=0, BM=32, BN=32),
-        dict(N=2, Cin=24, H=8, W=6, Cout=16, k=1, stride=2, pad=-1, BM=32, BN=32),
-        dict(N=1, Cin=8, H=5, W=7, Cout=8, k=3, stride=1, pad=1, BM=32, BN=32),
-        dict(N=1, Cin=40, H=12, W=10, Cout=136, k=3, stride=1, pad=1, BM=128, BN=64, slices=2),
-        # data gradients: stride 1 (plain), stride 2 by parity classes, even and odd maps, 1x1 with both FactorizedReduce offsets
-        dict(N=1, Cin=16, H=8, W=10, Cout=24, k=3, stride=1, pad=1, BM=64, BN=64, dgrad=True),
-        dict(N=2, Cin=16, H=8, W=12, Cout=24, k=3, stride=2, pad=1, BM=32, BN=32, dgrad=True),
-        dict(N=1, Cin=16, H=9, W=13, Cout=32, k=3, stride=2, pad=1, BM=64, BN=64, dgrad=True),
-        dict(N=2, Cin=24, H=8, W=6, Cout=16, k=1, stride=2, pad=0, BM=32, BN=32, dgrad=True),
-        dict(N=2, Cin=24, H=8, W=6, Cout=16, k=1, stride=2, pad=-1, BM=32, BN=32, dgrad=True),
-        dict(N=1, Cin=16, H=7, W=5, Cout=16, k=1, stride=2, pad=-1, BM=32, BN=32, dgrad=True),
-    ]
-    for c in cases:
+    for c in CASES:
         print(c, "max err %.2e" % run_case(**c))
     print("ok")
