@@ -56,3 +56,23 @@ def test_line_without_optional_parts():
     line, _ = bench.build_line(c2, {}, 2, None, "bf16", None)
     assert line["n_gpus"] == 2 and "roofline" not in line and line["detail"] is None
     assert len(json.dumps(line)) < 1500
+
+
+def test_step_traffic_is_null_when_the_pmc_table_predates_the_kernels():
+    """`roofline.traffic` comes from committed PMC passes (profiles/r0N_<workload>_pmc.json); a table taken before a kernel was replaced
+    must not be quoted for the new kernel."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    fam = bench.STEP_FAMILY_KERNELS["conv_igemm (fwd + dgrad)"]
+    if not os.path.exists(os.path.join(root, "profiles", "r03_c3_pmc.json")) or os.path.exists(os.path.join(root, "profiles", "r04_c3_pmc.json")):
+        import pytest
+        pytest.skip("needs the round-3 PMC table as the newest one")
+    old_step = {"conv_igemm_kernel": {"launches": 3352}}
+    new_step = {"conv_igemm2_kernel": {"launches": 1800}, "conv_igemm2_group_kernel": {"launches": 636}, "conv_igemm_kernel": {"launches": 100}}
+    assert bench.step_traffic("c3", fam, old_step) > 1e6                  # the kernels the table was taken with: quoted
+    assert bench.step_traffic("c3", fam, new_step) is None                # mostly kernels the table has never seen: null
+    assert bench.step_traffic("c3", fam) > 1e6                            # (no launch table given: the caller vouches)
