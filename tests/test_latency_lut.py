@@ -20,6 +20,7 @@ def test_forward_latency_lookup_and_miss_path(tmp_path, monkeypatch):
     from fasterseg_amd import operations
     monkeypatch.chdir(tmp_path)
     monkeypatch.setattr(operations, "latency_lookup_table", {})
+    monkeypatch.setattr(operations, "_journal_dirty", False)
     calls = []
     monkeypatch.setattr(operations, "compute_latency", lambda model, size: calls.append(size) or 0.123)
     op = operations.BasicResidual2x(32, 64, stride=2, slimmable=False)
@@ -49,6 +50,7 @@ def test_latency_table_persistence_is_one_save_and_survives_a_killed_process(tmp
     from fasterseg_amd import operations
     monkeypatch.chdir(tmp_path)
     monkeypatch.setattr(operations, "latency_lookup_table", {})
+    monkeypatch.setattr(operations, "_journal_dirty", False)          # (restored at teardown: nothing is left for the atexit flush)
     saves = []
     real_save = np.save
     monkeypatch.setattr(np, "save", lambda *a, **k: (saves.append(a[0]), real_save(*a, **k))[1])
