@@ -64,7 +64,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the fp32 re-run of every train workload")
     ap.add_argument("--no-class-map", action="store_true", help="skip the class-map (evaluator) variant of the C2 engine")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU budget of each cpu_baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=25.0, help="CPU budget of each cpu_baseline sample")
     ap.add_argument("--dump-plan", default=None, help="write the per-launch table of the C2 plan (json) here")
     ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"),
                     help="everything that is not in the (small) JSON line goes here: autotune logs, per-kernel tables, clocks, method strings")
@@ -166,7 +166,8 @@ def parallelism(world, backend, what):
 def frame_traffic(family, dtype):
     """HBM bytes per launch of a kernel family of the C2 frame: profiles/r03_c2_pmc_frame.json (tools/pmc_frame.py: FETCH_SIZE / WRITE_SIZE
     passes over plan-order frames, conv3x3 and conv1x1 separately), else the round-2 table; None when there is no measurement."""
-    for name, get in (("r04_c2_pmc_frame.json", lambda d: d.get(family, {}).get("hbm_bytes_per_launch")),
+    for name, get in (("r05_c2_pmc_frame.json", lambda d: d.get(family, {}).get("hbm_bytes_per_launch")),
+                      ("r04_c2_pmc_frame.json", lambda d: d.get(family, {}).get("hbm_bytes_per_launch")),
                       ("r03_c2_pmc_frame.json", lambda d: d.get(family, {}).get("hbm_bytes_per_launch")),
                       ("pmc_traffic.json", lambda d: d.get(dtype, {}).get(family))):
         path = os.path.join(ROOT, "profiles", name)
@@ -185,10 +186,11 @@ def step_traffic(workload, kernels, launched=None):
     """HBM bytes per launch of the given kernels of a train step from profiles/r0N_<workload>_pmc.json (tools/pmc_table.py: separate
     FETCH_SIZE / WRITE_SIZE passes), or None - also when the committed PMC table does not cover the kernels the step launches NOW
     (`launched`: name -> {"launches"} of the census step; a table taken with an older kernel would be a stale figure)."""
-    path = os.path.join(ROOT, "profiles", "r04_%s_pmc.json" % workload)
-    if not os.path.exists(path):
-        path = os.path.join(ROOT, "profiles", "r03_%s_pmc.json" % workload)
-    if not os.path.exists(path):
+    for rnd in ("r05", "r04", "r03"):
+        path = os.path.join(ROOT, "profiles", "%s_%s_pmc.json" % (rnd, workload))
+        if os.path.exists(path):
+            break
+    else:
         return None
     try:
         with open(path) as f:
@@ -308,6 +310,23 @@ def run_student_infer(args, world, rank, backend):
         if args.dump_plan:
             with open(args.dump_plan, "w") as f:
                 json.dump(rows, f, indent=1)
+    if rank == 0 and args.dtype == "bf16" and not args.no_fp32_leg:
+        # north_star's bar in ONE record: ">= 163 fps with logits within 1e-3 of the reference" is an fp32 statement (the published
+        # 163.9 FPS is TensorRT fp32, latency/run_latency.py:81) - the same engine in fp32 storage + exact-fp32 MFMA, gated and timed
+        torch.cuda.empty_cache()
+        eng32 = engine.InferenceEngine(net, shape, dtype=torch.float32, logits_dtype=torch.float32)
+        with torch.no_grad():
+            got32 = eng32(x.cuda()).float().cpu()
+        err32 = float((got32 - want).abs().max())
+        if not err32 <= 1e-3:
+            raise SystemExit("bench.py: fp32 engine logits differ from the CPU oracle by %.3e (> 1e-3)" % err32)
+        el32, steps32 = timed_region(eng32.run, args.steps, args.warmup, 1, args.min_seconds, args.exact, args.regions)
+        line["fp32"] = {"value": round(steps32 / el32, 2), "unit": "frames/s", "ms_per_step": round(el32 / steps32 * 1e3, 4), "steps": steps32,
+                        "max_abs_err": err32, "argmax_agreement": float((got32.argmax(1) == want.argmax(1)).float().mean()),
+                        "vs_baseline": round(steps32 / el32 / PUBLISHED_STUDENT_FPS, 3), "launches": len(eng32.calls),
+                        "note": PRECISION["fp32"] + "; logits vs oracle.ref_ops.derived_forward on the same weights and frame, bar 1e-3"}
+        del eng32, got32
+        torch.cuda.empty_cache()
     if rank == 0 and not args.no_class_map:
         # the evaluator path: same network, class map (uint8) instead of fp32 logits as the output
         eng_c = engine.InferenceEngine(net, shape, dtype=dtype, output="classes")
@@ -320,18 +339,13 @@ def run_student_infer(args, world, rank, backend):
                                      "launch, 2 MB uint8 out instead of 159 MB fp32 logits"}
         del eng_c
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        with torch.no_grad():
-            n, t0 = 0, time.perf_counter()
-            while True:
+        def cpu_frame():
+            with torch.no_grad():
                 ref_ops.derived_forward(params, meta, x)
-                n += 1
-                el = time.perf_counter() - t0
-                if el >= args.cpu_seconds or n >= 50:
-                    break
-        line["cpu_baseline"] = {"value": round(n / el, 3), "unit": "frames/s", "cores": cores, "kind": "port",
-                                "sample": "%d frames of 1x3x1024x2048 fp32 through oracle/ref_ops.derived_forward (port of train/model_seg.py "
-                                          "on torch-CPU kernels, pinned to fixtures generated from the unmodified reference), %.1f s; first "
-                                          "(cold) frame %.2f s" % (n, el, oracle_s)}
+        line["cpu_baseline"] = _time_cpu(cpu_frame, 1, args.cpu_seconds,
+                                         "frames of 1x3x1024x2048 fp32 through oracle/ref_ops.derived_forward (port of train/model_seg.py on "
+                                         "torch-CPU kernels, fixture-pinned); first (cold, %d threads) frame %.2f s" % (cores, oracle_s),
+                                         unit="frames/s")
     return line
 
 
@@ -462,34 +476,50 @@ def run_student_train(args, world, rank, backend):
     return line
 
 
-def _time_cpu(fn, images, budget_s, what, threads=None):
-    """`threads`: the supernet's maps are tiny (a few thousand pixels): with one thread per core of a 128-core host the torch-CPU
-    kernels spend their time in fork/join, so that baseline runs on a bounded pool (stated in `cores`)."""
+CPU_THREAD_SWEEP = (16, 32, 8, 64)              # tried in this order until the sample's budget is spent
+
+
+def _time_cpu(fn, images, budget_s, what, threads=None, unit="images/s"):
+    """cpu_baseline of one workload: `fn` = one pass of the CPU oracle over `images` units.  The oracle's maps are small (45 convs on a
+    frame, a few thousand pixels in the supernet): with one torch thread per core of a 128-core host the CPU kernels spend their time in
+    fork/join (0.8 fps on 128 threads, 4.4 fps on 8).  So the thread count is SWEPT - one pass per candidate after a
+    warm-up - and the rest of the budget is spent at the fastest one; `cores` states it, `sample` lists the sweep."""
     all_threads = torch.get_num_threads()
-    if threads:
-        torch.set_num_threads(min(threads, all_threads))
-    cores = torch.get_num_threads()
+    cands = []
+    for t in (threads or CPU_THREAD_SWEEP):
+        if min(t, all_threads) not in cands:
+            cands.append(min(t, all_threads))
+    sweep = {}
     try:
-        return _time_cpu_inner(fn, images, budget_s, what, cores)
+        torch.set_num_threads(cands[0])
+        t0 = time.perf_counter()
+        fn()                                               # warm-up (allocator, oneDNN primitive caches)
+        first = time.perf_counter() - t0
+        spent = first
+        for t in cands:
+            if sweep and spent + min(sweep.values()) > budget_s:       # out of budget: the candidates not reached are left out
+                break
+            torch.set_num_threads(t)
+            t0 = time.perf_counter()
+            fn()
+            sweep[t] = time.perf_counter() - t0
+            spent += sweep[t]
+        best = min(sweep, key=sweep.get)
+        torch.set_num_threads(best)
+        n, el = 1, sweep[best]
+        if spent + el < budget_s:
+            n, t0 = 0, time.perf_counter()
+            while True:
+                fn()
+                n += 1
+                el = time.perf_counter() - t0
+                if spent + el >= budget_s or n >= 20:
+                    break
     finally:
         torch.set_num_threads(all_threads)
-
-
-def _time_cpu_inner(fn, images, budget_s, what, cores):
-    t0 = time.perf_counter()
-    fn()                                                   # warm-up (also the only run if it already exceeds the budget)
-    first = time.perf_counter() - t0
-    n, el = 1, first
-    if first < budget_s:
-        n, t0 = 0, time.perf_counter()
-        while True:
-            fn()
-            n += 1
-            el = time.perf_counter() - t0
-            if el >= budget_s or n >= 20:
-                break
-    return {"value": round(images * n / el, 4), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "%s; %d timed pass(es) after one warm-up (%.1f s), %.1f s" % (what, n, first, el)}
+    return {"value": round(images * n / el, 4), "unit": unit, "cores": best, "kind": "port",
+            "sample": "%s; threads swept %s s/pass (host has %d), %d timed pass(es) at %d threads, %.1f s" %
+                      (what, {t: round(v, 2) for t, v in sweep.items()}, all_threads, n, best, el)}
 
 
 def run_supernet(args, world, rank, backend, pretrain):
@@ -554,11 +584,30 @@ def run_supernet(args, world, rank, backend, pretrain):
                        {"final_loss": float(out[0]), "arch_loss": None if out[1] is None else float(out[1]), "parity": parity,
                         "eager_passes_per_phase": sum(1 for s_ in stepper._specs() if not stepper._is_static(s_)),
                         "execution": stepper.describe()})
+    # ---- after the timed region (a capture-path fault that appears "from the 5th replay on" would pass a step-0 gate):
+    # the state the replayed steps left behind must be finite, and the NEXT step issued eagerly (no graph replay, same kernels) must land
+    # next to the last replayed one - consecutive steps on one batch differ by the width draws and one small SGD step, not by 25 %
+    graphed_loss = float(out[0])
+    eager_next = [None]
+
+    def eager_step():
+        eager_next[0] = stepper.step(imgs, target, imgs_s, target_s, force_eager=True)
     if not args.no_roofline:
-        timed = _timed_census(args, world, rank, lambda: stepper.step(imgs, target, imgs_s, target_s, force_eager=True),
-                              workload="c3" if pretrain else "c5")
+        timed = _timed_census(args, world, rank, eager_step, workload="c3" if pretrain else "c5")
         if timed:
             line.update(timed)
+    else:
+        eager_step()
+    eager_loss = float(eager_next[0][0])
+    flat = stepper.sync.flat
+    check = {"last_replayed_loss": graphed_loss, "next_eager_loss": eager_loss,
+             "rel_change": abs(eager_loss - graphed_loss) / max(abs(graphed_loss), 1e-12), "steps_before": steps + args.train_warmup + 1,
+             "grads_finite": bool(torch.isfinite(flat).all()), "weights_finite": all(bool(torch.isfinite(p).all()) for p in stepper.weights),
+             "bar": "finite state after the timed region; |eager next loss - last replayed loss| <= 25 %"}
+    check["pass"] = bool(check["grads_finite"] and check["weights_finite"] and math.isfinite(eager_loss) and check["rel_change"] <= 0.25)
+    line["post_timed_check"] = check
+    if not check["pass"]:
+        raise SystemExit("bench.py: the supernet step's state after the timed region is not sane: %s" % json.dumps(check))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         for k, v in params.items():
             if v.is_floating_point() and not k.endswith(("running_mean", "running_var")):
@@ -573,7 +622,7 @@ def run_supernet(args, world, rank, backend, pretrain):
                                          "1 image of 3x%dx%d: %s through oracle/ref_supernet (port of search/model_search.py on torch-CPU "
                                          "kernels, fixture-pinned)" % (H, W, "`_loss(pretrain)` forward+backward" if pretrain else
                                                                        "`_loss` forward+backward of the arch step and of the weight step"),
-                                         threads=16)
+                                         threads=(16, 32, 8))
     del stepper
     line.update(_fp32_leg(args, world, make, lambda st: (lambda: st.step(imgs, target, imgs_s, target_s)), batch))
     return line
@@ -610,6 +659,8 @@ def compact_workload(w):
     out = _pick(w, ("value", "unit", "ms_per_step", "steps", "dtype", "ms_per_step_fp32", "value_fp32", "fp32_steps", "per_gpu_batch"))
     par = w.get("parity") or {}
     out["parity"] = _pick(par, ("pass", "rel_err", "max_abs_err", "rel_to_max_logit", "argmax_agreement"))
+    if w.get("post_timed_check"):
+        out["parity"]["after_timed"] = bool(w["post_timed_check"].get("pass"))
     if w.get("roofline"):
         out["roofline"] = _pick(w["roofline"], _ROOF_KEYS)
     if w.get("cpu_baseline"):
@@ -637,6 +688,8 @@ def build_line(c2, train, world, steps_requested, dtype, detail_path):
         line["frame_roofline"] = _pick(c2["frame_roofline"], ("ideal_ms", "frac"))
     if c2.get("cpu_baseline"):
         line["cpu_baseline"] = dict(_pick(c2["cpu_baseline"], _CPU_KEYS), sample=_short(c2["cpu_baseline"].get("sample", ""), 110))
+    if c2.get("fp32"):               # the same engine in the reference's arithmetic: north_star's ">= 163 fps, logits within 1e-3" in one record
+        line["fp32"] = _pick(c2["fp32"], ("value", "unit", "ms_per_step", "max_abs_err", "vs_baseline"))
     if c2.get("class_map"):
         line["class_map"] = _pick(c2["class_map"], ("value", "unit", "ms_per_step"))
     workloads = {"C2_student_infer": _pick(c2, ("value", "unit", "ms_per_step", "steps", "dtype"))}    # its objects are the top-level ones
@@ -647,12 +700,38 @@ def build_line(c2, train, world, steps_requested, dtype, detail_path):
     line = _sig(line)
     detail = {"C2_student_infer": c2}
     detail.update(train)
-    # never let the line outgrow what the driver parses: drop optional objects, widest first
-    for k in ("class_map", "frame_roofline", "alg_mb_per_frame", "alg_gflop_per_frame"):
-        if len(json.dumps(line)) < LINE_LIMIT:
-            break
+    return fit_line(line), detail
+
+
+def fit_line(line, limit=LINE_LIMIT):
+    """Never let the printed line outgrow what the driver parses (round 3 lost its whole result to a 24 KB line), and never lose the
+    result to the limit either: optional objects are dropped widest first, then the per-workload objects are thinned, then
+    strings are cut, and as a last resort only the contract's scalars remain with a pointer to the detail file."""
+    size = lambda: len(json.dumps(line))
+    for k in ("class_map", "frame_roofline", "alg_mb_per_frame", "alg_gflop_per_frame", "steps_requested"):
+        if size() < limit:
+            return line
         line.pop(k, None)
-    return line, detail
+    for drop in (("cpu_baseline",), ("parity",), ("roofline",), ("fp32_steps", "per_gpu_batch", "steps", "dtype", "unit")):
+        for w in (line.get("workloads") or {}).values():
+            if size() < limit:
+                return line
+            for k in drop:
+                w.pop(k, None)
+    if size() >= limit and isinstance(line.get("cpu_baseline"), dict):
+        line["cpu_baseline"].pop("sample", None)
+    if size() >= limit:
+        for k in ("workload", "parallelism"):
+            line["config"][k] = _short(line["config"].get(k, ""), 60)
+    if size() >= limit:
+        line.pop("workloads", None)
+    if size() >= limit:
+        keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "detail")
+        for k in [k for k in line if k not in keep]:
+            line.pop(k)
+        line["metric"] = _short(line["metric"], 100)
+    return line
 
 
 def device_clocks():
@@ -707,8 +786,7 @@ def main():
                 json.dump(detail, f, indent=1, default=str)
         except OSError as e:
             line["detail"] = "not written: %r" % (e,)
-        text = json.dumps(line)
-        assert len(text) < LINE_LIMIT, "bench line grew to %d bytes" % len(text)
+        text = json.dumps(fit_line(line))
         sys.stdout.flush()
         print(text, flush=True)
     if world > 1:

@@ -10,6 +10,7 @@
 // Launches issued while a stream is capturing cannot carry events and are left untimed (the census step runs eagerly).
 #include <string.h>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -30,7 +31,9 @@ struct Pending {
     int kernel;                  // index into g_names
     int tag;                     // caller's tag at launch time (fs_census_tag), -1: none
     fs_census_entry* entry;      // geometry entry the launch belongs to (or null)
-    int group;                   // grouped launch: index into g_groups (its time is shared out over several entries), -1: none
+    // grouped launch: its time is shared out over several entries.  Held by value (shared with the scope that made it), never as an index
+    // into a container a harvest can clear: a live CensusGroupScope outlives the harvests census_events / fs_census_read trigger
+    std::shared_ptr<const std::vector<std::pair<fs_census_entry*, double>>> group;
 };
 
 std::recursive_mutex g_mutex;                        // autograd runs backward on its own thread
@@ -41,8 +44,7 @@ std::vector<KernelAcc> g_kernels;
 std::vector<Pending> g_pending;
 std::vector<std::pair<hipEvent_t, hipEvent_t>> g_free;
 thread_local fs_census_entry* t_scope = nullptr;
-thread_local int t_group = -1;
-std::vector<std::vector<std::pair<fs_census_entry*, double>>> g_groups;     // (entry, share of the launch's duration)
+thread_local std::shared_ptr<const std::vector<std::pair<fs_census_entry*, double>>> t_group;     // (entry, share of the launch's duration)
 std::map<int, KernelAcc> g_tags;
 int g_tag = -1;
 constexpr size_t MAX_PENDING = 8192;                 // harvest (one stream sync) when this many launches are outstanding
@@ -62,8 +64,8 @@ void harvest() {
         if (hipEventSynchronize(p.e1) == hipSuccess && hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
             g_kernels[p.kernel].ms += ms;
             if (p.entry) p.entry->ms += ms;
-            if (p.group >= 0)
-                for (auto& es : g_groups[p.group]) es.first->ms += ms * es.second;
+            if (p.group)
+                for (auto& es : *p.group) es.first->ms += ms * es.second;
             if (p.tag >= 0) {
                 KernelAcc& t = g_tags[p.tag];
                 t.count += 1;
@@ -75,7 +77,6 @@ void harvest() {
         g_free.emplace_back(p.e0, p.e1);
     }
     g_pending.clear();
-    g_groups.clear();
 }
 
 }  // namespace
@@ -84,7 +85,7 @@ void harvest() {
 CensusGroupScope::CensusGroupScope(int family, const fs_conv_desc* const* d, const double* share, int n) : live(false) {
     if (!g_census_on) return;
     std::lock_guard<std::recursive_mutex> lock(g_mutex);
-    std::vector<std::pair<fs_census_entry*, double>> grp;
+    auto grp = std::make_shared<std::vector<std::pair<fs_census_entry*, double>>>();
     for (int i = 0; i < n; ++i) {
         fs_census_entry e;
         memset(&e, 0, sizeof(e));
@@ -94,15 +95,14 @@ CensusGroupScope::CensusGroupScope(int family, const fs_conv_desc* const* d, con
         auto it = g_census.find(key);
         if (it == g_census.end()) it = g_census.emplace(key, e).first;
         it->second.count += 1;
-        grp.emplace_back(&it->second, share[i]);
+        grp->emplace_back(&it->second, share[i]);
     }
-    g_groups.push_back(grp);
-    t_group = (int)g_groups.size() - 1;
+    t_group = grp;
     live = true;
 }
 
 CensusGroupScope::~CensusGroupScope() {
-    if (live) t_group = -1;
+    if (live) t_group.reset();
 }
 
 CensusScope::CensusScope(int family, const fs_conv_desc* d) : live(false) {

@@ -449,7 +449,7 @@ struct Cfg2 {
     int bm, bn;
 };
 static const Cfg2 CFG2[] = {{64, 64}, {128, 64}, {64, 128}, {128, 128}, {32, 32}, {64, 32}, {32, 64}, {32, 32}, {64, 64}};
-constexpr int NCFG2 = (int)(sizeof(CFG2) / sizeof(CFG2[0]));
+[[maybe_unused]] constexpr int NCFG2 = (int)(sizeof(CFG2) / sizeof(CFG2[0]));
 
 template <typename T> static void launch2(hipStream_t st, const ConvArgs& a, int cfg, int grid) {
     switch (cfg) {
@@ -458,6 +458,9 @@ template <typename T> static void launch2(hipStream_t st, const ConvArgs& a, int
         case 2: FS_LAUNCH((conv_igemm2_kernel<T, 2, 2, 1, 1, 2, 4>), dim3((unsigned)grid), dim3(256), 0, st, a); break;    // 64 x 128
         case 3: FS_LAUNCH((conv_igemm2_kernel<T, 2, 2, 1, 2, 2, 3>), dim3((unsigned)grid), dim3(256), 0, st, a); break;    // 128 x 128
         case 4: FS_LAUNCH((conv_igemm2_kernel<T, 1, 1, 4, 1, 1, 4>), dim3((unsigned)grid), dim3(256), 0, st, a); break;    // 32 x 32, K over 4 waves
+        case 5: FS_LAUNCH((conv_igemm2_kernel<T, 2, 1, 2, 1, 1, 4>), dim3((unsigned)grid), dim3(256), 0, st, a); break;    // 64 x 32, K over 2 waves
+        case 6: FS_LAUNCH((conv_igemm2_kernel<T, 1, 2, 2, 1, 1, 4>), dim3((unsigned)grid), dim3(256), 0, st, a); break;    // 32 x 64, K over 2 waves
+#ifdef FS_BUILD_PROBES      // measurement-only instantiations (FS_BUILD_PROBES=1 python -m fasterseg_amd.build --force; tools/conv_sweep.py, tools/paced_check.py)
         case 20: FS_LAUNCH((conv_igemm2_kernel<T, 2, 2, 1, 1, 1, 4, 1>), dim3((unsigned)grid), dim3(256), 0, st, a); break;   // ablations of 64 x 64
         case 21: FS_LAUNCH((conv_igemm2_kernel<T, 2, 2, 1, 1, 1, 4, 2>), dim3((unsigned)grid), dim3(256), 0, st, a); break;
         case 22: FS_LAUNCH((conv_igemm2_kernel<T, 2, 2, 1, 1, 1, 4, 3>), dim3((unsigned)grid), dim3(256), 0, st, a); break;
@@ -468,10 +471,10 @@ template <typename T> static void launch2(hipStream_t st, const ConvArgs& a, int
         case 31: FS_LAUNCH((conv_igemm2_kernel<T, 1, 1, 4, 1, 1, 4, 4>), dim3((unsigned)grid), dim3(256), 0, st, a); break;   // ... 32 x 32 K4
         case 32: FS_LAUNCH((conv_igemm2_kernel<T, 2, 1, 2, 1, 1, 4, 4>), dim3((unsigned)grid), dim3(256), 0, st, a); break;   // ... 64 x 32 K2
         case 33: FS_LAUNCH((conv_igemm2_kernel<T, 2, 2, 1, 2, 2, 3, 4>), dim3((unsigned)grid), dim3(256), 0, st, a); break;   // ... 128 x 128
-        case 5: FS_LAUNCH((conv_igemm2_kernel<T, 2, 1, 2, 1, 1, 4>), dim3((unsigned)grid), dim3(256), 0, st, a); break;    // 64 x 32, K over 2 waves
-        case 6: FS_LAUNCH((conv_igemm2_kernel<T, 1, 2, 2, 1, 1, 4>), dim3((unsigned)grid), dim3(256), 0, st, a); break;    // 32 x 64, K over 2 waves
         case 7: FS_LAUNCH((conv_igemm2_kernel<T, 1, 1, 4, 1, 1, 8>), dim3((unsigned)grid), dim3(256), 0, st, a); break;    // 32 x 32, K over 4 waves, 8 stages
-        default: FS_LAUNCH((conv_igemm2_kernel<T, 2, 2, 1, 1, 1, 6>), dim3((unsigned)grid), dim3(256), 0, st, a); break;   // 64 x 64, 6 stages
+        case 8: FS_LAUNCH((conv_igemm2_kernel<T, 2, 2, 1, 1, 1, 6>), dim3((unsigned)grid), dim3(256), 0, st, a); break;    // 64 x 64, 6 stages
+#endif
+        default: break;                                    // (igemm2_launch only passes configurations this build has)
     }
 }
 
@@ -492,6 +495,11 @@ static bool igemm2_qualifies(const ConvArgs& a, int es) {
     if (a.vr_H > 0 || (a.flags & CONV_BIG_OPERANDS) || a.k_jump < 0 || a.n_jump < 0) return false;
     if ((a.Cin * es) % 16 != 0 || a.R * a.S > 9) return false;
     if ((long long)a.Cin * es * a.R * a.S / 16 >= 65536) return false;
+    // filter offsets are 32-bit (b_off + tap + channel + k_jump) and anything from 0x80000000 up reads as zeros without a fault: the whole
+    // bank this launch can address - every row up to Cout + n_jump, the last tap, a far second contraction segment - must stay below 2 GiB
+    // (CONV_BIG_OPERANDS only checks one filter row)
+    const long long w_span = ((long long)a.Cout + a.n_jump) * a.w_os * es + (long long)a.R * a.S * (a.Cin + a.w_tgap) * es + (long long)a.k_jump * es;
+    if (w_span >= 0x7fffffffLL) return false;
     return true;
 }
 
@@ -579,6 +587,10 @@ bool igemm2_launch(hipStream_t st, ConvArgs& a, int dtype, int force_cfg, float*
     if (slices_out) *slices_out = 1;
     if (force_cfg == -2 || (force_cfg >= 0 && force_cfg < 100)) return false;
     const int force_slices = force_cfg >= 1000 ? force_cfg / 1000 : 0;
+    if (force_cfg < 0 && g_igemm2_mode >= 100) {            // FS_IGEMM2=<100 + c | 1000 * s + 100 + c>: the same codes from the environment
+        force_cfg = g_igemm2_mode;
+        return igemm2_launch(st, a, dtype, force_cfg, ws, ws_bytes, defer_reduce, slices_out);
+    }
     if (force_cfg >= 1000) force_cfg %= 1000;
     if (force_cfg < 0 && g_igemm2_mode == 0) return false;
     const int es = elem_size(dtype);
@@ -596,7 +608,11 @@ bool igemm2_launch(hipStream_t st, ConvArgs& a, int dtype, int force_cfg, float*
     int cfg, slices = 1;
     if (force_cfg >= 100) {
         cfg = force_cfg - 100;
+#ifdef FS_BUILD_PROBES
         if (cfg >= NCFG2 && !(cfg >= 20 && cfg <= 25) && !(cfg >= 30 && cfg <= 33)) return false;
+#else
+        if (cfg >= 7) return false;                        // 7, 8, 20-25, 30-33: measurement instantiations, not in this build
+#endif
         if (can_split) {
             if (force_slices > 0) slices = force_slices;
             else if (g_igemm2_slices > 0) slices = g_igemm2_slices;

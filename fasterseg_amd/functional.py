@@ -720,6 +720,15 @@ def batch_pair(a, b):
     return _BatchPair.apply(a, b)
 
 
+def zero_arena(nbytes, device):
+    """`nbytes` of zero-initialised fp32 scratch for one direction of a launch program (BN statistics / reduction accumulators, the
+    coefficient gradients): a 256-byte aligned slice of the step's zero arena (ONE fill per step; inside a capture one captured fill per
+    replay), or a fresh torch.zeros when no step is active.  None for 0 bytes."""
+    if not nbytes:
+        return None
+    return K.zero_pool.take(nbytes // 4, device, align=64)
+
+
 class _MixedOpProgram(torch.autograd.Function):
     """A whole supernet MixedOp (five primitives + weighted sum) replayed from its pre-built launch programs
     (fasterseg_amd.program): one FFI crossing and three arena allocations per direction instead of ~12 autograd nodes."""
@@ -734,9 +743,10 @@ class _MixedOpProgram(torch.autograd.Function):
         tmp = torch.empty(prog.tmpf_bytes, dtype=torch.uint8, device=dev)
         N, C, H, W = prog.out_shape
         out = torch.empty_strided((N, C, H, W), (H * W * C, 1, W * C, C), dtype=x.dtype, device=dev)
+        zf = zero_arena(prog.zf_bytes, dev)
         prog.run(prog.f_words, prog.f_n, prog.f_blob,
                  (None, x.data_ptr(), c.data_ptr(), out.data_ptr(), save.data_ptr(), None, None, None, tmp.data_ptr(),
-                  K.stream_workspace(dev)[0]))
+                  K.stream_workspace(dev)[0], zf.data_ptr() if zf is not None else None, None))
         ctx.prog = prog
         ctx.save_for_backward(x, c, save)
         return out
@@ -753,16 +763,18 @@ class _MixedOpProgram(torch.autograd.Function):
         if prog.need_x:
             n, ci, h, w = x.shape
             gx = torch.empty_strided((n, ci, h, w), (h * w * ci, 1, w * ci, ci), dtype=x.dtype, device=x.device)
+        zb = zero_arena(prog.zb_bytes, x.device)
         prog.run(prog.b_words, prog.b_n, prog.b_blob,
                  (None, x.data_ptr(), c.data_ptr(), None, save.data_ptr(), dy.data_ptr(), tmp.data_ptr(),
-                  gx.data_ptr() if gx is not None else None, None, K.stream_workspace(x.device)[0]))
+                  gx.data_ptr() if gx is not None else None, None, K.stream_workspace(x.device)[0], None,
+                  zb.data_ptr() if zb is not None else None))
         if prog.touched:
             sink = _grad_sink
             for p in prog.touched:
                 sink.touched(p)
         gc = None
         if prog.need_coef:
-            gc = tmp[prog.gcoef_off:prog.gcoef_off + 4 * c.numel()].view(torch.float32).reshape(c.shape)
+            gc = zb[prog.gcoef_off // 4:prog.gcoef_off // 4 + c.numel()].reshape(c.shape)
         return gx, gc, None
 
 
@@ -791,11 +803,12 @@ class _MixedOpProgramGroup(torch.autograd.Function):
             tmp = torch.empty(prog.tmpf_bytes, dtype=torch.uint8, device=dev)
             N, C, H, W = prog.out_shape
             out = torch.empty_strided((N, C, H, W), (H * W * C, 1, W * C, C), dtype=x.dtype, device=dev)
+            zf = zero_arena(prog.zf_bytes, dev)
             slots.append((None, x.data_ptr(), c.data_ptr(), out.data_ptr(), save.data_ptr(), None, None, None, tmp.data_ptr(),
-                          K.stream_workspace(dev)[0]))
+                          K.stream_workspace(dev)[0], zf.data_ptr() if zf is not None else None, None))
             outs.append(out)
             saved += [x, c, save]
-            scratch.append(tmp)                   # forward scratch: alive until the launches are enqueued (stream-ordered reuse after)
+            scratch.append((tmp, zf))             # forward scratch: alive until the launches are enqueued (stream-ordered reuse after)
         program.run_group(progs, False, slots)
         del scratch
         ctx.progs = progs
@@ -820,9 +833,11 @@ class _MixedOpProgramGroup(torch.autograd.Function):
             if prog.need_x:
                 n, ci, h, w = x.shape
                 gx = torch.empty_strided((n, ci, h, w), (h * w * ci, 1, w * ci, ci), dtype=x.dtype, device=x.device)
+            zb = zero_arena(prog.zb_bytes, x.device)
             slots.append((None, x.data_ptr(), c.data_ptr(), None, save.data_ptr(), dy.data_ptr(), tmp.data_ptr(),
-                          gx.data_ptr() if gx is not None else None, None, K.stream_workspace(x.device)[0]))
-            tmps.append((tmp, dy))
+                          gx.data_ptr() if gx is not None else None, None, K.stream_workspace(x.device)[0], None,
+                          zb.data_ptr() if zb is not None else None))
+            tmps.append((tmp, dy, zb))
             gxs.append(gx)
         program.run_group(progs, True, slots)
         grads = [None]
@@ -833,7 +848,7 @@ class _MixedOpProgramGroup(torch.autograd.Function):
             gc = None
             if prog.need_coef:
                 c = saved[3 * i + 1]
-                gc = tmps[i][0][prog.gcoef_off:prog.gcoef_off + 4 * c.numel()].view(torch.float32).reshape(c.shape)
+                gc = tmps[i][2][prog.gcoef_off // 4:prog.gcoef_off // 4 + c.numel()].reshape(c.shape)
             grads += [gxs[i], gc]
         return tuple(grads)
 

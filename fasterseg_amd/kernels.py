@@ -75,17 +75,22 @@ class _ZeroPool:
     def stop(self):
         self.active = False
 
-    def take(self, n, device):
-        if self.cap_buf is not None and self.cap_off + n <= self.cap_buf.numel() and torch.cuda.is_current_stream_capturing():
-            v = self.cap_buf[self.cap_off:self.cap_off + n]
-            self.cap_off += (n + 3) & ~3
-            return v
-        if (not self.active or self.buf is None or self.off + n > self.capacity or self.buf.device != torch.device(device)
+    def take(self, n, device, align=4):
+        """n zeroed floats; `align` (floats, power of two): alignment of the view's first element inside the arena (the arena itself is
+        allocator-aligned: 512 bytes)."""
+        if self.cap_buf is not None and torch.cuda.is_current_stream_capturing():
+            off = (self.cap_off + align - 1) & ~(align - 1)
+            if off + n <= self.cap_buf.numel():
+                self.cap_off = off + ((n + 3) & ~3)
+                return self.cap_buf[off:off + n]
+        if (not self.active or self.buf is None or self.buf.device != torch.device(device)
                 or torch.cuda.is_current_stream_capturing()):      # a captured graph must own (and re-zero) its scratch
             return torch.zeros(n, dtype=torch.float32, device=device)
-        v = self.buf[self.off:self.off + n]
-        self.off += (n + 3) & ~3            # keep 16-byte alignment
-        return v
+        off = (self.off + align - 1) & ~(align - 1)
+        if off + n > self.capacity:
+            return torch.zeros(n, dtype=torch.float32, device=device)
+        self.off = off + ((n + 3) & ~3)         # keep 16-byte alignment
+        return self.buf[off:off + n]
 
 
 zero_pool = _ZeroPool()

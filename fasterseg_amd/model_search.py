@@ -59,6 +59,27 @@ def gumbel_softmax(logits, temperature=1, hard=False):
     return out
 
 
+class _SampledRatios(list):
+    """sample_prun_ratio("arch_ratio") result: the reference's nested [scale][layer] list of straight-through one-hots, plus the batched
+    tensors they are rows of (`stacked` [slots, widths], `index` [slots] = device-side arg-max) for the consumers that want all slots."""
+    stacked = None
+    index = None
+
+
+def gumbel_softmax_rows(logits, temperature=1):
+    """gumbel_softmax(hard=True) of every ROW of `logits` [slots, widths] in one batch of ~14 launches instead of ~14 per slot (44 slots
+    per call, three calls per architecture step: ~1.8 k of a C5 iteration's ATen launches).  The host RNG is consumed exactly like the
+    reference's slot-by-slot `torch.rand(widths)` calls (one serial uniform stream: torch.rand(n, w) == n x torch.rand(w), checked in
+    tests/test_supernet.py), so seeded runs draw the same sub-networks.  Returns (straight-through one-hots [slots, widths], arg-max)."""
+    y = logits + sample_gumbel(logits.size(), device=logits.device)
+    if temperature != 1:                      # (x / 1 is the identity: no launch for the reference's default)
+        y = y / temperature
+    y = F.softmax(y, dim=-1)
+    _, ind = y.max(dim=-1)
+    y_hard = torch.zeros_like(y).scatter_(1, ind.view(-1, 1), 1)
+    return (y_hard - y).detach() + y, ind
+
+
 def _width_and_score(ratio, width_mult_list):
     """int: force #channel; tensor: arch_ratio; float(<=1): force width (reference comment, model_search.py:61)."""
     if isinstance(ratio, torch.Tensor):
@@ -142,7 +163,12 @@ _GROUP_PROGRAMS = bool(int(os.environ.get("FS_GROUP_PROGRAMS", "1")))
 # k > 1 lockstep node is captured, and with the launch programs on the capture's origin stream instead (grouped OR one by one - the
 # round-3 _MixedOpProgram node shows it too) the fifth replay of the graph produces inf / NaN gradients (tools/debug_group_nan.py).
 # The captured fixed-width passes therefore keep one program per lane; the eager (sampled-width) passes are grouped.
-_GROUP_CAPTURE = int(os.environ.get("FS_GROUP_CAPTURE", "0"))       # 1: on the origin stream, 2: every bucket on ONE side lane
+_GROUP_CAPTURE = int(os.environ.get("FS_GROUP_CAPTURE", "0"))       # 2: every bucket on ONE side lane; 1 (origin stream) is refused below
+if _GROUP_CAPTURE == 1 and not int(os.environ.get("FS_ALLOW_BROKEN_CAPTURE", "0")):
+    # a mode that is known to produce inf / NaN gradients from the fifth replay on is not offered as a switch.  The
+    # reproduction (tools/debug_group_nan.py) sets FS_ALLOW_BROKEN_CAPTURE=1 to get at it.
+    raise RuntimeError("FS_GROUP_CAPTURE=1 (launch programs on the capture's origin stream) gives inf / NaN gradients after a few replays on "
+                       "ROCm 7.2 and is disabled; use FS_GROUP_CAPTURE=2 (all buckets on one side lane) or leave it at 0")
 
 
 # SupernetStep.step(force_eager=True) - bench.py's census step - sets this: the fixed-width passes, which the timed steps replay from
@@ -561,14 +587,30 @@ class Network_Multi_Path(nn.Module):
         counts = (self._layers - 1, self._layers - 1, self._layers - 2)
         if mode == "arch_ratio":
             names = self._arch_names[self.arch_idx]["ratios"]
-            ratios = [[gumbel_softmax(F.log_softmax(getattr(self, names[s])[layer], dim=-1), hard=True) for layer in range(counts[s])]
-                      for s in range(3)]
+            params = [getattr(self, names[s]) for s in range(3)]
+            assert all(p.shape[0] == counts[s] for s, p in enumerate(params))
+            # all slots (scale-major, layer-minor: the reference's draw order) in ONE batch; per-slot views for the per-cell consumers
+            out, ind = gumbel_softmax_rows(F.log_softmax(torch.cat(params), dim=-1))
+            rows = out.unbind(0)
             # The reference reads `ratio.argmax()` on the host once per MixedOp (model_search.py:64-65): ~230 device syncs per
             # forward, each draining the launch queue.  Read all sampled indices back in ONE transfer instead.
-            flat = [r for scale in ratios for r in scale]
-            if read_indices and flat and flat[0].is_cuda and not torch.cuda.is_current_stream_capturing():
-                for r, k in zip(flat, torch.cat([r._fs_index_t for r in flat]).tolist()):
-                    r._fs_index = k
+            host = None
+            if read_indices and out.is_cuda and not torch.cuda.is_current_stream_capturing():
+                host = ind.tolist()
+            elif read_indices and not out.is_cuda:
+                host = ind.tolist()
+            ratios, n = _SampledRatios(), 0
+            for s in range(3):
+                scale = []
+                for _ in range(counts[s]):
+                    r = rows[n]
+                    r._fs_index_t = ind[n:n + 1]      # device-side arg-max (a view: no launch)
+                    if host is not None:
+                        r._fs_index = host[n]
+                    scale.append(r)
+                    n += 1
+                ratios.append(scale)
+            ratios.stacked, ratios.index = out, ind
             return ratios
         if mode == "random":      # same draw order as the reference: all of scale 0, then scale 1, then scale 2
             return [[np.random.choice(self._width_mult_list) for _ in range(counts[s])] for s in range(3)]
@@ -629,9 +671,12 @@ class Network_Multi_Path(nn.Module):
                                                s_out=torch.tensor(s_out, device=dev))
         A = torch.cat(list(alphas))[plan["rows"]]
         if mode == "arch_ratio":
-            flat = [r for scale in ratios for r in scale]
-            idx = torch.cat([r._fs_index_t for r in flat])
-            score = torch.stack(flat).gather(1, idx[:, None]).squeeze(1)
+            if getattr(ratios, "stacked", None) is not None:
+                R, idx = ratios.stacked, ratios.index
+            else:
+                flat = [r for scale in ratios for r in scale]
+                R, idx = torch.stack(flat), torch.cat([r._fs_index_t for r in flat])
+            score = R.gather(1, idx[:, None]).squeeze(1)
             score = torch.cat([score, score.new_ones(1)])
             A = A * score[plan["s_in"]][:, None] * score[plan["s_out"]][:, None]
         return {key: _PreCoef(row) for key, row in zip(plan["keys"], A.unbind(0))}
@@ -815,9 +860,12 @@ class Network_Multi_Path(nn.Module):
         scores = None
         if mode == "arch_ratio":
             ratios = self.sample_prun_ratio(mode=mode, read_indices=False)          # same RNG draws as the per-MixedOp path
-            flat = [r for scale in ratios for r in scale]
-            idx = torch.cat([r._fs_index_t for r in flat])                          # sampled width index per slot, on the device
-            R = torch.stack(flat)                                                   # straight-through one-hots [slots, widths]
+            if getattr(ratios, "stacked", None) is not None:
+                R, idx = ratios.stacked, ratios.index                               # straight-through one-hots [slots, widths], arg-max per slot
+            else:
+                flat = [r for scale in ratios for r in scale]
+                idx = torch.cat([r._fs_index_t for r in flat])                      # sampled width index per slot, on the device
+                R = torch.stack(flat)
             score = R.gather(1, idx[:, None]).squeeze(1)                            # = ratio[k] of `_width_and_score`
             idx_ext = torch.cat([idx, idx.new_zeros(1)])
             scores = torch.cat([score, score.new_ones(1)])

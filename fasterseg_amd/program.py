@@ -9,13 +9,17 @@ gradients are wanted) into two command lists, forward and backward, whose pointe
 
     slot 0  absolute   parameters, BN buffers, slices of the flat gradient buffer (never move)
     slot 1  X          the input feature map             slot 5  DY    incoming gradient (dense NHWC)
-    slot 2  COEF       the 5 mixing coefficients         slot 6  TMPB  backward scratch (zero region first)
+    slot 2  COEF       the 5 mixing coefficients         slot 6  TMPB  backward scratch
     slot 3  OUT        the mixed output                  slot 7  GX    gradient w.r.t. X
-    slot 4  SAVE       activations kept for backward     slot 8  TMPF  forward scratch (zero region first)
+    slot 4  SAVE       activations kept for backward     slot 8  TMPF  forward scratch
                                                          slot 9  WS    the stream's split-K conv workspace
+    slot 10 ZF         zero-initialised accumulators of the forward list (BN statistics)
+    slot 11 ZB         ... of the backward list (BN reductions, coefficient gradients)
 
 Per call the autograd Function (functional._MixedOpProgram) allocates three arenas and the output and crosses the FFI once
-per direction.  The per-module path in functional.py computes exactly the same thing and remains the reference
+per direction.  The zero-initialised accumulators come out of the step's zero arena (kernels.zero_pool: ONE fill per step, or one
+captured fill per graph replay) - round 4 cleared a zero region per program and direction, ~600 fill launches per C3 step and ~1200
+per C5 iteration.  The per-module path in functional.py computes exactly the same thing and remains the reference
 implementation of these programs (tests compare the two); it is also what runs under hipGraph capture and whenever a
 precondition below does not hold.
 """
@@ -27,8 +31,8 @@ import torch
 from . import kernels as K
 from ._lib import ConvDesc, ResizeDesc
 
-ABS, X, COEF, OUT, SAVE, DY, TMPB, GX, TMPF, WS = range(10)
-N_SLOTS = 10
+ABS, X, COEF, OUT, SAVE, DY, TMPB, GX, TMPF, WS, ZF, ZB = range(12)
+N_SLOTS = 12
 _ALIGN = 256
 
 (OP_MEMSET, OP_PACK_WEIGHT, OP_CONV_FWD, OP_UNIT_FWD, OP_UNIT_BWD, OP_WGRAD_STRIDED, OP_CHANNEL_STATS, OP_BN_FINALIZE,
@@ -38,15 +42,14 @@ _ALIGN = 256
 
 
 class Ref:
-    """A device address = slots[slot] + off.  Arena allocations carry their region ("z": zero-filled part at the start of
-    the arena, "p": the plain part behind it) until the list is finished and the size of the zero part is known."""
-    __slots__ = ("slot", "off", "region")
+    """A device address = slots[slot] + off."""
+    __slots__ = ("slot", "off")
 
-    def __init__(self, slot, off, region=None):
-        self.slot, self.off, self.region = slot, off, region
+    def __init__(self, slot, off):
+        self.slot, self.off = slot, off
 
     def __add__(self, nbytes):
-        return Ref(self.slot, self.off + nbytes, self.region)
+        return Ref(self.slot, self.off + nbytes)
 
 
 NULL = Ref(ABS, 0)
@@ -79,37 +82,30 @@ class _Desc:
 class _List:
     """One direction (forward or backward) of a program."""
 
-    def __init__(self):
+    def __init__(self, zero_slot):
         self.words = []
         self.blob = bytearray()
-        self.sizes = {}             # arena slot -> [zeroed bytes, plain bytes]
+        self.sizes = {}             # arena slot -> bytes
+        self.zero_slot = zero_slot  # where `zero=True` allocations live: an arena the caller hands over already cleared
 
     def alloc(self, slot, nbytes, zero=False):
-        z = self.sizes.setdefault(slot, [0, 0])
+        if zero:
+            slot = self.zero_slot
         nbytes = (nbytes + _ALIGN - 1) // _ALIGN * _ALIGN
-        k = 0 if zero else 1
-        off = z[k]
-        z[k] += nbytes
-        return Ref(slot, off, "z" if zero else "p")          # resolved in finish(): plain region follows the zero region
+        off = self.sizes.get(slot, 0)
+        self.sizes[slot] = off + nbytes
+        return Ref(slot, off)
 
     def emit(self, op, *args, lane=0):
         self.words.append((op | (lane << 16), args))
 
     def finish(self):
-        zero = {s: z[0] for s, z in self.sizes.items()}
-
-        def resolve(r):       # arenas of the other direction (SAVE seen from the backward list) have no zero region
-            return r.slot, r.off + (zero.get(r.slot, 0) if r.region == "p" else 0)
         out = []
-        for slot, z in sorted(self.sizes.items()):
-            if z[0]:
-                out += [OP_MEMSET, 2, 2, slot, 0, 0, 0, z[0]]
         for op, args in self.words:
             out += [op, len(args)]
             for a in args:
                 if isinstance(a, Ref):
-                    s, o = resolve(a)
-                    out += [2, s, o]
+                    out += [2, a.slot, a.off]
                 elif isinstance(a, _Desc):
                     off = len(self.blob)
                     self.blob += a.raw
@@ -124,27 +120,27 @@ class _List:
                             if r is None:
                                 out += [0, -1]
                             else:
-                                out += list(resolve(r))
+                                out += [r.slot, r.off]
                     else:
                         out += [5, len(a), 0] + [int(v) for v in a]
                 else:
                     out += [0, 0, int(a)]
         words = (ctypes.c_longlong * len(out))(*out)
         blob = (ctypes.c_ubyte * max(1, len(self.blob))).from_buffer_copy(bytes(self.blob) or b"\0")
-        total = {s: z[0] + z[1] for s, z in self.sizes.items()}
-        return words, len(out), blob, total
+        return words, len(out), blob, dict(self.sizes)
 
 
 class MixedOpProgram:
     """Forward + backward command lists of one MixedOp configuration."""
 
     def __init__(self, fwd, bwd, out_shape, touched, need_x, need_coef, gcoef_off, guard):
-        assert fwd.sizes.get(SAVE, [0, 0])[0] == 0, "SAVE is addressed from both lists: it must not have a zero region"
         self.f_words, self.f_n, self.f_blob, f_sizes = fwd.finish()
         self.b_words, self.b_n, self.b_blob, b_sizes = bwd.finish()
         self.save_bytes = max(_ALIGN, f_sizes.get(SAVE, 0))
         self.tmpf_bytes = max(_ALIGN, f_sizes.get(TMPF, 0))
         self.tmpb_bytes = max(_ALIGN, b_sizes.get(TMPB, 0))
+        self.zf_bytes = f_sizes.get(ZF, 0)    # zero-initialised accumulators: slices of the step's zero arena (functional.zero_arena)
+        self.zb_bytes = b_sizes.get(ZB, 0)
         self.out_shape = out_shape            # (N, C, H, W)
         self.touched = touched                # parameters whose flat-gradient slices the backward writes
         self.need_x, self.need_coef, self.gcoef_off = need_x, need_coef, gcoef_off
@@ -187,7 +183,7 @@ def run_group(progs, backward, slot_lists):
 # ---------------------------------------------------------------------------------------------------
 class _Lowering:
     def __init__(self, dtype, want_w, sink, groups=1):
-        self.f, self.b = _List(), _List()
+        self.f, self.b = _List(ZF), _List(ZB)
         self.groups = groups                  # BatchNorm groups: the batch is this many independently normalised inputs
         self.dtype = dtype
         self.dt = K.dtype_code(dtype)
@@ -515,7 +511,7 @@ def _lower_fused(lo, x, mixed, need_x):
     (conv, conv2x), (du, du2x) = pairs
     if conv.ZOOM or not du.ZOOM or conv.NUM_CONVS != 1 or conv2x.NUM_CONVS != 2 or du.NUM_CONVS != 1 or du2x.NUM_CONVS != 2:
         return None
-    mark_f, mark_b = (len(lo.f.words), dict((k, list(v)) for k, v in lo.f.sizes.items())), None
+    mark_f, mark_b = (len(lo.f.words), dict(lo.f.sizes)), None
     stride = conv.stride
     upsample = stride == 1
     y0, bw0 = lo.primitive(x, ops[0])
@@ -598,7 +594,7 @@ def lower_mixed_op(mixed, x_shape, x_cs, dtype, device, need_x, need_coef, want_
         b.emit(OP_WSUM, x.pixels, C, len(dxs), [d.ref for d in dxs], [d.cs for d in dxs], absolute(_ones(device)), Ref(GX, 0), C, lo.dt)
     gcoef_off = None
     if gcoef is not None:
-        gcoef_off = gcoef.off             # the zero region starts the arena
+        gcoef_off = gcoef.off             # byte offset inside the backward list's zero arena (slot ZB)
     touched, seen = [], set()
     for p in lo.touched:
         if id(p) not in seen:

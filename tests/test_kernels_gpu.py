@@ -77,7 +77,7 @@ def force_cfg(request):
 
 # -1: production heuristic (conv_igemm2.hip where it qualifies); -2: conv_igemm.hip's heuristic alone; 0..7: its configurations;
 # 100..106: conv_igemm2.hip's configurations; 1000 * s + 100 + c: with s K slices (fp32 slabs + reduce launch)
-@pytest.mark.parametrize("force_cfg", [-1, -2, 0, 1, 2, 3, 4, 5, 6, 7, 100, 101, 102, 103, 104, 105, 106, 107, 108, 3100, 2104], indirect=True,
+@pytest.mark.parametrize("force_cfg", [-1, -2, 0, 1, 2, 3, 4, 5, 6, 7, 100, 101, 102, 103, 104, 105, 106, 3100, 2104], indirect=True,
                          ids=lambda c: "cfg%d" % c)
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=[str(c) for c in CONV_CASES])
@@ -245,7 +245,7 @@ S2_DGRAD_CASES = [
 ]
 
 
-@pytest.mark.parametrize("force_cfg", [-1, -2, 100, 101, 102, 104, 105, 106, 107], indirect=True, ids=lambda c: "cfg%d" % c)
+@pytest.mark.parametrize("force_cfg", [-1, -2, 100, 101, 102, 104, 105, 106], indirect=True, ids=lambda c: "cfg%d" % c)
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("case", S2_DGRAD_CASES, ids=[str(c) for c in S2_DGRAD_CASES])
 def test_stride2_dgrad_by_parity_classes(case, dtype, force_cfg):

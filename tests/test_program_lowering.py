@@ -68,11 +68,15 @@ def test_mixed_op_lowering_structure(stride, want_w):
                                   want_w=want_w, sink=sync)
     cout = int(48 * stride * 10 / 12)
     assert prog.out_shape == (2, cout, 16 // stride, 24 // stride)
-    fwd = decode(prog.f_words, prog.f_n, {program.SAVE: prog.save_bytes, program.TMPF: prog.tmpf_bytes})
-    bwd = decode(prog.b_words, prog.b_n, {program.SAVE: prog.save_bytes, program.TMPB: prog.tmpb_bytes})
+    fwd = decode(prog.f_words, prog.f_n, {program.SAVE: prog.save_bytes, program.TMPF: prog.tmpf_bytes, program.ZF: prog.zf_bytes})
+    bwd = decode(prog.b_words, prog.b_n, {program.SAVE: prog.save_bytes, program.TMPB: prog.tmpb_bytes, program.ZB: prog.zb_bytes})
     f_ops, b_ops = [c[0] for c in fwd], [c[0] for c in bwd]
-    # forward: zero-fill first, one weighted sum last; 6 conv->BN units for stride 1 (skip 1x1, conv, downup, 2x conv_2x, 2x ...)
-    assert f_ops[0] == program.OP_MEMSET and f_ops[-1] == program.OP_WSUM
+    # forward: one weighted sum last; 6 conv->BN units for stride 1 (skip 1x1, conv, downup, 2x conv_2x, 2x ...).  No fill command: the
+    # zero-initialised accumulators (BN statistics / reductions, coefficient gradients) are slices of the step's zero arena (slots ZF / ZB)
+    assert program.OP_MEMSET not in f_ops and program.OP_MEMSET not in b_ops and f_ops[-1] == program.OP_WSUM
+    assert prog.zf_bytes > 0 and prog.zb_bytes > 0 and prog.zf_bytes % 256 == 0 and prog.zb_bytes % 256 == 0
+    if not want_w:
+        assert 0 <= prog.gcoef_off < prog.zb_bytes
     units = 7 if stride == 1 else 6            # stride 2: the skip is a FactorizedReduce (two plain convs + BN), no 1x1 unit
     assert f_ops.count(program.OP_UNIT_FWD) == units and b_ops.count(program.OP_UNIT_BWD) == units
     assert f_ops.count(program.OP_BILINEAR_FWD) == (4 if stride == 1 else 2)

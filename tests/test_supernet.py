@@ -4,6 +4,7 @@ GPU part: eval forward, pretrain and search losses + gradients through every pri
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from oracle.seeded import seeded_input, seeded_state
 from tests._util import assert_close_golden, golden_get, load_json, load_npz
@@ -152,6 +153,45 @@ def test_batched_coefficients_equal_per_mixedop_products(arch_idx, mode):
     assert set(g0) == set(g1)
     for n in g0:
         assert torch.allclose(g0[n], g1[n], rtol=1e-5, atol=1e-7), (n, float((g0[n] - g1[n]).abs().max()))
+
+
+def test_batched_gumbel_sampling_equals_the_slot_by_slot_reference_draws():
+    """sample_prun_ratio("arch_ratio") draws all 44 slots in one batch (round 5); the reference draws them one by one
+    (model_search.py:19-44,243-247: gumbel_softmax(F.log_softmax(ratio[layer]), hard=True) per slot).  Same host-RNG consumption (the next
+    draw after the call is the same), same one-hots, same soft scores, same gradients w.r.t. the ratio parameters."""
+    from fasterseg_amd import model_search
+    net = build()
+    net.arch_idx = 1
+    g = torch.Generator().manual_seed(5)
+    for p in net._arch_parameters[1]:
+        p.data.add_(torch.randn(p.shape, generator=g) * 0.7)
+    names = net._arch_names[1]["ratios"]
+    counts = (net._layers - 1, net._layers - 1, net._layers - 2)
+    torch.manual_seed(11)
+    got = net.sample_prun_ratio(mode="arch_ratio")
+    after_got = torch.rand(3)
+    assert got.stacked.shape == (sum(counts), len(net._width_mult_list)) and got.index.shape == (sum(counts),)
+    wsum = torch.Generator().manual_seed(2)
+    weights = [[torch.randn(len(net._width_mult_list), generator=wsum) for _ in range(counts[s])] for s in range(3)]
+    sum((r * w).sum() for rs, ws in zip(got, weights) for r, w in zip(rs, ws)).backward()
+    grads_got = [getattr(net, n).grad.clone() for n in names]
+    net.zero_grad()
+    torch.manual_seed(11)
+    want = [[model_search.gumbel_softmax(F.log_softmax(getattr(net, names[s])[layer], dim=-1), hard=True) for layer in range(counts[s])]
+            for s in range(3)]
+    after_want = torch.rand(3)
+    assert torch.equal(after_got, after_want)                    # the generator is left where the reference leaves it
+    sum((r * w).sum() for rs, ws in zip(want, weights) for r, w in zip(rs, ws)).backward()
+    n = 0
+    for s in range(3):
+        assert len(got[s]) == counts[s]
+        for layer in range(counts[s]):
+            a, b = got[s][layer], want[s][layer]
+            assert torch.allclose(a, b, rtol=0, atol=1e-7), (s, layer)
+            assert int(a.argmax()) == int(b.argmax()) == int(a._fs_index) == int(a._fs_index_t) == int(got.index[n])
+            n += 1
+    for a, n_ in zip(grads_got, names):
+        assert torch.allclose(a, getattr(net, n_).grad, rtol=1e-5, atol=1e-7), n_
 
 
 def _rel_l2(got, store, key):

@@ -1,0 +1,48 @@
+#!/bin/bash
+# One parameterised GPU job script (replaces the one-shot tools/gpu_job_r0*.sh of rounds 3-4).  Run through gpurun from the repo root:
+#   gpurun --timeout 900 -- 'bash tools/gpu_job.sh <job> [args]'
+# Everything a job writes goes to gpurun_out/ (merged back by gpurun); summaries worth keeping are copied to profiles/ by hand.
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out
+cd $R
+mkdir -p $O
+job=${1:-help}; shift
+case $job in
+  probe)      # grid-barrier probe + supernet step time against the number of hardware queues the runtime may use
+    timeout 300 tools/probes/grid_barrier.bin > $O/r05_grid_barrier.txt 2>&1; tail -5 $O/r05_grid_barrier.txt
+    for q in default 2 8; do
+      if [ $q = default ]; then unset GPU_MAX_HW_QUEUES; else export GPU_MAX_HW_QUEUES=$q; fi
+      timeout 300 python -W ignore tools/step_time.py c3 20 2>&1 | grep STEP_TIME | sed "s/^/hwq=$q /" | tee -a $O/r05_hwq_c3.txt
+    done
+    unset GPU_MAX_HW_QUEUES
+    ;;
+  call2)      # round 5, second call: barrier probe v2, ATen call sites of a C5 step, the tests that touch this round's host-side changes,
+              # C3 under fewer hardware queues, and the in-flight histogram of a C3 step
+    timeout 200 tools/probes/grid_barrier.bin > $O/r05_grid_barrier_v2.txt 2>&1; tail -3 $O/r05_grid_barrier_v2.txt
+    timeout 400 python -W ignore tools/aten_sites.py c5 $O/r05_c5_aten_sites.json > $O/r05_c5_aten_sites.txt 2>&1; head -45 $O/r05_c5_aten_sites.txt
+    timeout 600 python -W ignore -m pytest tests/test_program_group_gpu.py tests/test_supernet.py tests/test_train_steps_gpu.py tests/test_train_parity_gpu.py \
+        "tests/test_kernels_gpu.py::test_conv2d_fwd" -m gpu -q -x --timeout 300 --durations=5 2>&1 | tail -15 | cut -c1-220
+    for q in 2 1; do
+      GPU_MAX_HW_QUEUES=$q timeout 300 python -W ignore tools/step_time.py c3 20 2>&1 | grep -a "STEP_TIME\|Error\|error" | head -3 | sed "s/^/hwq=$q /" | tee -a $O/r05_hwq_c3.txt
+    done
+    bash tools/prof_step.sh c3 3 r05_c3_probe 2>&1 | head -12
+    python tools/trace_concurrency.py $(find /tmp/prof_step -name "*kernel_trace.csv" | head -1) $O/prof_step_r05_c3_probe.log 3 $O/r05_c3_concurrency.json
+    ;;
+  tests)      # bash tools/gpu_job.sh tests <pytest args...>
+    timeout ${FS_JOB_TIMEOUT:-600} python -W ignore -m pytest "$@" -m gpu -q -x --timeout 300 --durations=8 2>&1 | tail -25 | cut -c1-240
+    ;;
+  step)       # bash tools/gpu_job.sh step c3|c4|c5 [steps] [fp32]
+    timeout 400 python -W ignore tools/step_time.py "$@" 2>&1 | tail -3
+    ;;
+  bench)      # bash tools/gpu_job.sh bench <name> [bench.py args...]  -> gpurun_out/<name>.json + <name>_detail.json
+    name=$1; shift
+    timeout 900 python -W ignore bench.py --detail $O/${name}_detail.json "$@" > $O/$name.json 2> $O/$name.err; echo rc=$?; tail -c 1500 $O/$name.json; tail -3 $O/$name.err
+    ;;
+  prof)       # bash tools/gpu_job.sh prof c3|c4|c5 <steps> <name>: rocprofv3 kernel table of the timed steps only
+    bash tools/prof_step.sh "$@" 2>&1 | head -40
+    ;;
+  *)
+    echo "jobs: probe | tests <pytest args> | step <c3|c4|c5> [steps] [fp32] | bench <name> [args] | prof <wl> <steps> <name>"
+    ;;
+esac
