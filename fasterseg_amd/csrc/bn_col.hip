@@ -184,7 +184,6 @@ __global__ __launch_bounds__(BNC_THREADS) void bn_group_bwd_kernel(long long pix
     __shared__ float red[2 * BNC_MAX_WAVES * VEC];
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int c0 = blockIdx.x * VEC;
-    const int relu_arg = relu;
     relu = relu_at(relu, c0) ? 1 : 0;          // per channel vector (see common.h)
     const long long mg = pixels / groups;
     float tot_b[VEC], tot_g[VEC], ga[VEC];
@@ -313,6 +312,16 @@ __global__ __launch_bounds__(BNS_THREADS) void bn_small_fwd_kernel(long long pix
     relu = relu_at(relu, c0) ? 1 : 0;          // per channel vector (see common.h)
     const int mg = (int)(pixels / G);
     if (blockIdx.x == 0 && tid == 0) bump_batches_tracked(num_batches_tracked, relu_arg, G);
+    // the finalising lanes request their channel's affine parameters and running statistics NOW, together with the map: after the block
+    // reduction they would be one more dependent round trip to memory on the critical path of an ~8 us kernel (round 5)
+    float p_ga = 1.f, p_be = 0.f, p_rm = 0.f, p_rv = 0.f;
+    if (tid < VEC) {
+        const int c = c0 + tid;
+        if (gamma) p_ga = gamma[c];
+        if (beta) p_be = beta[c];
+        if (running_mean) p_rm = running_mean[c];
+        if (running_var) p_rv = running_var[c];
+    }
     u32x4 raw[G][BNS_UNROLL];
     if (splits > 1) {                     // sum the split-K slabs of the producing conv; keep z for the backward
 #pragma unroll
@@ -370,8 +379,8 @@ __global__ __launch_bounds__(BNS_THREADS) void bn_small_fwd_kernel(long long pix
     if (tid < VEC) {
         const int c = c0 + tid;
         const float count = (float)mg;
-        const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
-        float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 0.f;
+        const float ga = p_ga, be = p_be;
+        float rm = p_rm, rv = p_rv;
 #pragma unroll
         for (int g = 0; g < G; ++g) {     // running statistics take the groups' updates in order
             float sum1 = 0.f, sum2 = 0.f;
@@ -429,7 +438,6 @@ __global__ __launch_bounds__(BNS_THREADS) void bn_small_bwd_kernel(long long pix
     __shared__ float red[G * 2 * VEC * BNS_WAVES];
     const int tid = threadIdx.x;
     const int c0 = blockIdx.x * VEC;
-    const int relu_arg = relu;
     relu = relu_at(relu, c0) ? 1 : 0;          // per channel vector (see common.h)
     const int mg = (int)(pixels / G);
     u32x4 rz[G][BNS_UNROLL], rg[G][BNS_UNROLL], ro[G][BNS_UNROLL];
@@ -446,6 +454,11 @@ __global__ __launch_bounds__(BNS_THREADS) void bn_small_bwd_kernel(long long pix
     float ga[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) ga[i] = gamma[c0 + i];
+    float p_dg = 0.f, p_db = 0.f;         // running parameter gradients: requested with the map, added to at the very end (one writer)
+    if (tid < VEC && dgamma_acc) {
+        p_dg = dgamma_acc[c0 + tid];
+        p_db = dbeta_acc[c0 + tid];
+    }
     float acc[G * 2 * VEC];               // per group: sum g [VEC], sum g * xhat [VEC]
     float gr[G][BNS_UNROLL][VEC], xh[G][BNS_UNROLL][VEC];
     float is[G][VEC];
@@ -503,8 +516,8 @@ __global__ __launch_bounds__(BNS_THREADS) void bn_small_bwd_kernel(long long pix
         red_out[c] = b;
         red_out[C + c] = gsum;
         if (dgamma_acc) {
-            dgamma_acc[c] += gsum;
-            dbeta_acc[c] += b;
+            dgamma_acc[c] = p_dg + gsum;
+            dbeta_acc[c] = p_db + b;
         }
     }
 }

@@ -152,8 +152,11 @@ __global__ void ew_kernel(long long pixels, int cv, const T* __restrict__ x, int
 }
 
 // Train-mode BN normalise pass with the statistics finalisation folded in: every thread derives scale/shift of its channel
-// vector from the raw (sum, sumsq) - a few flops - so the separate bn_finalize launch disappears; block 0 also publishes
-// mean / invstd / scale / shift for the backward and updates running statistics and num_batches_tracked.
+// vector from the raw (sum, sumsq) - a few flops - so the separate bn_finalize launch disappears; ONE extra block (block 0, which
+// takes no share of the map) publishes mean / invstd / scale / shift for the backward and updates running statistics and
+// num_batches_tracked.  Round 5: that bookkeeping used to be done by block 0 BEFORE its share of the normalisation - five dependent
+// loads per channel in front of the same work every other block does, i.e. the kernel's critical path on the supernet's maps
+// (24-100 blocks, 8.1 us average where the plain pass takes ~5); as a block of its own it runs beside the pass.
 // `groups` > 1: consecutive ranges of pixels/groups pixels are normalised independently (stats / saved hold one block of 2C / 4C
 // floats per group), running statistics take the groups' updates one after the other (fs_conv_desc.bn_groups).
 template <typename T>
@@ -167,28 +170,30 @@ __global__ void bn_train_apply_kernel(long long pixels, int cv, const T* __restr
     if (blockIdx.x == 0) {
         if (threadIdx.x == 0) bump_batches_tracked(num_batches_tracked, relu, groups);
         for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+            float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 0.f;
             for (int g_ = 0; g_ < groups; ++g_) {
                 const float* st = stats + (long long)g_ * 2 * C;
                 float* sv = saved + (long long)g_ * 4 * C;
                 const float m = st[c] / count;
                 const float var = fmaxf(st[C + c] / count - m * m, 0.f);
                 const float is = 1.0f / sqrtf(var + eps);
-                const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
                 sv[c] = m;
                 sv[C + c] = is;
                 sv[2 * C + c] = g * is;
                 sv[3 * C + c] = b - m * g * is;
-                if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
-                if (running_var) {
-                    const float unbiased = count > 1.f ? var * (count / (count - 1.f)) : var;
-                    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
-                }
+                rm = (1.f - momentum) * rm + momentum * m;
+                const float unbiased = count > 1.f ? var * (count / (count - 1.f)) : var;
+                rv = (1.f - momentum) * rv + momentum * unbiased;
             }
+            if (running_mean) running_mean[c] = rm;
+            if (running_var) running_var[c] = rv;
         }
+        return;
     }
     const long long total = pixels * cv;
-    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * blockDim.x) {
+    const long long stride = (long long)(gridDim.x - 1) * blockDim.x;
+    for (long long idx = (blockIdx.x - 1) * (long long)blockDim.x + threadIdx.x; idx < total; idx += stride) {
         const long long pix = idx / cv;
         const int c = (int)(idx - pix * cv) * VEC;
         const float* stats_g = groups > 1 ? stats + (pix / mg) * 2 * C : stats;
@@ -319,24 +324,30 @@ __global__ void bn_bwd_apply_kernel(long long pixels, int cv, const T* __restric
     const int C = cv * VEC;
     const long long total = pixels * cv;
     const long long mg = pixels / groups;
-    if ((dgamma_acc || red_total) && blockIdx.x == 0)          // parameter gradients: grad += this pass's reduction, summed over
-        for (int c = threadIdx.x; c < C; c += blockDim.x) {    // the groups in order (one block, plain RMW)
-            float sg = 0.f, sb = 0.f;
-            for (int g_ = 0; g_ < groups; ++g_) {
-                sg += red[(long long)g_ * 2 * C + C + c];
-                sb += red[(long long)g_ * 2 * C + c];
+    // block 0 takes no share of the map: parameter gradients (grad += this pass's reduction, summed over the groups in order; one
+    // block, plain RMW) beside the pass instead of in front of block 0's share of it (round 5, see bn_train_apply_kernel)
+    if (blockIdx.x == 0) {
+        if (dgamma_acc || red_total)
+            for (int c = threadIdx.x; c < C; c += blockDim.x) {
+                float dg = dgamma_acc ? dgamma_acc[c] : 0.f, db = dgamma_acc ? dbeta_acc[c] : 0.f;
+                float sg = 0.f, sb = 0.f;
+                for (int g_ = 0; g_ < groups; ++g_) {
+                    sg += red[(long long)g_ * 2 * C + C + c];
+                    sb += red[(long long)g_ * 2 * C + c];
+                }
+                if (dgamma_acc) {
+                    dgamma_acc[c] = dg + sg;
+                    dbeta_acc[c] = db + sb;
+                }
+                if (red_total) {
+                    red_total[c] = sb;
+                    red_total[C + c] = sg;
+                }
             }
-            if (dgamma_acc) {
-                dgamma_acc[c] += sg;
-                dbeta_acc[c] += sb;
-            }
-            if (red_total) {
-                red_total[c] = sb;
-                red_total[C + c] = sg;
-            }
-        }
-    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * blockDim.x) {
+        return;
+    }
+    const long long stride = (long long)(gridDim.x - 1) * blockDim.x;
+    for (long long idx = (blockIdx.x - 1) * (long long)blockDim.x + threadIdx.x; idx < total; idx += stride) {
         const long long pix = idx / cv;
         const int c = (int)(idx - pix * cv) * VEC;
         const long long grp = groups > 1 ? pix / mg : 0;
@@ -722,7 +733,7 @@ extern "C" fs_status fs_bn_bwd_apply_g(void* stream, long long pixels, int C, in
     FS_REQUIRE(mean && invstd && gamma && red && count > 0, FS_ERR_INVALID, "fs_bn_bwd_apply: bad argument");
     FS_REQUIRE(groups >= 1 && pixels % groups == 0, FS_ERR_INVALID, "fs_bn_bwd_apply: %lld pixels in %d groups", pixels, groups);
     const int cv = C / vec_elems(dtype);
-    DT_DISPATCH(dtype, FS_LAUNCH((bn_bwd_apply_kernel<T>), dim3(grid_for(pixels * cv)), dim3(256), 0, (hipStream_t)stream,
+    DT_DISPATCH(dtype, FS_LAUNCH((bn_bwd_apply_kernel<T>), dim3(grid_for(pixels * cv) + 1), dim3(256), 0, (hipStream_t)stream,
                                           pixels, cv, (const T*)x, x_cs, (const T*)dy, dy_cs, (const T*)y_out, y_cs, mean, invstd,
                                           gamma, red, 1.0f / (float)count, relu, (T*)dx, dx_cs, dgamma_acc, dbeta_acc, groups,
                                           saved_stride, red_total);)
@@ -813,7 +824,7 @@ extern "C" fs_status fs_bn_train_apply_g(void* stream, long long pixels, int C, 
     FS_REQUIRE(stats && saved && pixels > 0, FS_ERR_INVALID, "fs_bn_train_apply: bad argument");
     FS_REQUIRE(groups >= 1 && pixels % groups == 0, FS_ERR_INVALID, "fs_bn_train_apply: %lld pixels in %d groups", pixels, groups);
     const int cv = C / vec_elems(dtype);
-    DT_DISPATCH(dtype, FS_LAUNCH((bn_train_apply_kernel<T>), dim3(grid_for(pixels * cv)), dim3(256), 0, (hipStream_t)stream,
+    DT_DISPATCH(dtype, FS_LAUNCH((bn_train_apply_kernel<T>), dim3(grid_for(pixels * cv) + 1), dim3(256), 0, (hipStream_t)stream,
                                           pixels, cv, (const T*)x, x_cs, stats, (float)(pixels / groups), gamma, beta, eps, momentum,
                                           running_mean, running_var, num_batches_tracked, saved, (T*)y, y_cs, relu, groups);)
     return check_launch("fs_bn_train_apply");

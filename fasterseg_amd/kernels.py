@@ -531,7 +531,7 @@ def weighted_sum_dots(dy, xs):
     """fp32 vector [<dy, x_k>]."""
     dy_cs = require_nhwc(dy, "dy")
     n, ptrs, strides = _operand_arrays(xs)
-    out = torch.zeros(n, dtype=torch.float32, device=dy.device)
+    out = zeros_f32(n, dy.device)             # the step's zero arena (one fill per step / graph replay) instead of one fill launch per call
     call("fs_weighted_sum_dots", _stream(), _pix(dy), dy.shape[1], n, dy.data_ptr(), dy_cs, ptrs, strides, dtype_code(dy.dtype),
          out.data_ptr())
     return out

@@ -692,6 +692,8 @@ class Network_Multi_Path(nn.Module):
         coef_rows = self._coefficient_rows(alphas, ratios, mode) if _BATCHED_COEFS else None
         # one host read of the whole beta tables instead of one implicit sync per cell (reference :326-328)
         beta_pos = _positive_table(betas)
+        # rows handed out by ONE unbind per table: `betas[j][row]` per cell is a select whose backward is a zero-fill + copy + add per cell
+        beta_rows = [None] + [b.unbind(0) for b in betas[1:]]
 
         out_prev = [[stem(input), None]]  # stem: one cell
         probe = [[_SAMPLED] * len(r) for r in ratios]          # which entries of a cell's (in, out, down) widths are sampled
@@ -737,7 +739,7 @@ class Network_Multi_Path(nn.Module):
                 elif i == j:
                     out.append((res[(j, 0, 0)], res.get((j, 0, 1))))
                 else:
-                    b = betas[j][i - j - 1]
+                    b = beta_rows[j][i - j - 1]
                     if (j, 2, 0) in res:
                         out.append((FN.pair_merge(res[(j, 2, 0)], b), FN.pair_merge(res[(j, 2, 1)], b) if (j, 2, 1) in res else 0))
                     else:

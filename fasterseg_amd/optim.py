@@ -104,9 +104,16 @@ class FlatSGD:
                 raise RuntimeError("FlatSGD: parameter storage moved since the optimizer was built")
         scale = None
         self.last_norm = None
+        gs = float(getattr(sync, "grad_scale", 1.0))          # average="defer": the buffer holds the SUM over ranks
         if self.max_norm is not None:
             self.last_norm = sync.flat.norm()                 # slices of untouched parameters are zero
+            if gs != 1.0:
+                self.last_norm = self.last_norm * gs          # norm of the average
             scale = torch.clamp(self.max_norm / (self.last_norm + 1e-6), max=1.0)
+            if gs != 1.0:
+                scale = scale * gs                            # ... and the kernel's gradient read applies clip and average at once
+        elif gs != 1.0:
+            scale = torch.full((), gs, dtype=torch.float32, device=sync.flat.device)
         touched = sync._touched
         if self.unused == "decay":
             ever = self._ever_touched or [False] * len(touched)

@@ -82,7 +82,7 @@ class _Desc:
 class _List:
     """One direction (forward or backward) of a program."""
 
-    def __init__(self, zero_slot):
+    def __init__(self, zero_slot=ZF):
         self.words = []
         self.blob = bytearray()
         self.sizes = {}             # arena slot -> bytes

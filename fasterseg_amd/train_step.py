@@ -28,7 +28,7 @@ class StudentDistillStep:
         broadcast_parameters(self.teacher)
         min_kept = int(batch * height * width // 16)                       # train/train.py:62 with gt_down_sampling = 1
         self.ohem = ProbOhemCrossEntropy2d(ignore_label=255, thresh=0.7, min_kept=min_kept, use_weight=False)
-        self.sync = FlatGradientSync(self.student.parameters(), bucket_mb=4)      # 17.6 MB -> 5 buckets, overlapped with backward
+        self.sync = FlatGradientSync(self.student.parameters(), bucket_mb=4, average="defer")      # 17.6 MB -> 5 buckets, overlapped with backward
         self.optimizer = FlatSGD(self.sync, lr, momentum, weight_decay, pack_dtype=compute_dtype)       # train/train.py:173-176
         self.lamb = 0.2
         # loss heads straight from the 1/8 - 1/32 resolution logits (loss_up.hip): the up-sampled (B, 19, H, W) tensors of
@@ -150,7 +150,7 @@ class SupernetStep:
         self.arch_params = [p for group in self.model._arch_parameters for p in group]
         for p in self.arch_params:
             p.requires_grad_(False)
-        self.sync = FlatGradientSync(self.weights, bucket_mb=128)
+        self.sync = FlatGradientSync(self.weights, bucket_mb=128, average="defer")      # FlatSGD folds 1 / world into its clip scale
         # train_search.py:94-98 SGD + :249 clip_grad_norm_(5), one launch over the flat buffers
         self.optimizer = FlatSGD(self.sync, cfg.lr, cfg.momentum, cfg.weight_decay, max_norm=cfg.grad_clip,
                                  pack_dtype=compute_dtype, unused=os.environ.get("FS_SGD_UNUSED", "skip"))

@@ -51,12 +51,18 @@ def _student_worker(rank, world, port, out):
     loss = ohem_ce_lowres(st.ohem, p8, target) + 0.2 * ohem_ce_lowres(st.ohem, p16, target) + 0.2 * ohem_ce_lowres(st.ohem, p32, target)
     (loss + distill_kl_lowres(p8, t_logits, (128, 256))).backward()
     st.sync.sync()
-    synced = {k: (None if p.grad is None else p.grad.detach().float().cpu().clone()) for k, p in st.student.named_parameters()}
+    # average="defer": the buffer holds the SUM over ranks and sync.grad_scale = 1 / world, which FlatSGD folds into its gradient read
+    assert st.sync.grad_scale == 0.5
+    synced = {k: (None if p.grad is None else (p.grad.detach().float() * st.sync.grad_scale).cpu().clone()) for k, p in st.student.named_parameters()}
+    probe = [k for k, p in st.student.named_parameters() if p.grad is not None and p.dim() in (1, 4)][:40:13]
+    before = {k: dict(st.student.named_parameters())[k].detach().float().cpu().clone() for k in probe}
     st.optimizer.step()
+    after = {k: dict(st.student.named_parameters())[k].detach().float().cpu().clone() for k in probe}
     for _ in range(2):
         st.step(imgs, target)
     torch.cuda.synchronize()
-    torch.save({"local": local, "synced": synced, "state": {k: v.detach().cpu() for k, v in st.student.state_dict().items()}},
+    torch.save({"local": local, "synced": synced, "state": {k: v.detach().cpu() for k, v in st.student.state_dict().items()},
+                "before": before, "after": after, "hyper": (st.optimizer.lr, st.optimizer.weight_decay)},
                "%s.r%d" % (out, rank))
     dist.destroy_process_group()
 
@@ -83,6 +89,14 @@ def test_student_step_data_parallel_two_ranks_one_gpu(tmp_path):
     # amplifies to several per cent in a few tensors - the bar had to be 8e-2): a sum-instead-of-mean or a missed bucket is off by 50-100 %.
     assert worst[0][0] <= 1e-4, worst[:8]
     assert n > 100
+    # the first SGD step applied the AVERAGE (momentum buffer starts at zero: w1 = w0 - lr * (g_avg + wd * w0)); a sum instead of the mean
+    # would double the update
+    lr, wd = r0["hyper"]
+    assert len(r0["before"]) >= 2
+    for k in r0["before"]:
+        w0, w1 = r0["before"][k], r0["after"][k]
+        want = w0 - lr * (r0["synced"][k] + wd * w0)
+        assert float((w1 - want).abs().max()) <= 1e-6 + 1e-4 * float((w1 - w0).abs().max()), k
     for k in r0["state"]:
         if k.endswith(("running_mean", "running_var", "num_batches_tracked")):
             continue                                  # BatchNorm statistics stay per rank by design (no SyncBN in the reference)

@@ -52,6 +52,45 @@ def test_graphed_supernet_step_equals_eager():
         assert rel < 2e-2, (k, rel)
 
 
+def test_graphed_l16_supernet_step_tracks_eager_over_12_steps():
+    """a capture-path fault that only shows "from the 5th replay on" would pass the 3-step comparison above
+    and bench.py's step-0 gate.  The benchmarked configuration itself - F12.L16, 3 x 3x256x512, bf16, default switches - stepped 12 times
+    from its hipGraphs and 12 times eagerly from the same seeds: every loss finite, the two trajectories side by side (float atomics and
+    grouped-vs-single launches reorder sums, tiny-batch BatchNorm amplifies that: the bar is a few per cent, an inf / NaN / runaway
+    replay is orders of magnitude), probe weights finite and close."""
+    from fasterseg_amd.train_step import SupernetStep
+
+    def run(use_graphs):
+        st = SupernetStep(pretrain=True, seed=11, use_graphs=use_graphs, compute_dtype=torch.bfloat16)
+        g = torch.Generator().manual_seed(3)
+        imgs = torch.randn(3, 3, 256, 512, generator=g).cuda()
+        tgt = torch.randint(0, 19, (3, 32, 64), generator=g)
+        tgt[torch.rand(3, 32, 64, generator=g) < 0.05] = 255
+        tgt = tgt.cuda()
+        np.random.seed(21)
+        losses = []
+        for _ in range(12):
+            losses.append(float(st.step(imgs, tgt)[0]))
+            assert bool(torch.isfinite(st.sync.flat).all()), ("non-finite gradient after step %d" % len(losses), use_graphs, losses)
+        probe = {k: p.detach().float().cpu().clone() for k, p in st.model.named_parameters()
+                 if k in ("stem.0.0.conv.0.weight", "cells.3.1._op._ops.3.conv1.weight", "cells.9.2._op._ops.1.conv1.weight", "head02.0.conv_1x1.weight")}
+        del st
+        torch.cuda.empty_cache()
+        return losses, probe
+    graph_losses, graph_w = run(True)
+    eager_losses, eager_w = run(False)
+    assert all(np.isfinite(graph_losses)) and all(np.isfinite(eager_losses)), (graph_losses, eager_losses)
+    worst = max(abs(a - b) / abs(a) for a, b in zip(eager_losses, graph_losses))
+    print("12-step L16 trajectories: eager %s\n graphed %s\n worst relative gap %.3e" % (eager_losses, graph_losses, worst))
+    assert worst <= 5e-2, (worst, eager_losses, graph_losses)
+    assert min(graph_losses[-3:]) < graph_losses[0]                   # it trains
+    assert len(graph_w) == 4
+    for k in graph_w:
+        assert bool(torch.isfinite(graph_w[k]).all()), k
+        rel = float((eager_w[k] - graph_w[k]).norm() / (eager_w[k].norm() + 1e-12))
+        assert rel < 0.15, (k, rel)
+
+
 def test_deterministic_mode_makes_supernet_steps_bit_identical():
     """kernels.deterministic() (fs_set_deterministic): two fresh builds of the graphed pretrain step - fused MixedOp programs, eager
     lanes, pair batching and all - on the same batch and seeds produce the SAME bits: losses of three consecutive SGD steps and the
