@@ -15,6 +15,10 @@
 //   kind 4: pointer array      [4, n, 0] + n x [slot, offset]  -> host array of n resolved pointers (a null slot entry
 //                                                                 with offset -1 stays NULL)
 //   kind 5: int array          [5, n, 0] + n x [value]         -> host array of n ints
+// Op word: bits 0-15 the op code, bits 16-39 the stream lane (multi-stream form), bit 40 JOIN = "independent of the NEXT command, which
+// has the same op": a run of joined bare convolutions (FS_OP_CONV_FWD) or strided weight gradients (FS_OP_WGRAD_STRIDED) goes out as ONE
+// grouped launch - the two 1x1 stride-2 convolutions of a FactorizedReduce (reference search/operations.py:521-526), their two weight
+// gradients and their two data gradients are one launch each instead of two (round 5).
 #include <string.h>
 #include "conv_igemm.h"
 
@@ -64,10 +68,11 @@ extern "C" void fs_event_destroy(void* ev) {
 // graph replay can become host-bound on a slow host core.
 // one command of a program: op, stream lane and resolved arguments; advances pos
 static fs_status parse_command(const long long* words, long long n_words, long long& pos, const unsigned char* blob, void* const* slots,
-                               int n_slots, int index, int& op, int& lane, int& nargs, Args& a) {
+                               int n_slots, int index, int& op, int& lane, int& nargs, Args& a, int* join = nullptr) {
     FS_REQUIRE(pos + 2 <= n_words, FS_ERR_INVALID, "fs_exec_program: truncated command %d", index);
     op = (int)(words[pos] & 0xffff);
-    lane = (int)(words[pos] >> 16);
+    lane = (int)((words[pos] >> 16) & 0xffffff);
+    if (join) *join = (int)((words[pos] >> 40) & 1);
     nargs = (int)words[pos + 1];
     pos += 2;
     FS_REQUIRE(nargs >= 0 && nargs <= MAX_ARGS, FS_ERR_INVALID, "fs_exec_program: command %d has %d arguments", index, nargs);
@@ -242,22 +247,68 @@ fs_status st = FS_OK;
     return st;
 }
 
+// n commands of one op that do not depend on each other (a JOIN run, or the same command of several lockstep programs): bare
+// convolutions and strided weight gradients as grouped launches of up to FS_MAX_GROUP problems, anything else one by one
+constexpr int MAX_POOL = 2 * FS_MAX_GROUP;
+static fs_status run_pool(int op, int nargs, Args* pool, int n, void* stream, int index) {
+    fs_status st = FS_OK;
+    for (int lo = 0; lo < n && st == FS_OK; lo += FS_MAX_GROUP) {
+        const int m = n - lo < FS_MAX_GROUP ? n - lo : FS_MAX_GROUP;
+        Args* q = pool + lo;
+        if (m > 1 && op == FS_OP_CONV_FWD && nargs == 9) {
+            const fs_conv_desc* dp[FS_MAX_GROUP];
+            fs::ConvArgs args[FS_MAX_GROUP];
+            for (int i = 0; i < m && st == FS_OK; ++i) {
+                dp[i] = (const fs_conv_desc*)q[i].pv[0];
+                st = fs::conv_prepare(dp[i], q[i].pv[1], q[i].pv[2], (const float*)q[i].pv[3], (const float*)q[i].pv[4], q[i].pv[5], (float*)q[i].pv[6],
+                                      &args[i]);
+            }
+            if (st == FS_OK) st = fs::conv_launch_group(stream, dp, args, m);
+        } else if (m > 1 && op == FS_OP_WGRAD_STRIDED && nargs == 9) {
+            const fs_conv_desc* dp[FS_MAX_GROUP];
+            const void* xs[FS_MAX_GROUP];
+            const void* dys[FS_MAX_GROUP];
+            float* dws[FS_MAX_GROUP];
+            long long so[FS_MAX_GROUP], si[FS_MAX_GROUP], ts[FS_MAX_GROUP];
+            for (int i = 0; i < m; ++i) {
+                dp[i] = (const fs_conv_desc*)q[i].pv[0]; xs[i] = q[i].pv[1]; dys[i] = q[i].pv[2]; dws[i] = (float*)q[i].pv[3];
+                so[i] = q[i].iv[4]; si[i] = q[i].iv[5]; ts[i] = q[i].iv[6];
+            }
+            st = fs::wgrad_launch_group(stream, m, dp, xs, dys, dws, so, si, ts, q[0].pv[7], q[0].iv[8]);
+        } else {
+            for (int i = 0; i < m && st == FS_OK; ++i) st = run_command(op, nargs, q[i], stream, index);
+        }
+    }
+    return st;
+}
+
 extern "C" fs_status fs_exec_program_streams(void* const* streams, int n_streams, const long long* words, long long n_words,
                                              const unsigned char* blob, void* const* slots, int n_slots) {
     FS_REQUIRE(streams && n_streams > 0 && words && n_words >= 0 && slots && n_slots > 0, FS_ERR_INVALID,
                "fs_exec_program: bad argument");
     long long pos = 0;
     int index = 0;
+    static thread_local Args pool[MAX_POOL];
+    int pooled = 0, pool_op = -1, pool_nargs = 0, pool_lane = 0;
     while (pos < n_words) {
-        int op, lane, nargs;
-        Args a;
-        fs_status st = parse_command(words, n_words, pos, blob, slots, n_slots, index, op, lane, nargs, a);
+        int op, lane, nargs, join = 0;
+        Args& a = pool[pooled];
+        fs_status st = parse_command(words, n_words, pos, blob, slots, n_slots, index, op, lane, nargs, a, &join);
         if (st != FS_OK) return st;
         FS_REQUIRE(lane >= 0 && lane < n_streams, FS_ERR_INVALID, "fs_exec_program: command %d on stream %d of %d", index, lane, n_streams);
-        st = run_command(op, nargs, a, streams[lane], index);
-        if (st != FS_OK) return st;      // fs_last_error() already names the failing entry point
+        if (pooled > 0)
+            FS_REQUIRE(op == pool_op && nargs == pool_nargs && lane == pool_lane, FS_ERR_INVALID,
+                       "fs_exec_program: command %d does not continue the joined run before it", index);
+        pool_op = op; pool_nargs = nargs; pool_lane = lane;
+        ++pooled;
+        if (!join || pooled == MAX_POOL) {
+            st = pooled == 1 ? run_command(op, nargs, pool[0], streams[lane], index) : run_pool(op, nargs, pool, pooled, streams[lane], index);
+            if (st != FS_OK) return st;      // fs_last_error() already names the failing entry point
+            pooled = 0;
+        }
         ++index;
     }
+    FS_REQUIRE(pooled == 0, FS_ERR_INVALID, "fs_exec_program: the last command carries the JOIN bit");
     return FS_OK;
 }
 
@@ -274,19 +325,34 @@ extern "C" fs_status fs_exec_program_group(void* stream, int k, const long long*
     long long pos[FS_MAX_GROUP] = {0};
     int index = 0;
     static thread_local Args a[FS_MAX_GROUP];
+    static thread_local Args pool[FS_MAX_GROUP * MAX_POOL];      // a JOIN run of every program, program-major inside each command
+    int pooled = 0, pool_op = -1, pool_nargs = 0;
     while (pos[0] < n_words[0]) {
-        int op0 = -1, nargs0 = 0;
+        int op0 = -1, nargs0 = 0, join0 = 0;
         for (int i = 0; i < k; ++i) {
-            int op, lane, nargs;
+            int op, lane, nargs, join = 0;
             FS_REQUIRE(pos[i] < n_words[i], FS_ERR_INVALID, "fs_exec_program_group: program %d is shorter than program 0", i);
             const fs_status st = parse_command(words[i], n_words[i], pos[i], blobs[i], slots + (long long)i * n_slots, n_slots, index, op, lane, nargs,
-                                               a[i]);
+                                               a[i], &join);
             if (st != FS_OK) return st;
-            if (i == 0) { op0 = op; nargs0 = nargs; }
-            FS_REQUIRE(op == op0 && nargs == nargs0, FS_ERR_INVALID, "fs_exec_program_group: command %d differs between programs 0 and %d", index, i);
+            if (i == 0) { op0 = op; nargs0 = nargs; join0 = join; }
+            FS_REQUIRE(op == op0 && nargs == nargs0 && join == join0, FS_ERR_INVALID,
+                       "fs_exec_program_group: command %d differs between programs 0 and %d", index, i);
         }
         fs_status st = FS_OK;
-        if (k > 1 && op0 == FS_OP_UNIT_FWD && nargs0 == 16) {
+        if (join0 || pooled > 0) {
+            // joined run: command after command of all k programs collected, then issued as grouped launches of up to FS_MAX_GROUP problems
+            if (pooled > 0)
+                FS_REQUIRE(op0 == pool_op && nargs0 == pool_nargs, FS_ERR_INVALID,
+                           "fs_exec_program_group: command %d does not continue the joined run before it", index);
+            FS_REQUIRE(pooled + k <= FS_MAX_GROUP * MAX_POOL, FS_ERR_INVALID, "fs_exec_program_group: joined run too long at command %d", index);
+            for (int i = 0; i < k; ++i) pool[pooled++] = a[i];
+            pool_op = op0; pool_nargs = nargs0;
+            if (!join0) {
+                st = run_pool(pool_op, pool_nargs, pool, pooled, stream, index);
+                pooled = 0;
+            }
+        } else if (k > 1 && op0 == FS_OP_UNIT_FWD && nargs0 == 16) {
             fs::UnitFwdCall u[FS_MAX_GROUP];
             for (int i = 0; i < k; ++i) {
                 Args& q = a[i];
@@ -304,33 +370,15 @@ extern "C" fs_status fs_exec_program_group(void* stream, int k, const long long*
                                        q.iv[14], q.iv[15], q.iv[16], q.pv[17], (int)q.iv[18], (int)q.iv[19], (int)q.iv[20], q.pv[21], q.iv[22]};
             }
             st = fs::unit_bwd_group(stream, u, k);
-        } else if (k > 1 && op0 == FS_OP_CONV_FWD && nargs0 == 9) {
-            const fs_conv_desc* dp[FS_MAX_GROUP];
-            fs::ConvArgs args[FS_MAX_GROUP];
-            for (int i = 0; i < k && st == FS_OK; ++i) {
-                Args& q = a[i];
-                dp[i] = (const fs_conv_desc*)q.pv[0];
-                st = fs::conv_prepare(dp[i], q.pv[1], q.pv[2], (const float*)q.pv[3], (const float*)q.pv[4], q.pv[5], (float*)q.pv[6], &args[i]);
-            }
-            if (st == FS_OK) st = fs::conv_launch_group(stream, dp, args, k);
-        } else if (k > 1 && op0 == FS_OP_WGRAD_STRIDED && nargs0 == 9) {
-            const fs_conv_desc* dp[FS_MAX_GROUP];
-            const void* xs[FS_MAX_GROUP];
-            const void* dys[FS_MAX_GROUP];
-            float* dws[FS_MAX_GROUP];
-            long long so[FS_MAX_GROUP], si[FS_MAX_GROUP], ts[FS_MAX_GROUP];
-            for (int i = 0; i < k; ++i) {
-                Args& q = a[i];
-                dp[i] = (const fs_conv_desc*)q.pv[0]; xs[i] = q.pv[1]; dys[i] = q.pv[2]; dws[i] = (float*)q.pv[3];
-                so[i] = q.iv[4]; si[i] = q.iv[5]; ts[i] = q.iv[6];
-            }
-            st = fs::wgrad_launch_group(stream, k, dp, xs, dys, dws, so, si, ts, a[0].pv[7], a[0].iv[8]);
+        } else if (k > 1 && (op0 == FS_OP_CONV_FWD || op0 == FS_OP_WGRAD_STRIDED) && nargs0 == 9) {
+            st = run_pool(op0, nargs0, a, k, stream, index);
         } else {
             for (int i = 0; i < k && st == FS_OK; ++i) st = run_command(op0, nargs0, a[i], stream, index);
         }
         if (st != FS_OK) return st;
         ++index;
     }
+    FS_REQUIRE(pooled == 0, FS_ERR_INVALID, "fs_exec_program_group: the last command carries the JOIN bit");
     for (int i = 1; i < k; ++i) FS_REQUIRE(pos[i] == n_words[i], FS_ERR_INVALID, "fs_exec_program_group: program %d is longer than program 0", i);
     return FS_OK;
 }

@@ -96,8 +96,9 @@ class _List:
         self.sizes[slot] = off + nbytes
         return Ref(slot, off)
 
-    def emit(self, op, *args, lane=0):
-        self.words.append((op | (lane << 16), args))
+    def emit(self, op, *args, lane=0, join=False):
+        """join=True: this command and the NEXT one (same op) are independent; the executor issues the run as one grouped launch."""
+        self.words.append((op | (lane << 16) | (int(bool(join)) << 40), args))
 
     def finish(self):
         out = []
@@ -402,13 +403,14 @@ class _Lowering:
         Ho, Wo = x.H // 2, x.W // 2
         z = self.new(f, SAVE, x.N, C2, Ho, Wo)
         y = self.new(f, SAVE, x.N, C2, Ho, Wo)
-        descs = []
-        for k, (conv, pad) in enumerate(((op.conv1, 0), (op.conv2, -1))):
-            w = conv.weight
-            wp, w_os, w_ts = self.filter(f, TMPF, w, half, cin, False)
-            d = ConvDesc(x.N, x.H, x.W, cin, half, 1, 1, 2, pad, Ho, Wo, x.cs, C2, self.dt, 0, w_os, w_ts)
-            descs.append(d)
-            f.emit(OP_CONV_FWD, _Desc(d), x.ref, wp, NULL, NULL, z.ref + k * half * self.esize, NULL, Ref(WS, 0), K.WORKSPACE_BYTES)
+        descs, packs = [], []
+        for conv, pad in ((op.conv1, 0), (op.conv2, -1)):           # (the filters first: a non-resident one emits its pack command here)
+            wp, w_os, w_ts = self.filter(f, TMPF, conv.weight, half, cin, False)
+            packs.append(wp)
+            descs.append(ConvDesc(x.N, x.H, x.W, cin, half, 1, 1, 2, pad, Ho, Wo, x.cs, C2, self.dt, 0, w_os, w_ts))
+        for k in range(2):      # both read x, each writes its own channel half of z: ONE grouped launch (JOIN, csrc/program.hip)
+            f.emit(OP_CONV_FWD, _Desc(descs[k]), x.ref, packs[k], NULL, NULL, z.ref + k * half * self.esize, NULL, Ref(WS, 0), K.WORKSPACE_BYTES,
+                   join=(k == 0 and _JOIN_FR))
         G = self.groups
         stats = f.alloc(TMPF, G * 2 * C2 * 4, zero=True)
         saved = f.alloc(SAVE, G * 4 * C2 * 4)
@@ -424,24 +426,24 @@ class _Lowering:
             acc = (absolute(self.grad_slot(b.weight)), absolute(self.grad_slot(b.bias))) if self.want_w else (NULL, NULL)
             bl.emit(OP_BN_UNIT_BWD, z.pixels, C2, G, z.ref, z.cs, dy.ref, dy.cs, y.ref, y.cs, saved, absolute(b.weight), red,
                     self.dt, 1, dz.ref, dz.cs, acc[0], acc[1], Ref(WS, 0), K.WORKSPACE_BYTES)
-            dx = None
-            for k, conv in enumerate((op.conv1, op.conv2)):
-                w = conv.weight
-                dzk = dz.ref + k * half * self.esize
-                if self.want_w:
-                    g = self.grad_slot(w)
-                    bl.emit(OP_WGRAD_STRIDED, _Desc(descs[k]), x.ref, dzk, absolute(g), g.stride(0), g.stride(1), g.stride(3), Ref(WS, 0),
-                            K.WORKSPACE_BYTES)
-                if need_x:
-                    wf, wf_os, wf_ts = self.filter(bl, TMPB, w, half, cin, True)
-                    gk = self.new(bl, TMPB, x.N, cin, x.H, x.W)
-                    g = ConvDesc(x.N, Ho, Wo, half, cin, 1, 1, 1, 0 - descs[k].pad, x.H, x.W, C2, cin, self.dt, K.FS_CONV_TRANSPOSED,
-                                 wf_os, wf_ts)
-                    bl.emit(OP_CONV_FWD, _Desc(g), dzk, wf, NULL, NULL, gk.ref, NULL, Ref(WS, 0), K.WORKSPACE_BYTES)
-                    if dx is None:
-                        dx = gk
-                    else:       # the second branch touches only odd (h, w): disjoint from the first one's even taps
-                        bl.emit(OP_AXPY, dx.pixels, cin, gk.ref, gk.cs, absolute(_ones(b.weight.device)), dx.ref, dx.cs, self.dt, 1)
+            convs = (op.conv1, op.conv2)
+            dzs = [dz.ref + k * half * self.esize for k in range(2)]
+            if self.want_w:         # the two weight gradients: independent, one grouped launch
+                for k, conv in enumerate(convs):
+                    g = self.grad_slot(conv.weight)
+                    bl.emit(OP_WGRAD_STRIDED, _Desc(descs[k]), x.ref, dzs[k], absolute(g), g.stride(0), g.stride(1), g.stride(3), Ref(WS, 0),
+                            K.WORKSPACE_BYTES, join=(k == 0 and _JOIN_FR))
+            if not need_x:
+                return None
+            flips = [self.filter(bl, TMPB, conv.weight, half, cin, True) for conv in convs]
+            gks = [self.new(bl, TMPB, x.N, cin, x.H, x.W) for _ in convs]
+            for k in range(2):      # the two data gradients into their own maps: one grouped launch, then the sum
+                wf, wf_os, wf_ts = flips[k]
+                g = ConvDesc(x.N, Ho, Wo, half, cin, 1, 1, 1, 0 - descs[k].pad, x.H, x.W, C2, cin, self.dt, K.FS_CONV_TRANSPOSED, wf_os, wf_ts)
+                bl.emit(OP_CONV_FWD, _Desc(g), dzs[k], wf, NULL, NULL, gks[k].ref, NULL, Ref(WS, 0), K.WORKSPACE_BYTES, join=(k == 0 and _JOIN_FR))
+            dx, gk = gks
+            # the second branch touches only odd (h, w): disjoint from the first one's even taps
+            bl.emit(OP_AXPY, dx.pixels, cin, gk.ref, gk.cs, absolute(_ones(b.weight.device)), dx.ref, dx.cs, self.dt, 1)
             return dx
         return y, backward
 
@@ -495,6 +497,9 @@ def _ones(device):
 # FS_FUSE_MIXEDOP=0 lowers every primitive on its own (the round-2 programs)
 import os
 _FUSE = bool(int(os.environ.get("FS_FUSE_MIXEDOP", "1")))
+# FactorizedReduce (operations.py:521-526): its two 1x1 stride-2 convolutions, their weight gradients and their data gradients as one
+# grouped launch each (JOIN bit).  FS_JOIN_FR=0: one launch per convolution (the round-4 programs).
+_JOIN_FR = bool(int(os.environ.get("FS_JOIN_FR", "1")))
 
 
 def _lower_fused(lo, x, mixed, need_x):

@@ -16,14 +16,20 @@ NARGS = {program.OP_MEMSET: 2, program.OP_PACK_WEIGHT: 10, program.OP_CONV_FWD: 
 WIDTHS = [4. / 12, 6. / 12, 8. / 12, 10. / 12, 1.]
 
 
+JOINS = []          # (op, join bit) of every command decoded last
+
+
 def decode(words, n, sizes):
     """-> list of (op, [args]); asserts structural validity."""
     w = list(words[:n])
     pos, cmds = 0, []
+    del JOINS[:]
     while pos < n:
-        op, nargs = w[pos], w[pos + 1]
+        word, nargs = w[pos], w[pos + 1]
+        op, join = word & 0xffff, (word >> 40) & 1          # bits 16-39: stream lane, bit 40: JOIN with the next command
         pos += 2
         assert op in NARGS and nargs == NARGS[op], (op, nargs)
+        JOINS.append((op, join))
         args = []
         for _ in range(nargs):
             kind, s, v = w[pos:pos + 3]
@@ -71,6 +77,18 @@ def test_mixed_op_lowering_structure(stride, want_w):
     fwd = decode(prog.f_words, prog.f_n, {program.SAVE: prog.save_bytes, program.TMPF: prog.tmpf_bytes, program.ZF: prog.zf_bytes})
     bwd = decode(prog.b_words, prog.b_n, {program.SAVE: prog.save_bytes, program.TMPB: prog.tmpb_bytes, program.ZB: prog.zb_bytes})
     f_ops, b_ops = [c[0] for c in fwd], [c[0] for c in bwd]
+    # JOIN runs (round 5): the FactorizedReduce of a stride-2 MixedOp issues its two 1x1 convolutions, their two weight gradients and their
+    # two data gradients as one grouped launch each; a joined command is always followed by the same op
+    decode(prog.f_words, prog.f_n, {})
+    f_join = list(JOINS)
+    decode(prog.b_words, prog.b_n, {})
+    b_join = list(JOINS)
+    for seq in (f_join, b_join):
+        for (op, j), (nxt, _) in zip(seq, seq[1:] + [(None, 0)]):
+            assert not j or nxt == op, (op, nxt)
+    assert [op for op, j in f_join if j] == ([program.OP_CONV_FWD] if stride == 2 else [])
+    want_b = ([program.OP_WGRAD_STRIDED] if want_w else []) + [program.OP_CONV_FWD]
+    assert [op for op, j in b_join if j] == (want_b if stride == 2 else [])
     # forward: one weighted sum last; 6 conv->BN units for stride 1 (skip 1x1, conv, downup, 2x conv_2x, 2x ...).  No fill command: the
     # zero-initialised accumulators (BN statistics / reductions, coefficient gradients) are slices of the step's zero arena (slots ZF / ZB)
     assert program.OP_MEMSET not in f_ops and program.OP_MEMSET not in b_ops and f_ops[-1] == program.OP_WSUM

@@ -29,6 +29,14 @@ case $job in
     bash tools/prof_step.sh c3 3 r05_c3_probe 2>&1 | head -12
     python tools/trace_concurrency.py $(find /tmp/prof_step -name "*kernel_trace.csv" | head -1) $O/prof_step_r05_c3_probe.log 3 $O/r05_c3_concurrency.json
     ;;
+  call3)      # round 5, third call: the tests that touch the BN kernels / zero arenas / DP changes, step times, and the C2 part of the bench line
+    timeout 900 python -W ignore -m pytest tests/test_bn_group_gpu.py tests/test_conv_unit_gpu.py tests/test_train_steps_gpu.py tests/test_parallel_gpu.py \
+        tests/test_engine_gpu.py tests/test_ops_gpu.py tests/test_supernet.py tests/test_program_group_gpu.py \
+        "tests/test_kernels_gpu.py::test_batchnorm_train_fwd_bwd" "tests/test_kernels_gpu.py::test_bn_finalize_counter_and_fused_param_grad_accumulation" -m gpu -q -x --timeout 600 --durations=6 -s 2>&1 | grep -v "^$" | tail -30 | cut -c1-260
+    for wl in c3 c5; do timeout 400 python -W ignore tools/step_time.py $wl 20 2>&1 | grep -a STEP_TIME | tee -a $O/r05_step_times.txt; done
+    timeout 600 python -W ignore bench.py --workloads c2 --steps 20 --warmup 5 --detail $O/r05_bench_c2_detail.json > $O/r05_bench_c2.json 2> $O/r05_bench_c2.err; echo rc=$?
+    tail -c 2500 $O/r05_bench_c2.json; tail -3 $O/r05_bench_c2.err
+    ;;
   tests)      # bash tools/gpu_job.sh tests <pytest args...>
     timeout ${FS_JOB_TIMEOUT:-600} python -W ignore -m pytest "$@" -m gpu -q -x --timeout 300 --durations=8 2>&1 | tail -25 | cut -c1-240
     ;;
