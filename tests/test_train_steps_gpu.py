@@ -56,7 +56,7 @@ def test_graphed_l16_supernet_step_tracks_eager_over_12_steps():
     """a capture-path fault that only shows "from the 5th replay on" would pass the 3-step comparison above
     and bench.py's step-0 gate.  The benchmarked configuration itself - F12.L16, 3 x 3x256x512, bf16, default switches - stepped 12 times
     from its hipGraphs and 12 times eagerly from the same seeds: every loss finite, the two trajectories side by side (float atomics and
-    grouped-vs-single launches reorder sums, tiny-batch BatchNorm amplifies that: the bar is a few per cent, an inf / NaN / runaway
+    grouped-vs-single launches reorder sums, tiny-batch BatchNorm amplifies that: the bar is one per cent, an inf / NaN / runaway
     replay is orders of magnitude), probe weights finite and close."""
     from fasterseg_amd.train_step import SupernetStep
 
@@ -82,7 +82,7 @@ def test_graphed_l16_supernet_step_tracks_eager_over_12_steps():
     assert all(np.isfinite(graph_losses)) and all(np.isfinite(eager_losses)), (graph_losses, eager_losses)
     worst = max(abs(a - b) / abs(a) for a, b in zip(eager_losses, graph_losses))
     print("12-step L16 trajectories: eager %s\n graphed %s\n worst relative gap %.3e" % (eager_losses, graph_losses, worst))
-    assert worst <= 5e-2, (worst, eager_losses, graph_losses)
+    assert worst <= 1e-2, (worst, eager_losses, graph_losses)          # measured 5.4e-4 (profiles/r05_gpu_tests.log)
     assert min(graph_losses[-3:]) < graph_losses[0]                   # it trains
     assert len(graph_w) == 4
     for k in graph_w:

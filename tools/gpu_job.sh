@@ -37,6 +37,12 @@ case $job in
     timeout 600 python -W ignore bench.py --workloads c2 --steps 20 --warmup 5 --detail $O/r05_bench_c2_detail.json > $O/r05_bench_c2.json 2> $O/r05_bench_c2.err; echo rc=$?
     tail -c 2500 $O/r05_bench_c2.json; tail -3 $O/r05_bench_c2.err
     ;;
+  call4)      # round 5: what bounds the C3 step - host issue or device execution - and what the launch-grouping switches do on ONE box
+    timeout 300 python -W ignore tools/host_vs_device.py c3 10 2>&1 | grep -a -A4 HOST_VS | tee $O/r05_host_vs_device.txt
+    for env in "FS_NONE=1" "FS_GROUP_CAPTURE=2" "FS_GROUP_PROGRAMS=0" "FS_EAGER_LANES=1" "FS_JOIN_FR=0" "FS_LAYER_LANES=1"; do
+      env $env timeout 300 python -W ignore tools/step_time.py c3 20 2>&1 | grep -a STEP_TIME | sed "s/^/$env /" | tee -a $O/r05_switches_c3.txt
+    done
+    ;;
   tests)      # bash tools/gpu_job.sh tests <pytest args...>
     timeout ${FS_JOB_TIMEOUT:-600} python -W ignore -m pytest "$@" -m gpu -q -x --timeout 300 --durations=8 2>&1 | tail -25 | cut -c1-240
     ;;
