@@ -171,6 +171,12 @@ if _GROUP_CAPTURE == 1 and not int(os.environ.get("FS_ALLOW_BROKEN_CAPTURE", "0"
                        "ROCm 7.2 and is disabled; use FS_GROUP_CAPTURE=2 (all buckets on one side lane) or leave it at 0")
 
 
+# Round 5 measured what the forked capture layout costs and buys (profiles/r05_host_vs_device_c3.txt): replaying a forked graph of ~3 k
+# kernel nodes takes ~12.5 ms of HOST time on ROCm 7.2 (every cross-lane edge is a signal wired up per replay), a pass captured on ONE
+# stream replays in ~1 ms of host time - but the device then runs the pass as one chain, and the step got SLOWER (98 vs 86 ms; 90 with
+# grouped launches in the linear capture): the forks are worth more on the device than they cost on the host.  The layout stays.
+
+
 # SupernetStep.step(force_eager=True) - bench.py's census step - sets this: the fixed-width passes, which the timed steps replay from
 # hipGraphs, then issue the launches the capture would have recorded (ungrouped unless FS_GROUP_CAPTURE), so that the census times the
 # kernels of the timed steps and agrees with a rocprofv3 table of them.
@@ -472,12 +478,51 @@ class Cell(nn.Module):
         return out, down
 
 
-def _positive_table(betas):
-    """[(b0 > 0, b1 > 0), ...] per beta row.  One host read per forward; under hipGraph capture (no host sync allowed) the
-    softmax outputs are taken as positive, which they always are."""
-    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
-        return [None] + [[[True, True]] * b.shape[0] for b in betas[1:]]
-    return [None] + [(b > 0).tolist() for b in betas[1:]]
+def _positive_table(betas, key=None, cache=None):
+    """[(b0 > 0, b1 > 0), ...] per beta row (reference :326-328 tests `betas[..] > 0` once per cell: one device sync each).  Under hipGraph
+    capture (no host sync allowed) the softmax outputs are taken as positive, which they always are.
+
+    Round 5: the supernet step is HOST-bound (tools/host_vs_device.py), and this read was a full device drain at the head of every eager
+    forward - the host stood still until the replayed passes before it had finished, then the device stood still while the host caught up.
+    `cache` (a dict owned by the network) / `key` (arch index + the beta parameters' version counters): the table is read back ONCE per value
+    of the parameters - never again in a pretrain run, where they are frozen.  When the parameters have changed (the architect's Adam
+    step), the previous table is used and the new values are CHECKED asynchronously: `(b > 0).all()` goes to pinned host memory behind an
+    event, and the flag of the previous check is examined here without blocking; a softmax output can only become 0 when two logits differ
+    by > 87, i.e. after ~3e5 Adam steps of 3e-4 in one direction, so the optimistic table is the exact one in any run one can afford - and
+    if a check ever fails, this function says so and falls back to the blocking read for good."""
+    live = betas[1:]
+    if live and live[0].is_cuda and torch.cuda.is_current_stream_capturing():
+        return [None] + [[[True, True]] * b.shape[0] for b in live]
+    if cache is None or key is None or not (live and live[0].is_cuda):
+        return [None] + [(b > 0).tolist() for b in live]
+    if cache.get("blocking"):
+        return [None] + [(b > 0).tolist() for b in live]
+    # examine finished asynchronous checks (never blocks)
+    pending = cache.setdefault("pending", [])
+    while pending and pending[0][0].query():
+        _, flag = pending.pop(0)
+        if not bool(flag.item()):                   # (host tensor: no device access)
+            import warnings
+            warnings.warn("fasterseg_amd: a softmaxed beta reached 0 - switching to the blocking per-forward read of the beta tables")
+            cache["blocking"] = True
+            return [None] + [(b > 0).tolist() for b in live]
+    hit = cache.get("table")
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    shapes = tuple(b.shape[0] for b in live)
+    if hit is not None and hit[2] == shapes and len(pending) < 8:
+        # new parameter values: keep the table, verify the new values behind the launch stream
+        flag = torch.empty((), dtype=torch.bool).pin_memory()
+        ok = torch.stack([(b > 0).all() for b in live]).all()
+        flag.copy_(ok, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        pending.append((ev, flag))
+        cache["table"] = (key, hit[1], shapes)
+        return hit[1]
+    table = [None] + [(b > 0).tolist() for b in live]       # first use: one blocking read
+    cache["table"] = (key, table, shapes)
+    return table
 
 
 def _weighted_sum(weights, tensors):
@@ -691,7 +736,9 @@ class Network_Multi_Path(nn.Module):
         ratios = self.sample_prun_ratio(mode=mode)
         coef_rows = self._coefficient_rows(alphas, ratios, mode) if _BATCHED_COEFS else None
         # one host read of the whole beta tables instead of one implicit sync per cell (reference :326-328)
-        beta_pos = _positive_table(betas)
+        names = self._arch_names[k]["betas"]
+        beta_pos = _positive_table(betas, (k,) + tuple(getattr(self, n)._version for n in names) + tuple(getattr(self, n).data_ptr() for n in names),
+                                   self.__dict__.setdefault("_beta_pos_cache", {}).setdefault(k, {}))
         # rows handed out by ONE unbind per table: `betas[j][row]` per cell is a select whose backward is a zero-fill + copy + add per cell
         beta_rows = [None] + [b.unbind(0) for b in betas[1:]]
 

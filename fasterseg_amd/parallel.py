@@ -51,6 +51,7 @@ class FlatGradientSync:
         self.handles = {}
         self.stage = torch.empty_like(self.flat, dtype=self.comm_dtype) if (self.comm_dtype is not None and self.world > 1) else None
         self._touched = [False] * len(self.params)
+        self._hidden = None          # indices whose .grad sync() set to None (None: unknown, re-point everything)
         self._index = {id(p): i for i, p in enumerate(self.params)}
         self._hooks = []
         for i, p in enumerate(self.params):
@@ -111,8 +112,17 @@ class FlatGradientSync:
         self.handles = {}
         self.pending = [0] * len(self.buckets)
         self._touched = [False] * len(self.params)
-        for p, v in zip(self.params, self.views):
-            p.grad = v
+        # point every .grad at its slice: only the parameters sync() hid last time (and anything re-homed since) need touching - the
+        # supernet has ~40 k parameters and the step is host-bound (a full loop is ~1 ms of pure Python per step, twice)
+        hidden = self._hidden
+        if hidden is None:
+            for p, v in zip(self.params, self.views):
+                p.grad = v
+        else:
+            params, views = self.params, self.views
+            for i in hidden:
+                params[i].grad = views[i]
+        self._hidden = []
 
     def sync(self):
         """Call after backward: finish the all-reduce of every bucket, average, hide untouched parameters from the
@@ -134,9 +144,10 @@ class FlatGradientSync:
         elif self.world > 1 and self.average:
             self.flat.div_(self.world)
         if hasattr(self.params[0], "register_post_accumulate_grad_hook"):
-            for p, t in zip(self.params, self._touched):
-                if not t:
-                    p.grad = None
+            params = self.params
+            hidden = self._hidden = [i for i, t in enumerate(self._touched) if not t]
+            for i in hidden:
+                params[i].grad = None
 
     def touched_indices(self):
         return [i for i, t in enumerate(self._touched) if t]

@@ -209,6 +209,9 @@ class SupernetStep:
     def _set_phase(self, phase):
         """'w': network weights receive gradients, architecture parameters are frozen; 'a': the opposite.  The reference
         computes both sets in both phases and throws one away (train_search.py:245 optimizer.zero_grad / architect.py:38)."""
+        if getattr(self, "_phase", None) == phase:          # (a pretrain run never leaves "w": 40 k requires_grad_ calls per step otherwise)
+            return
+        self._phase = phase
         for p in self.weights:
             p.requires_grad_(phase == "w")
         for p in self.arch_params:
@@ -412,6 +415,7 @@ class SupernetStep:
             # step: no wgrad / BN-parameter gradient kernels run, the alpha/beta/ratio gradients are unchanged.
             for p in self.weights:
                 p.grad = None
+            self.sync._hidden = None              # every .grad was dropped: the next prepare() re-points all of them
             self._set_phase("a")
             try:
                 loss_arch = self.architect.step(imgs, target, imgs_search, target_search)

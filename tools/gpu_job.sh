@@ -43,6 +43,17 @@ case $job in
       env $env timeout 300 python -W ignore tools/step_time.py c3 20 2>&1 | grep -a STEP_TIME | sed "s/^/$env /" | tee -a $O/r05_switches_c3.txt
     done
     ;;
+  call5)      # round 5: the host side of the C3 step (it is host-bound: call4) - cProfile, and the capture without forks
+    timeout 300 python -W ignore tools/host_profile.py c3 5 > $O/r05_host_profile_c3.txt 2>&1; grep -a -A40 "sorted by tottime" $O/r05_host_profile_c3.txt | cut -c1-180
+    for env in "FS_LAYER_LANES=1 FS_BRANCH_LANES=1" "FS_LAYER_LANES=1 FS_BRANCH_LANES=1 FS_EAGER_LANES=1"; do
+      env $env timeout 300 python -W ignore tools/host_vs_device.py c3 10 2>&1 | grep -a -A3 HOST_VS | sed "s/^/$env /" | tee -a $O/r05_host_vs_device.txt
+    done
+    ;;
+  call6)      # round 5: after the beta-table read left the eager forwards - the capture layouts against each other (host issue vs device)
+    for env in "FS_NONE=1" "FS_LAYER_LANES=2" "FS_LAYER_LANES=2 FS_GROUP_CAPTURE=2" "FS_LAYER_LANES=1 FS_BRANCH_LANES=1" "FS_LAYER_LANES=2 FS_EAGER_LANES=1"; do
+      env $env timeout 300 python -W ignore tools/host_vs_device.py c3 10 2>&1 | grep -a -A3 HOST_VS | grep -v synchronised | sed "s/^/$env /" | tee -a $O/r05_host_vs_device_2.txt
+    done
+    ;;
   tests)      # bash tools/gpu_job.sh tests <pytest args...>
     timeout ${FS_JOB_TIMEOUT:-600} python -W ignore -m pytest "$@" -m gpu -q -x --timeout 300 --durations=8 2>&1 | tail -25 | cut -c1-240
     ;;
