@@ -221,11 +221,15 @@ def _run_tasks(tasks):
         return lane
     for op, x, alpha, ratios, groups in tasks:
         widths = [None, None]
-        coef = op._coefficients(x, alpha, ratios, widths)  # also selects the widths of the five primitives
+        # (the widths are applied to the five primitives' modules only when something reads them there: a launch-program cache miss or
+        # the per-module path - 23 us of attribute stores per MixedOp otherwise, on a host-bound step)
+        coef = op._coefficients(x, alpha, ratios, widths, set_ratio=False)
         prog = None
         if _PROGRAMS and (_CAPTURE_PROGRAMS or not capturing) and op.training and torch.is_grad_enabled():
             with FN.bn_groups(groups):
                 prog = op._program(FN.as_nhwc(x), coef, widths[0], widths[1])
+        if prog is None:
+            op.set_prun_ratio((widths[0], widths[1]))
         group = _GROUP_PROGRAMS and (not capturing or _GROUP_CAPTURE)
         if MIMIC_CAPTURE and not capturing and not _SAMPLING_PASS:
             group = group and bool(_GROUP_CAPTURE)
@@ -332,11 +336,13 @@ class MixedOp(nn.Module):
         for op in self._ops:
             op.set_ratio(ratio)
 
-    def _coefficients(self, x, weights, ratios, widths=None):
-        """Selects the widths (set_prun_ratio) and returns the five coefficients w_k * r_score0 * r_score1 (reference :64-78)."""
+    def _coefficients(self, x, weights, ratios, widths=None, set_ratio=True):
+        """Selects the widths (set_prun_ratio, unless the caller does it when needed) and returns the five coefficients
+        w_k * r_score0 * r_score1 (reference :64-78)."""
         ratio0, r_score0 = _width_and_score(ratios[0], self._width_mult_list)
         ratio1, r_score1 = _width_and_score(ratios[1], self._width_mult_list)
-        self.set_prun_ratio((ratio0, ratio1))
+        if set_ratio:
+            self.set_prun_ratio((ratio0, ratio1))
         if widths is not None:
             widths[:] = [ratio0, ratio1]
         if isinstance(weights, _PreCoef):
@@ -380,6 +386,7 @@ class MixedOp(nn.Module):
         prog = cache.get(key)
         if prog is None or not prog.valid():
             from . import program
+            self.set_prun_ratio((ratio0, ratio1))          # the lowering reads the active widths from the modules
             prog = cache[key] = program.lower_mixed_op(self, tuple(x.shape), x.stride(3), x.dtype, x.device, need_x, need_coef,
                                                        want_w, sink, groups)
         if _SAMPLING_PASS and x.stride(3) == x.shape[1]:

@@ -54,6 +54,12 @@ case $job in
       env $env timeout 300 python -W ignore tools/host_vs_device.py c3 10 2>&1 | grep -a -A3 HOST_VS | grep -v synchronised | sed "s/^/$env /" | tee -a $O/r05_host_vs_device_2.txt
     done
     ;;
+  sweep)      # bash tools/gpu_job.sh sweep <c3|c5> "ENV=.. ENV=.." "ENV=.." ...: host_vs_device of one workload under each environment, one box
+    wl=$1; shift
+    for env in "$@"; do
+      env $env timeout 300 python -W ignore tools/host_vs_device.py $wl 10 2>&1 | grep -a -A3 "HOST_VS" | grep -v synchronised | sed "s/^/$env /" | tee -a $O/r05_sweep_$wl.txt
+    done
+    ;;
   tests)      # bash tools/gpu_job.sh tests <pytest args...>
     timeout ${FS_JOB_TIMEOUT:-600} python -W ignore -m pytest "$@" -m gpu -q -x --timeout 300 --durations=8 2>&1 | tail -25 | cut -c1-240
     ;;

@@ -9,6 +9,31 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from fasterseg_amd import latency_lookup_table, train_step
 which = sys.argv[1] if len(sys.argv) > 1 else "c3"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+if which == "c2":            # the student frame: hipGraph replays back to back
+    from fasterseg_amd import archs, engine
+    net = archs.init_weight(archs.build_derived(1, training=False), seed=12345).cuda().eval()
+    eng = engine.InferenceEngine(net, (1, 3, 1024, 2048), dtype=torch.bfloat16, logits_dtype=torch.float32)
+    eng.input.copy_(torch.randn(1, 3, 1024, 2048, device="cuda"))
+    for _ in range(200):
+        eng.run()
+    torch.cuda.synchronize()
+    n = max(steps, 2000)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        eng.run()
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print("HOST_VS_DEVICE c2: enqueue %.4f ms/frame, done %.4f ms/frame over %d frames (device tail %.2f ms); lanes %s" %
+          ((t1 - t0) / n * 1e3, (t2 - t0) / n * 1e3, n, (t2 - t1) * 1e3, getattr(eng, "graph_lanes", "?")))
+    # one frame at a time: the host cost of ONE replay with an idle queue
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(200):
+        eng.run()
+        torch.cuda.synchronize()
+    print("   one frame at a time (replay + drain): %.4f ms" % ((time.perf_counter() - t0) / 200 * 1e3))
+    sys.exit(0)
 pre = which == "c3"
 b, h, w = (3, 256, 512) if pre else (2, 224, 448)
 st = train_step.SupernetStep(pretrain=pre, lut=None if pre else latency_lookup_table.load_shipped("bf16"), compute_dtype=torch.bfloat16)

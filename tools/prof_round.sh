@@ -47,9 +47,13 @@ if [ $what = all ] || [ $what = pmc ] || [ $what = pmc_c2 ]; then
 fi
 for wl in c3 c4; do
   if [ $what = all ] || [ $what = pmc ] || [ $what = pmc_$wl ]; then
-    F=$(pmc ${wl}f FETCH_SIZE -- python $R/tools/profile_step.py $wl 2)
-    W=$(pmc ${wl}w WRITE_SIZE -- python $R/tools/profile_step.py $wl 2)
-    M=$(pmc ${wl}m SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- python $R/tools/profile_step.py $wl 2)
+    # ONE eager step per pass (no capture warm-ups, no graph replays: under --pmc every dispatch is serialised and a pass over a graphed
+    # run does not fit the GPU budget); the kernels are the ones the timed steps launch (tests/test_measurement_artifacts.py checks the names)
+    export FS_SUPERNET_GRAPHS=0 FS_PROFILE_WARMUP=0
+    F=$(pmc ${wl}f FETCH_SIZE -- python $R/tools/profile_step.py $wl 1)
+    W=$(pmc ${wl}w WRITE_SIZE -- python $R/tools/profile_step.py $wl 1)
+    M=$(pmc ${wl}m SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- python $R/tools/profile_step.py $wl 1)
+    unset FS_SUPERNET_GRAPHS FS_PROFILE_WARMUP
     python $R/tools/pmc_table.py $O/${TAG}_${wl}_pmc.json f=$F w=$W m=$M | head -10
   fi
 done
