@@ -45,6 +45,8 @@ class Architect(object):
             self.grad_sync([p for group in self.model._arch_parameters for p in group])
         for optimizer in self.optimizers:
             optimizer.step()
+        if hasattr(self.model, "note_arch_update"):
+            self.model.note_arch_update()
         return loss + loss_latency
 
     def _backward_step(self, input_valid, target_valid):

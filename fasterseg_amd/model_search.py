@@ -455,6 +455,8 @@ _latency_vectors = {}      # (five LUT latencies, device, dtype) -> device vecto
 _LINEAR_LATENCY = bool(int(os.environ.get("FS_LINEAR_LATENCY", "1")))
 # the MixedOp coefficients of a whole pass in a few batched ops (Network_Multi_Path._coefficient_rows); FS_BATCHED_COEFS=0: per MixedOp
 _BATCHED_COEFS = bool(int(os.environ.get("FS_BATCHED_COEFS", "1")))
+# the host read of the sampled width indices from a side stream (sample_prun_ratio); FS_SAMPLE_STREAM=0: on the launch stream (a drain)
+_SAMPLE_STREAM = bool(int(os.environ.get("FS_SAMPLE_STREAM", "1")))
 _SAMPLED = object()        # stands in for a sampled width in _cell_ratio probes
 _SAMPLING_PASS = False     # the forward in progress draws its widths ("random" / Gumbel "arch_ratio"): its call sites are worth prewarming
 
@@ -641,16 +643,35 @@ class Network_Multi_Path(nn.Module):
             names = self._arch_names[self.arch_idx]["ratios"]
             params = [getattr(self, names[s]) for s in range(3)]
             assert all(p.shape[0] == counts[s] for s, p in enumerate(params))
-            # all slots (scale-major, layer-minor: the reference's draw order) in ONE batch; per-slot views for the per-cell consumers
-            out, ind = gumbel_softmax_rows(F.log_softmax(torch.cat(params), dim=-1))
-            rows = out.unbind(0)
+            # all slots (scale-major, layer-minor: the reference's draw order) in ONE batch; per-slot views for the per-cell consumers.
             # The reference reads `ratio.argmax()` on the host once per MixedOp (model_search.py:64-65): ~230 device syncs per
-            # forward, each draining the launch queue.  Read all sampled indices back in ONE transfer instead.
+            # forward, each draining the launch queue.  Read all sampled indices back in ONE transfer instead - and (round 5) from a
+            # SIDE stream that only waits for the last write of the architecture parameters (note_arch_update), not for everything the
+            # step has queued on the launch stream: the widths are needed on the host to shape the pass, the step is host-bound, and a
+            # drain here left the host idle for ~10 ms per Gumbel pass (profiles/r05_host_vs_device_c5.txt).
             host = None
-            if read_indices and out.is_cuda and not torch.cuda.is_current_stream_capturing():
-                host = ind.tolist()
-            elif read_indices and not out.is_cuda:
-                host = ind.tolist()
+            on_gpu = params[0].is_cuda
+            if read_indices and on_gpu and not torch.cuda.is_current_stream_capturing() and _SAMPLE_STREAM:
+                main = torch.cuda.current_stream()
+                side = self.__dict__.get("_sample_stream")
+                if side is None or side.device != params[0].device:
+                    side = self.__dict__["_sample_stream"] = torch.cuda.Stream(device=params[0].device)
+                upd = self.__dict__.get("_arch_update")
+                if upd is not None and upd[1] == self._arch_versions():
+                    side.wait_event(upd[0])             # the parameters' last writer
+                else:
+                    side.wait_stream(main)              # written by something that did not say so: behind everything queued (a drain)
+                with torch.cuda.stream(side):
+                    out, ind = gumbel_softmax_rows(F.log_softmax(torch.cat(params), dim=-1))
+                    host = ind.tolist()                 # waits for `side` only
+                main.wait_stream(side)
+                out.record_stream(main)
+                ind.record_stream(main)
+            else:
+                out, ind = gumbel_softmax_rows(F.log_softmax(torch.cat(params), dim=-1))
+                if read_indices and not (on_gpu and torch.cuda.is_current_stream_capturing()):
+                    host = ind.tolist()
+            rows = out.unbind(0)
             ratios, n = _SampledRatios(), 0
             for s in range(3):
                 scale = []
@@ -668,6 +689,18 @@ class Network_Multi_Path(nn.Module):
             return [[np.random.choice(self._width_mult_list) for _ in range(counts[s])] for s in range(3)]
         w = self._width_mult_list[0] if mode == "min" else self._width_mult_list[-1]
         return [[w] * counts[s] for s in range(3)]
+
+    def _arch_versions(self):
+        return tuple(p._version for group in self._arch_parameters for p in group) + tuple(p.data_ptr() for p in self._arch_parameters[0][:1])
+
+    def note_arch_update(self):
+        """Call right after the architecture parameters were written on the current stream (the architect's optimizer step): the next
+        host read of sampled widths waits for THIS point of the stream instead of for everything queued behind it."""
+        p = self._arch_parameters[0][0]
+        if p.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+            self.__dict__["_arch_update"] = (ev, self._arch_versions())
 
     def _arch_tensors(self, alpha=True, beta=True):
         names = self._arch_names[self.arch_idx]

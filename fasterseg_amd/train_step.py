@@ -96,6 +96,10 @@ class StudentDistillStep:
         return loss.detach()
 
 
+import os as _os
+_FAST_PHASE = bool(int(_os.environ.get("FS_FAST_PHASE", "1")))      # 0: flip requires_grad of all ~40 k weights at every phase change
+
+
 class SearchConfig:
     """The fields of search/config_search.py the steps read (:57-59,78-107)."""
     lr = 2e-2
@@ -167,6 +171,7 @@ class SupernetStep:
         self._prewarmed = not bool(int(os.environ.get("FS_PREWARM_PROGRAMS", "1")))
         self.gc_freeze = bool(int(os.environ.get("FS_GC_FREEZE", "1"))) if gc_freeze is None else bool(gc_freeze)
         self.last_arch_ce = None
+        self._phase_weights = None
         self.architect = None
         if not pretrain:
             if lut is not None:
@@ -212,7 +217,22 @@ class SupernetStep:
         if getattr(self, "_phase", None) == phase:          # (a pretrain run never leaves "w": 40 k requires_grad_ calls per step otherwise)
             return
         self._phase = phase
-        for p in self.weights:
+        weights = self.weights
+        if self.use_graphs and getattr(self, "_capture_done", False) and _FAST_PHASE:
+            # A search iteration flips the phase twice: 80 k requires_grad_ calls = ~16 ms of a host-bound 160 ms step.  Once the
+            # fixed-width passes are captured, the flags are only read (a) by autograd for the modules that run module by module in the
+            # eager passes - stem, refine, heads - and (b) by MixedOp._program, which asks ONE weight per MixedOp whether the launch
+            # programs should write weight gradients.  Those ~600 tensors are flipped; the other cell weights stay trainable (they are
+            # only ever touched through the launch programs, which take their decision from (b)).
+            if self._phase_weights is None:
+                for p in self.weights:                       # leave the full set coherent before the subset takes over
+                    p.requires_grad_(True)
+                from . import model_search
+                probe = {id(m._ops[1].conv1.weight) for m in self.model.modules() if isinstance(m, model_search.MixedOp)}
+                cells = {id(p) for p in self.model.cells.parameters()}
+                self._phase_weights = [p for p in self.weights if id(p) in probe or id(p) not in cells]
+            weights = self._phase_weights
+        for p in weights:
             p.requires_grad_(phase == "w")
         for p in self.arch_params:
             p.requires_grad_(phase == "a")
@@ -290,6 +310,7 @@ class SupernetStep:
                     self.graphs[(phase, spec)] = self._capture_pass(phase, spec, side)
         self.model.arch_idx, self.model.prun_mode = state
         torch.cuda.synchronize()
+        self._capture_done = True             # from here on the phase flips touch the ~600 tensors that are still consulted (_set_phase)
 
     def _phase_loss(self, phase, imgs, target):
         """All passes of `_loss(imgs, target)` with their backward; gradients accumulate pass by pass (d(sum)/dp = sum d/dp)."""
@@ -358,6 +379,7 @@ class SupernetStep:
                 self.architect.grad_sync(self.arch_params)
             for optimizer in self.architect.optimizers:
                 optimizer.step()
+            self.model.note_arch_update()
         self._set_phase("w")
         self.sync.prepare(passes=len(self._specs()))
         loss = self._phase_loss("w", imgs, target)

@@ -132,3 +132,63 @@ def test_r04_census_families_agree_with_the_profiler_tables_of_the_timed_steps(k
                           ("conv_wgrad", ("wgrad_kernel", "wgrad_group_kernel"))):
         ms = sum(prof.get(k, 0.0) for k in kernels)
         assert abs(fam[name]["ms_per_step"] / ms - 1.0) <= 0.06, (key, name, fam[name]["ms_per_step"], ms)
+
+
+# ---- round 5: the line carries the fp32 leg of C2, a swept CPU baseline, measured traffic for every workload, and the post-timed check ----
+def _bench_r05():
+    line, detail = os.path.join(PROFILES, "r05_bench_default.json"), os.path.join(PROFILES, "r05_bench_default_detail.json")
+    if not (os.path.exists(line) and os.path.exists(detail)):
+        pytest.skip("no committed round-5 bench line")
+    text = [l for l in open(line) if l.startswith('{"metric"')][-1]
+    return text, json.loads(text), json.load(open(detail))
+
+
+def test_r05_bench_line_closes_the_measurement_gaps_of_round_4():
+    """(a) `traffic` non-null for the headline, (b) cpu_baseline = the oracle's best over a thread sweep with its count
+    (C2 near 4-5 fps, not 0.8 on 128 threads), (c) C2's fp32 leg - north_star's ">= 163 fps, logits within 1e-3" - in the driver's line."""
+    text, d, detail = _bench_r05()
+    assert len(text.strip()) < 4096
+    assert d["parity"]["pass"] and d["n_gpus"] == 1 and d["unit"] == "frames/s" and d["dtype"] == "bf16"
+    assert d["roofline"]["traffic"] is not None and d["roofline"]["traffic"] > 0
+    assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-3
+    assert d["fp32"]["max_abs_err"] <= 1e-3 and d["fp32"]["value"] >= 163.0 and d["fp32"]["unit"] == "frames/s"
+    cpu = d["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["cores"] <= 64 and cpu["value"] >= 2.0, cpu          # 0.82 fps on 128 threads in round 4
+    assert "threads swept" in detail["C2_student_infer"]["cpu_baseline"]["sample"]
+    for key in ("C3_supernet_pretrain", "C4_student_train", "C5_supernet_search"):
+        w = d["workloads"][key]
+        assert w["parity"]["pass"] and w["parity"]["rel_err"] <= 1e-2, key
+        assert w["ms_per_step_fp32"] > w["ms_per_step"] > 0 and w["cpu_baseline"]["cores"] <= 64, key
+    for key in ("C3_supernet_pretrain", "C5_supernet_search"):
+        chk = detail[key]["post_timed_check"]
+        assert chk["pass"] and chk["grads_finite"] and chk["weights_finite"] and chk["rel_change"] <= 0.25, (key, chk)
+        assert d["workloads"][key]["parity"]["after_timed"] is True
+
+
+@pytest.mark.parametrize("key,table", [("C3_supernet_pretrain", "r05_c3_supernet_pretrain_bf16_kernel_stats.csv"),
+                                       ("C4_student_train", "r05_c4_student_train_bf16_kernel_stats.csv")])
+def test_r05_census_families_agree_with_the_profiler_tables_of_the_timed_steps(key, table):
+    _, _, detail = _bench_r05()
+    path = os.path.join(PROFILES, table)
+    if not os.path.exists(path):
+        pytest.skip("no profiler table")
+    prof = {}
+    for r in csv.DictReader(open(path)):
+        prof[_short(r["Name"])] = prof.get(_short(r["Name"]), 0.0) + float(r["MsPerStep"])
+    fam = detail[key]["kernel_families"]
+    for name, kernels in (("conv_igemm (fwd + dgrad)", ("conv_igemm_kernel", "conv_igemm2_kernel", "conv_igemm2_group_kernel", "splitk_reduce_kernel")),
+                          ("conv_wgrad", ("wgrad_kernel", "wgrad_group_kernel"))):
+        ms = sum(prof.get(k, 0.0) for k in kernels)
+        assert abs(fam[name]["ms_per_step"] / ms - 1.0) <= 0.08, (key, name, fam[name]["ms_per_step"], ms)
+
+
+def test_r05_step_traffic_tables_cover_the_kernels_the_steps_launch():
+    """`roofline.traffic` of a train step is quoted from profiles/r05_<workload>_pmc.json only when that table was taken with the kernels the
+    census step launches (bench.step_traffic); the committed tables must do so for C3 (and C5, which launches the same kernels)."""
+    import bench
+    _, d, detail = _bench_r05()
+    if not os.path.exists(os.path.join(PROFILES, "r05_c3_pmc.json")):
+        pytest.skip("no round-5 PMC table")
+    fam = bench.STEP_FAMILY_KERNELS["conv_igemm (fwd + dgrad)"]
+    launched = detail["C3_supernet_pretrain"]["kernels_in_step"]
+    assert bench.step_traffic("c3", fam, launched) > 1e5

@@ -60,6 +60,12 @@ case $job in
       env $env timeout 300 python -W ignore tools/host_vs_device.py $wl 10 2>&1 | grep -a -A3 "HOST_VS" | grep -v synchronised | sed "s/^/$env /" | tee -a $O/r05_sweep_$wl.txt
     done
     ;;
+  call9)      # round 5: supernet tests after the host-side changes, then step times of C3 / C5 and the C2 frame's host share
+    timeout 900 python -W ignore -m pytest tests/test_train_steps_gpu.py tests/test_program_group_gpu.py tests/test_supernet.py tests/test_train_parity_gpu.py \
+        -m gpu -q -x --timeout 600 --durations=4 2>&1 | grep -v "^$" | tail -12 | cut -c1-250
+    for wl in c3 c5 c2; do timeout 400 python -W ignore tools/host_vs_device.py $wl 10 2>&1 | grep -a -A3 "HOST_VS" | grep -v synchronised | tee -a $O/r05_host_vs_device_3.txt; done
+    for wl in c3 c5; do timeout 400 python -W ignore tools/step_time.py $wl 20 2>&1 | grep -a STEP_TIME | tee -a $O/r05_step_times.txt; done
+    ;;
   tests)      # bash tools/gpu_job.sh tests <pytest args...>
     timeout ${FS_JOB_TIMEOUT:-600} python -W ignore -m pytest "$@" -m gpu -q -x --timeout 300 --durations=8 2>&1 | tail -25 | cut -c1-240
     ;;

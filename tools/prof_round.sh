@@ -2,7 +2,7 @@
 # A round's evidence on one MI355X (through gpurun from the repo root): rocprofv3 kernel tables of the C2 frame (plan-order trace) and of
 # the C3 / C4 / C5 steps, PMC passes (HBM traffic, MFMA busy) for the C2 frame and the C3 / C4 steps.  Everything lands in gpurun_out/ as
 # <tag>_*; the summaries are copied to profiles/ afterwards.  (One script for every round: rounds 2-4 had a copy each.)
-# Usage: bash tools/prof_round.sh [c2|steps|pmc_c2|pmc_c3|pmc_c4|pmc|all] [tag, default r05]
+# Usage: bash tools/prof_round.sh [c2|steps|pmc_c2|pmc_c3|pmc_c5|pmc_c4|pmc|all] [tag, default r05]
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
@@ -45,15 +45,19 @@ if [ $what = all ] || [ $what = pmc ] || [ $what = pmc_c2 ]; then
   python $R/tools/pmc_table.py $O/${TAG}_c2_pmc.json f=$F w=$W m=$M | head -12
   python $R/tools/pmc_frame.py $O/${TAG}_c2_plan_bf16.json $O/${TAG}_c2_pmc_frame.json fetch=$F write=$W mfma=$M | head -12
 fi
-for wl in c3 c4; do
+for wl in c3 c5 c4; do
   if [ $what = all ] || [ $what = pmc ] || [ $what = pmc_$wl ]; then
     # ONE eager step per pass (no capture warm-ups, no graph replays: under --pmc every dispatch is serialised and a pass over a graphed
     # run does not fit the GPU budget); the kernels are the ones the timed steps launch (tests/test_measurement_artifacts.py checks the names)
     export FS_SUPERNET_GRAPHS=0 FS_PROFILE_WARMUP=0
     F=$(pmc ${wl}f FETCH_SIZE -- python $R/tools/profile_step.py $wl 1)
     W=$(pmc ${wl}w WRITE_SIZE -- python $R/tools/profile_step.py $wl 1)
-    M=$(pmc ${wl}m SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- python $R/tools/profile_step.py $wl 1)
+    if [ $wl = c3 ]; then            # MFMA busy cycles: one workload is enough to cross-check the FLOP-derived fractions
+      M=$(pmc ${wl}m SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- python $R/tools/profile_step.py $wl 1)
+      python $R/tools/pmc_table.py $O/${TAG}_${wl}_pmc.json f=$F w=$W m=$M | head -10
+    else
+      python $R/tools/pmc_table.py $O/${TAG}_${wl}_pmc.json f=$F w=$W | head -8
+    fi
     unset FS_SUPERNET_GRAPHS FS_PROFILE_WARMUP
-    python $R/tools/pmc_table.py $O/${TAG}_${wl}_pmc.json f=$F w=$W m=$M | head -10
   fi
 done
