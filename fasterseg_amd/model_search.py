@@ -30,7 +30,13 @@ from .seg_oprs import Head
 def sample_gumbel(shape, eps=1e-20, device=None):
     U = torch.rand(shape)                       # host RNG like the reference (model_search.py:15-17): ranks stay in sync
     if device is not None:
-        U = U.to(device)
+        if torch.device(device).type == "cuda":
+            # a blocking `.to(device)` of pageable memory ends in a synchronisation of the launch stream - a device drain per call, 28 ms
+            # of a host-bound C5 iteration (profiles/r05_host_profile_c5.txt).  Pinned + non_blocking: the copy is just another enqueue
+            # (the caching host allocator keeps the staging block alive until the stream has consumed it).
+            U = U.pin_memory().to(device, non_blocking=True)
+        else:
+            U = U.to(device)
     return -torch.log(-torch.log(U + eps) + eps)
 
 

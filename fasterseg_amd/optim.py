@@ -119,7 +119,9 @@ class FlatSGD:
             ever = self._ever_touched or [False] * len(touched)
             touched = self._ever_touched = [a or b for a, b in zip(ever, touched)]
         if touched != self._last_touched:
-            self.touched_dev.copy_(torch.tensor(touched, dtype=torch.uint8))
+            # pinned + non_blocking: a blocking copy from pageable memory synchronises the launch stream, i.e. the host would wait here for
+            # the whole backward of the step instead of going on to issue the next one (the table changes every step under sampled widths)
+            self.touched_dev.copy_(torch.tensor(touched, dtype=torch.uint8).pin_memory(), non_blocking=True)
             self._last_touched = list(touched)
         self._launch(scale)
         FN.bump_weights_epoch()            # parameters changed behind autograd's version counters: drop packed copies

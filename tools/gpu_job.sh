@@ -66,6 +66,12 @@ case $job in
     for wl in c3 c5 c2; do timeout 400 python -W ignore tools/host_vs_device.py $wl 10 2>&1 | grep -a -A3 "HOST_VS" | grep -v synchronised | tee -a $O/r05_host_vs_device_3.txt; done
     for wl in c3 c5; do timeout 400 python -W ignore tools/step_time.py $wl 20 2>&1 | grep -a STEP_TIME | tee -a $O/r05_step_times.txt; done
     ;;
+  call10)     # round 5: the search step after the side-stream width read and the fast phase flips
+    timeout 900 python -W ignore -m pytest tests/test_train_steps_gpu.py tests/test_parallel_gpu.py tests/test_train_parity_gpu.py tests/test_supernet.py \
+        -m gpu -q -x --timeout 600 -k "search or arch or latency or supernet" --durations=4 2>&1 | grep -v "^$" | tail -12 | cut -c1-250
+    timeout 400 python -W ignore tools/host_vs_device.py c5 10 2>&1 | grep -a -A3 "HOST_VS" | grep -v synchronised | tee -a $O/r05_host_vs_device_3.txt
+    timeout 400 python -W ignore tools/host_profile.py c5 5 > $O/r05_host_profile_c5.txt 2>&1; grep -a -A28 "sorted by tottime" $O/r05_host_profile_c5.txt | cut -c1-160
+    ;;
   tests)      # bash tools/gpu_job.sh tests <pytest args...>
     timeout ${FS_JOB_TIMEOUT:-600} python -W ignore -m pytest "$@" -m gpu -q -x --timeout 300 --durations=8 2>&1 | tail -25 | cut -c1-240
     ;;
