@@ -200,8 +200,13 @@ def step_traffic(workload, kernels, launched=None):
             covered = sum(v["launches"] for k, v in launched.items() if k in kernels and k in d)
             if ran and covered < 0.9 * ran:
                 return None
-        n = sum(d[k]["launches"] for k in kernels if k in d)
-        b = sum(d[k]["launches"] * (d[k].get("hbm_read_bytes_per_launch", 0) + d[k].get("hbm_write_bytes_per_launch", 0)) for k in kernels if k in d)
+        per = lambda k: d[k].get("hbm_read_bytes_per_launch", 0) + d[k].get("hbm_write_bytes_per_launch", 0)
+        if launched:      # the table's per-launch bytes of every kernel, weighted by what THIS step launches (the PMC pass is an all-eager
+            n = sum(v["launches"] for k, v in launched.items() if k in kernels and k in d)      # step: more grouped launches than a timed one)
+            b = sum(v["launches"] * per(k) for k, v in launched.items() if k in kernels and k in d)
+        else:
+            n = sum(d[k]["launches"] for k in kernels if k in d)
+            b = sum(d[k]["launches"] * per(k) for k in kernels if k in d)
         return int(b / n) if n else None
     except Exception:
         return None

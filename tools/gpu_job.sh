@@ -72,6 +72,13 @@ case $job in
     timeout 400 python -W ignore tools/host_vs_device.py c5 10 2>&1 | grep -a -A3 "HOST_VS" | grep -v synchronised | tee -a $O/r05_host_vs_device_3.txt
     timeout 400 python -W ignore tools/host_profile.py c5 5 > $O/r05_host_profile_c5.txt 2>&1; grep -a -A28 "sorted by tottime" $O/r05_host_profile_c5.txt | cut -c1-160
     ;;
+  final)      # the round's evidence on ONE box: whole GPU suite, the default bench line, rocprofv3 kernel tables of the timed steps
+    tag=${1:-r05}
+    timeout 1500 python -W ignore -m pytest tests -m gpu -q --timeout 900 --durations=10 > $O/${tag}_gpu_tests.log 2>&1; echo "pytest rc=$?"; tail -4 $O/${tag}_gpu_tests.log | cut -c1-200
+    timeout 900 python -W ignore bench.py --steps 20 --warmup 5 --detail $O/${tag}_bench_default_detail.json > $O/${tag}_bench_default.json 2> $O/${tag}_bench_default.err; echo "bench rc=$?"
+    tail -c 3200 $O/${tag}_bench_default.json; tail -2 $O/${tag}_bench_default.err
+    bash tools/prof_round.sh steps $tag 2>&1 | tail -6
+    ;;
   tests)      # bash tools/gpu_job.sh tests <pytest args...>
     timeout ${FS_JOB_TIMEOUT:-600} python -W ignore -m pytest "$@" -m gpu -q -x --timeout 300 --durations=8 2>&1 | tail -25 | cut -c1-240
     ;;
