@@ -752,6 +752,21 @@ def device_clocks():
         return {"error": repr(e)[:120]}
 
 
+def host_info():
+    info = {"logical_cpus": os.cpu_count(), "torch_threads": torch.get_num_threads()}
+    try:
+        with open("/proc/cpuinfo") as f:
+            models = [l.split(":", 1)[1].strip() for l in f if l.startswith("model name")]
+        info["cpu_model"] = models[0] if models else None
+        mhz = [float(l.split(":", 1)[1]) for l in open("/proc/cpuinfo") if l.startswith("cpu MHz")]
+        if mhz:
+            info["cpu_mhz_max_now"] = max(mhz)
+        info["loadavg"] = open("/proc/loadavg").read().split()[:3]
+    except Exception as e:
+        info["error"] = repr(e)[:80]
+    return info
+
+
 def main():
     args = parse()
     if not torch.cuda.is_available():
@@ -762,7 +777,10 @@ def main():
                "c5": ("C5_supernet_search", lambda: run_supernet(args, world, rank, backend, False))}
     train = {}
     clocks = {}
-    order = os.environ.get("FS_BENCH_ORDER", "c2,c4,c3,c5").split(",")
+    # The supernet steps are HOST-bound: run them before the student train step, whose teardown leaves the
+    # process ~15 % slower at issuing launches (measured on one box: C3 83.9 ms first / 87.3 ms after C2 / 101.6 ms after C2 + C4 with its
+    # CPU-oracle and fp32 legs; profiles/r05_bench_order.txt).  C4 itself is device-bound and does not care.  FS_BENCH_ORDER overrides.
+    order = os.environ.get("FS_BENCH_ORDER", "c2,c3,c5,c4").split(",")
     c2 = None
 
     def clocked(name, fn):
@@ -786,6 +804,8 @@ def main():
         line, detail = build_line(c2, train, world, args.steps_requested, args.dtype, args.detail)
         detail["clocks"] = clocks
         detail["argv"] = sys.argv[1:]
+        detail["order"] = order
+        detail["host"] = host_info()          # the supernet steps are host-bound: the box's CPU is part of the result
         try:
             with open(args.detail, "w") as f:
                 json.dump(detail, f, indent=1, default=str)
