@@ -636,6 +636,13 @@ def scale_accumulate(acc, x, coef):
     return _ScaleAccumulate.apply(acc, x, coef)
 
 
+def _own(grad, for_leaf):
+    """Coefficient gradients are slices of the step's zero arena (kernels.zero_pool: valid until the next step clears it).  Every
+    consumer inside the product copies or accumulates them (the coefficients are computed tensors: unbind / select / mul backward) -
+    but an AccumulateGrad node of a LEAF with no .grad yet may adopt the incoming tensor as .grad, which must then own its memory."""
+    return grad.clone() if for_leaf and grad is not None else grad
+
+
 class _WeightedSum(torch.autograd.Function):
     """out = sum_k coef[k] * x_k in one launch (MixedOp's five primitives, the beta mixing of two cell inputs); coef is a
     contiguous fp32 device vector.  Backward: one launch for all dx_k, one for all d coef[k] (only when coef needs it)."""
@@ -647,6 +654,7 @@ class _WeightedSum(torch.autograd.Function):
             c = c.float().contiguous()
         out = K.weighted_sum(xs, c)
         ctx.n = len(xs)
+        ctx.coef_leaf = coef.is_leaf          # (a leaf's AccumulateGrad may adopt the gradient tensor itself: see _own)
         ctx.save_for_backward(c, *(xs if ctx.needs_input_grad[0] else ()))
         return out
 
@@ -657,7 +665,7 @@ class _WeightedSum(torch.autograd.Function):
         gxs = K.weighted_sum_bwd(dy, c, ctx.needs_input_grad[1:])
         gc = None
         if ctx.needs_input_grad[0]:
-            gc = K.weighted_sum_dots(dy, [as_nhwc(t, dy.dtype) for t in ctx.saved_tensors[1:]])
+            gc = _own(K.weighted_sum_dots(dy, [as_nhwc(t, dy.dtype) for t in ctx.saved_tensors[1:]]), ctx.coef_leaf)
         return (gc,) + tuple(gxs)
 
 
@@ -673,6 +681,7 @@ class _PairMerge(torch.autograd.Function):
             c = c.float().contiguous()
         n = x.shape[0] // 2
         out = K.weighted_sum([x[:n], x[n:]], c)
+        ctx.coef_leaf = coef.is_leaf
         ctx.save_for_backward(c, x)
         return out
 
@@ -686,7 +695,7 @@ class _PairMerge(torch.autograd.Function):
             gx = K.empty_nhwc(*x.shape, x.dtype, x.device)
             K.weighted_sum_bwd(dy, c, (True, True), outs=[gx[:n], gx[n:]])
         if ctx.needs_input_grad[0]:
-            gc = K.weighted_sum_dots(dy, [x[:n], x[n:]])
+            gc = _own(K.weighted_sum_dots(dy, [x[:n], x[n:]]), ctx.coef_leaf)
         return gc, gx
 
 
@@ -748,6 +757,7 @@ class _MixedOpProgram(torch.autograd.Function):
                  (None, x.data_ptr(), c.data_ptr(), out.data_ptr(), save.data_ptr(), None, None, None, tmp.data_ptr(),
                   K.stream_workspace(dev)[0], zf.data_ptr() if zf is not None else None, None))
         ctx.prog = prog
+        ctx.coef_leaf = coef.is_leaf
         ctx.save_for_backward(x, c, save)
         return out
 
@@ -774,7 +784,7 @@ class _MixedOpProgram(torch.autograd.Function):
                 sink.touched(p)
         gc = None
         if prog.need_coef:
-            gc = zb[prog.gcoef_off // 4:prog.gcoef_off // 4 + c.numel()].reshape(c.shape)
+            gc = _own(zb[prog.gcoef_off // 4:prog.gcoef_off // 4 + c.numel()].reshape(c.shape), ctx.coef_leaf)
         return gx, gc, None
 
 
@@ -812,6 +822,7 @@ class _MixedOpProgramGroup(torch.autograd.Function):
         program.run_group(progs, False, slots)
         del scratch
         ctx.progs = progs
+        ctx.coef_leaf = [tensors[2 * i + 1].is_leaf for i in range(k)]
         ctx.save_for_backward(*saved)
         return tuple(outs)
 
@@ -848,7 +859,7 @@ class _MixedOpProgramGroup(torch.autograd.Function):
             gc = None
             if prog.need_coef:
                 c = saved[3 * i + 1]
-                gc = tmps[i][2][prog.gcoef_off // 4:prog.gcoef_off // 4 + c.numel()].reshape(c.shape)
+                gc = _own(tmps[i][2][prog.gcoef_off // 4:prog.gcoef_off // 4 + c.numel()].reshape(c.shape), ctx.coef_leaf[i])
             grads += [gxs[i], gc]
         return tuple(grads)
 
