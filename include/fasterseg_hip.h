@@ -88,7 +88,7 @@ typedef struct fs_resize_desc {
 const char* fs_last_error(void);
 /* ABI revision of this header; fs_version() returns the one the library was built from.  Bindings check both this and
  * fs_struct_size() when they load the library (fasterseg_amd/_lib.py) - a stale .so must not be used silently. */
-#define FS_ABI_VERSION 207
+#define FS_ABI_VERSION 208
 int fs_version(void);
 /* Bit-reproducible mode (default off; FS_DETERMINISTIC=1 in the environment turns it on at load): every cross-block reduction that
  * otherwise uses float atomics - the pixel slabs of fs_conv2d_wgrad_ws, BatchNorm statistics and parameter gradients of maps above
@@ -494,7 +494,11 @@ enum {
 };
 fs_status fs_exec_program(void* stream, const long long* words, long long n_words, const unsigned char* blob,
                           void* const* slots, int n_slots);
-/* Multi-stream form: every op word carries its stream index in bits 16 and up (`op | lane << 16`); the inference engine
+/* Op word of every command: bits 0-15 the op code, bits 16-39 the stream lane (multi-stream form), bit 40 JOIN (ABI 208): this command
+ * is independent of the NEXT one, which has the same op.  A run of joined FS_OP_CONV_FWD / FS_OP_WGRAD_STRIDED commands goes out as one
+ * grouped launch (the two 1x1 stride-2 convolutions of FactorizedReduce, search/operations.py:521-526, their weight gradients and their
+ * data gradients); joined commands of other ops are simply issued one after the other.  The last command must not carry the bit.
+ * Multi-stream form: every op word carries its stream index in bits 16 and up (`op | lane << 16`); the inference engine
  * issues a whole frame (71 launches on 3 streams with event edges) through one call instead of a hipGraph launch, whose
  * host cost per kernel node is higher.  Events are created / destroyed with fs_event_create / fs_event_destroy. */
 fs_status fs_exec_program_streams(void* const* streams, int n_streams, const long long* words, long long n_words,
