@@ -506,15 +506,14 @@ def _positive_table(betas, key=None, cache=None):
     by > 87, i.e. after ~3e5 Adam steps of 3e-4 in one direction, so the optimistic table is the exact one in any run one can afford - and
     if a check ever fails, this function says so and falls back to the blocking read for good."""
     live = betas[1:]
-    if live and live[0].is_cuda and torch.cuda.is_current_stream_capturing():
+    on_gpu = bool(live) and live[0].is_cuda
+    if on_gpu and torch.cuda.is_current_stream_capturing():
         return [None] + [[[True, True]] * b.shape[0] for b in live]
-    if cache is None or key is None or not (live and live[0].is_cuda):
-        return [None] + [(b > 0).tolist() for b in live]
-    if cache.get("blocking"):
+    if cache is None or key is None or not live or cache.get("blocking"):
         return [None] + [(b > 0).tolist() for b in live]
     # examine finished asynchronous checks (never blocks)
     pending = cache.setdefault("pending", [])
-    while pending and pending[0][0].query():
+    while pending and (pending[0][0] is None or pending[0][0].query()):
         _, flag = pending.pop(0)
         if not bool(flag.item()):                   # (host tensor: no device access)
             import warnings
@@ -527,11 +526,14 @@ def _positive_table(betas, key=None, cache=None):
     shapes = tuple(b.shape[0] for b in live)
     if hit is not None and hit[2] == shapes and len(pending) < 8:
         # new parameter values: keep the table, verify the new values behind the launch stream
-        flag = torch.empty((), dtype=torch.bool).pin_memory()
         ok = torch.stack([(b > 0).all() for b in live]).all()
-        flag.copy_(ok, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
+        if on_gpu:
+            flag = torch.empty((), dtype=torch.bool).pin_memory()
+            flag.copy_(ok, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        else:                                       # (host tensors: the check is complete as soon as it is made; unit tests drive this path)
+            flag, ev = ok.clone(), None
         pending.append((ev, flag))
         cache["table"] = (key, hit[1], shapes)
         return hit[1]
@@ -783,8 +785,9 @@ class Network_Multi_Path(nn.Module):
         coef_rows = self._coefficient_rows(alphas, ratios, mode) if _BATCHED_COEFS else None
         # one host read of the whole beta tables instead of one implicit sync per cell (reference :326-328)
         names = self._arch_names[k]["betas"]
+        on_gpu = betas[1].is_cuda          # (host tensors: the plain read costs nothing and is exact, as in the reference)
         beta_pos = _positive_table(betas, (k,) + tuple(getattr(self, n)._version for n in names) + tuple(getattr(self, n).data_ptr() for n in names),
-                                   self.__dict__.setdefault("_beta_pos_cache", {}).setdefault(k, {}))
+                                   self.__dict__.setdefault("_beta_pos_cache", {}).setdefault(k, {}) if on_gpu else None)
         # rows handed out by ONE unbind per table: `betas[j][row]` per cell is a select whose backward is a zero-fill + copy + add per cell
         beta_rows = [None] + [b.unbind(0) for b in betas[1:]]
 

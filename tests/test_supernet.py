@@ -243,3 +243,34 @@ def test_supernet_loss_and_gradients(mode):
             pname = key[len("%s_f64/g/" % mode):].split("@")[0]
             rel = _rel_l2(params[pname].grad, store, "%s_f64/g/%s" % (mode, pname))
             assert rel < 5e-2, (key, rel)
+
+
+def test_beta_table_cache_reads_once_per_value_and_catches_a_zero():
+    """model_search._positive_table (round 5): the `betas > 0` table is read back once per VALUE of the beta parameters; when they change, the
+    previous table is used while the new values are checked asynchronously, and a check that finds a 0 switches the blocking read back on.
+    Driven here with host tensors (the device path differs only in the pinned flag + event behind which the check completes)."""
+    import warnings
+    from fasterseg_amd import model_search
+    b1 = torch.softmax(torch.randn(3, 2), -1)
+    b2 = torch.softmax(torch.randn(2, 2), -1)
+    cache = {}
+    t0 = model_search._positive_table([None, b1, b2], key=("v", 0), cache=cache)
+    assert t0 == [None, [[True, True]] * 3, [[True, True]] * 2] and cache["table"][0] == ("v", 0)
+    # same key: served from the cache, whatever the tensors now hold
+    zero = torch.tensor([[1.0, 0.0]] * 3)
+    assert model_search._positive_table([None, zero, b2], key=("v", 0), cache=cache) is t0
+    # new key, still positive: the old table, one pending check that passes at the next call
+    t1 = model_search._positive_table([None, b1 * 0.5, b2], key=("v", 1), cache=cache)
+    assert t1 is t0 and len(cache["pending"]) == 1
+    assert model_search._positive_table([None, b1 * 0.5, b2], key=("v", 1), cache=cache) is t0 and not cache["pending"] and not cache.get("blocking")
+    # new key with a zero: optimistic answer now, caught at the next call, exact (blocking) answers from then on
+    t2 = model_search._positive_table([None, zero, b2], key=("v", 2), cache=cache)
+    assert t2 is t0 and len(cache["pending"]) == 1
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        t3 = model_search._positive_table([None, zero, b2], key=("v", 2), cache=cache)
+    assert cache["blocking"] and any("beta reached 0" in str(x.message) for x in w)
+    assert t3 == [None, [[True, False]] * 3, [[True, True]] * 2]
+    assert model_search._positive_table([None, b1, b2], key=("v", 3), cache=cache) == t0          # blocking mode: exact every time
+    # without a cache (host tensors in the model, or no key): the plain read
+    assert model_search._positive_table([None, zero, b2]) == t3
