@@ -120,3 +120,27 @@ def test_library_reports_the_abi_the_bindings_expect():
     for which, struct in enumerate((_lib.ConvDesc, _lib.ResizeDesc, _lib.ZoomDesc, _lib.SgdTensor)):
         assert h.fs_struct_size(which) == __import__("ctypes").sizeof(struct)
     assert h.fs_struct_size(99) == -1
+
+
+def test_measurement_scripts_parse_and_probes_are_not_in_the_product_build():
+    """Round 5 hygiene: one GPU job script and one profiling script (shell syntax checked here); the product library
+    carries no measurement-only conv_igemm2 instantiation (ablation builds ABL 1-4, 6- and 8-stage rings); no built probe is tracked."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for script in ("tools/gpu_job.sh", "tools/prof_round.sh", "tools/prof_step.sh"):
+        r = subprocess.run(["bash", "-n", os.path.join(root, script)], capture_output=True, text=True)
+        assert r.returncode == 0, (script, r.stderr)
+    assert not [f for f in os.listdir(os.path.join(root, "tools")) if f.startswith("gpu_job_r0") or f.startswith("prof_r0")]
+    src = open(os.path.join(root, "fasterseg_amd", "csrc", "conv_igemm2.hip")).read()
+    guarded = src[src.index("#ifdef FS_BUILD_PROBES"):]
+    assert "conv_igemm2_kernel<T, 2, 2, 1, 1, 1, 4, 1>" in guarded[:guarded.index("#endif")]           # the ablations live inside the guard
+    assert "conv_igemm2_kernel<T, 2, 2, 1, 1, 1, 4, 1>" not in src[:src.index("#ifdef FS_BUILD_PROBES")]
+    lib = os.path.join(root, "fasterseg_amd", "libfasterseg_hip.so")
+    if os.path.exists(lib):
+        syms = subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, text=True).stdout
+        # mangled names end in the last two template arguments <..., NSTAGE, ABL>: the product build has 3- / 4-stage rings with ABL = 0 only
+        tails = [re.search(r"Li(\d)ELi(\d)EEEvNS_8ConvArgsE$", l) for l in syms.splitlines() if "conv_igemm2_kernelI" in l]
+        assert tails and all(t is not None for t in tails)
+        assert {(t.group(1), t.group(2)) for t in tails} <= {("3", "0"), ("4", "0")}, sorted({(t.group(1), t.group(2)) for t in tails})
+    tracked = subprocess.run(["git", "ls-files", "tools/probes"], capture_output=True, text=True, cwd=root).stdout.split()
+    assert all(f.endswith(".hip") for f in tracked), tracked
