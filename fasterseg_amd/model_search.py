@@ -656,7 +656,7 @@ class Network_Multi_Path(nn.Module):
             # forward, each draining the launch queue.  Read all sampled indices back in ONE transfer instead - and (round 5) from a
             # SIDE stream that only waits for the last write of the architecture parameters (note_arch_update), not for everything the
             # step has queued on the launch stream: the widths are needed on the host to shape the pass, the step is host-bound, and a
-            # drain here left the host idle for ~10 ms per Gumbel pass (profiles/r05_host_vs_device_c5.txt).
+            # drain here left the host idle for ~10 ms per Gumbel pass (profiles/r05_host_vs_device_c3_c5_c2.txt).
             host = None
             on_gpu = params[0].is_cuda
             if read_indices and on_gpu and not torch.cuda.is_current_stream_capturing() and _SAMPLE_STREAM:
