@@ -154,6 +154,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError("libfasterseg_hip.so is not built (%s missing): run `python -m fasterseg_amd.build` "
                               "— there is no CPU/eager fallback" % LIB_PATH)
+        import torch  # noqa: F401  torch first: its bundled libamdhip64 must be the process's HIP runtime, not a second copy loaded for us
         handle = ctypes.CDLL(LIB_PATH)
         for name, argtypes in SIGNATURES.items():
             fn = getattr(handle, name)

@@ -63,9 +63,14 @@ def build(force=False, verbose=True):
             print("built", LIB)
     elif verbose:
         print("up to date:", LIB)
-    # undefined symbols (a kernel whose host stub hipcc dropped, a missing object) must fail HERE, not at first use on the GPU box
-    import ctypes
-    ctypes.CDLL(LIB, mode=os.RTLD_NOW)
+    # undefined symbols (a kernel whose host stub hipcc dropped, a missing object) must fail HERE, not at first use on the GPU box.
+    # In a CHILD process: the library links the system libamdhip64, torch ships its own copy - whichever is loaded first serves both, and
+    # loading this library before `import torch` leaves the process with two HIP runtimes (the library's launches then fail with "no
+    # ROCm-capable device is detected": `python __graft_entry__.py smoke` did, round 5).  Every other loader imports torch first (_lib.py).
+    check = subprocess.run([sys.executable, "-c", "import ctypes, os, sys; ctypes.CDLL(sys.argv[1], mode=os.RTLD_NOW)", LIB],
+                           capture_output=True, text=True)
+    if check.returncode != 0:
+        raise RuntimeError("libfasterseg_hip.so does not load:\n%s" % check.stderr)
     return LIB
 
 
