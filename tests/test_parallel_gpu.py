@@ -138,6 +138,36 @@ def test_search_step_data_parallel_two_ranks_one_gpu(tmp_path):
     assert checked > 1000 and any(k.startswith("alpha_") for k in r0)
 
 
+def test_bench_two_ranks_over_gloo_runs_the_supernet_step(tmp_path):
+    """The same launch for the supernet pretrain step: F12.L16 on two ranks - one flat broadcast per dtype of the ~70 k
+    parameter / buffer tensors, rank 0's width-sampling seed on both ranks, four accumulating passes (two replayed from hipGraphs:
+    mark_touched), every bucket all-reduced in sync(), the average folded into the SGD kernel's clip scale, the post-timed check on every
+    rank - gated on rank 0 against the CPU oracle like the single-GPU run."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FS_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workloads", "c3", "--steps", "50", "--warmup", "5", "--train-steps", "2",
+           "--train-warmup", "1", "--min-seconds", "0.05", "--no-cpu-baseline", "--no-class-map", "--no-fp32-leg", "--detail", str(tmp_path / "detail.json")]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1 and len(lines[0]) < 4096
+    d = json.loads(lines[0])
+    w = d["workloads"]["C3_supernet_pretrain"]
+    assert d["n_gpus"] == 2 and w["parity"]["pass"] and w["parity"]["rel_err"] <= 1e-2 and w["parity"]["after_timed"] is True
+    with open(tmp_path / "detail.json") as f:
+        c3 = json.load(f)["C3_supernet_pretrain"]
+    assert c3["global_batch"] == 6 and c3["per_gpu_batch"] == 3
+    assert "dp2" in c3["config"]["parallelism"] and "gloo" in c3["config"]["parallelism"]
+    assert c3["post_timed_check"]["grads_finite"] and c3["post_timed_check"]["weights_finite"]
+    assert c3["roofline"]["frac"] > 0 and c3["execution"]["graphed"] == 2
+
+
 def test_bench_two_ranks_over_gloo_runs_the_collective_path(tmp_path):
     """`python bench.py --gpus 2` as the driver launches it (self-spawned torch.distributed.run, one rank per process), with both ranks
     on this box's one GPU over gloo (RCCL refuses two ranks on a device): the data-parallel train path, the parity gate and the timed
