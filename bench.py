@@ -1,6 +1,6 @@
 """bench.py — headline benchmark of the FasterSeg hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|fp32] [--workloads c2,c3,c4,c5]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|fp32] [--train-dtype fp32|bf16] [--workloads c2,c3,c4,c5]
 
 ONE JSON line on rank 0.  Top level = BASELINE.json configs[1] (C2): searched student (arch_1) inference at 1x3x1024x2048,
 frames/s, input resident in HBM, the whole forward replayed from one hipGraph (fasterseg_amd.engine).  Before anything is
@@ -19,8 +19,9 @@ With N > 1 (one rank per GPU, RCCL) inference runs as independent replicas (it d
 collective path; launched without torchrun, `--gpus N` re-executes itself under torch.distributed.run.
 
 Every train workload is gated like C2: the loss of the FIRST step of the stepper that is about to be timed is compared with the CPU
-oracle on the same weights / batch / RNG seeds (`parity` inside each workload; a miss aborts), and carries an fp32 leg
-(`ms_per_step_fp32`: the reference's arithmetic) beside the bf16 number.
+oracle on the same weights / batch / RNG seeds (`parity` inside each workload; a miss aborts).  A train workload's `value` / `dtype` are
+the fp32 step's (fp32 storage + exact-fp32 MFMA: the reference trains in fp32, and only this step's gradients are the reference's
+within its own fp32-vs-fp64 gap); the all-bf16 step is timed beside it as a labelled throughput mode (`value_bf16`, `ms_per_step_bf16`).
 roofline: one more frame / step issued eagerly with every kernel launch timed by its own start/stop HIP event pair on the launch
 stream (hipExtLaunchKernelGGL; fasterseg_amd/census.py, csrc/census.hip): achieved = algorithmic FLOPs of ALL launches of the dominant
 kernel family / the sum of their measured durations - the figures tools/roofline_from_profile.py recomputes from the rocprofv3
@@ -55,14 +56,18 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed C2 frames (default 2000); train workloads time 10 steps")
     ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 100 frames / 3 train steps)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"], help="C2 (the headline): BASELINE configs[1] names bf16")
+    ap.add_argument("--train-dtype", default="fp32", choices=["bf16", "fp32"],
+                    help="precision of each train workload's `value` (C3/C4/C5): fp32 = the reference's arithmetic (default); the other "
+                         "precision is timed as a labelled extra")
     ap.add_argument("--workloads", default="c2,c3,c4,c5", help="comma list of c2,c3,c4,c5 (c2 is always the headline)")
     ap.add_argument("--train-steps", type=int, default=None, help="timed steps of every train workload (default 10; with an explicit --steps K: K bounded to 10..50)")
     ap.add_argument("--train-warmup", type=int, default=3)
     ap.add_argument("--min-seconds", type=float, default=0.5, help="minimum length of every timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the fp32 re-run of every train workload")
+    ap.add_argument("--no-fp32-leg", "--no-other-leg", dest="no_fp32_leg", action="store_true",
+                    help="skip the other-precision re-run of every train workload (and the fp32 engine of C2)")
     ap.add_argument("--no-class-map", action="store_true", help="skip the class-map (evaluator) variant of the C2 engine")
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="CPU budget of each cpu_baseline sample")
     ap.add_argument("--dump-plan", default=None, help="write the per-launch table of the C2 plan (json) here")
@@ -401,18 +406,24 @@ def _timed_census(args, world, rank, step_fn, extra_entries=(), workload=None):
     return {"roofline": roof, "kernel_families": families, "kernels_in_step": kernels}
 
 
-def _fp32_leg(args, world, make_stepper, run_of, batch):
-    """The same step in the reference's arithmetic (fp32 storage, exact-fp32 MFMA): a same-precision number beside the bf16 one."""
-    if args.dtype == "fp32" or args.no_fp32_leg:
+def _other_leg(args, world, make_stepper, run_of, batch):
+    """The same step in the OTHER precision.  Round 6: a train workload's `value` is the fp32 step - fp32 storage,
+    exact-fp32 MFMA: the reference's arithmetic (search/train_search.py:215-251, train/train.py:219-271), gradients within the
+    reference's own fp32-vs-fp64 gap - and the all-bf16 step is this labelled extra (`*_bf16`: loss right to 1e-3, deep-layer
+    gradients cosine 0.4-0.6, a throughput mode).  With --train-dtype bf16 the roles swap (`*_fp32`), as rounds 2-5 printed them."""
+    if args.no_fp32_leg:
         return {}
+    other = "bf16" if args.dtype == "fp32" else "fp32"
     torch.cuda.empty_cache()
-    stepper = make_stepper(torch.float32)
+    stepper = make_stepper(torch.float32 if other == "fp32" else torch.bfloat16)
     run = run_of(stepper)
     elapsed, steps = timed_region(run, max(10, args.train_steps), 2, world, args.min_seconds, args.exact, min(args.regions, 3))
     del stepper
     torch.cuda.empty_cache()
-    return {"ms_per_step_fp32": round(elapsed / steps * 1e3, 3), "value_fp32": round(world * batch * steps / elapsed, 4),
-            "fp32_steps": steps, "fp32_note": PRECISION["fp32"] + " - the reference trains in fp32 (search/train_search.py:215-251, train/train.py:219-271)"}
+    note = (PRECISION["fp32"] + " - the reference trains in fp32 (search/train_search.py:215-251, train/train.py:219-271)") if other == "fp32" else \
+           (PRECISION["bf16"] + " - throughput mode, NOT the reference's computation: " + GRADIENT_FIDELITY["bf16"])
+    return {"ms_per_step_" + other: round(elapsed / steps * 1e3, 3), "value_" + other: round(world * batch * steps / elapsed, 4),
+            other + "_steps": steps, other + "_note": note}
 
 
 def run_student_train(args, world, rank, backend):
@@ -477,7 +488,7 @@ def run_student_train(args, world, rank, backend):
                                          "%d images of 3x%dx%d: teacher eval forward + student train forward/backward through oracle/ref_ops, "
                                          "OHEM-CE + KLDiv through oracle/ref_loss" % (nb, H, W))
     del stepper
-    line.update(_fp32_leg(args, world, make, lambda st: (lambda: st.step(imgs, target)), batch))
+    line.update(_other_leg(args, world, make, lambda st: (lambda: st.step(imgs, target)), batch))
     return line
 
 
@@ -629,7 +640,7 @@ def run_supernet(args, world, rank, backend, pretrain):
                                                                        "`_loss` forward+backward of the arch step and of the weight step"),
                                          threads=(16, 32, 8))
     del stepper
-    line.update(_fp32_leg(args, world, make, lambda st: (lambda: st.step(imgs, target, imgs_s, target_s)), batch))
+    line.update(_other_leg(args, world, make, lambda st: (lambda: st.step(imgs, target, imgs_s, target_s)), batch))
     return line
 
 
@@ -661,7 +672,8 @@ def _short(text, n):
 
 def compact_workload(w):
     """The per-workload object of the printed line: numbers only, no method strings, no per-kernel tables."""
-    out = _pick(w, ("value", "unit", "ms_per_step", "steps", "dtype", "ms_per_step_fp32", "value_fp32", "fp32_steps", "per_gpu_batch"))
+    out = _pick(w, ("value", "unit", "ms_per_step", "steps", "dtype", "ms_per_step_fp32", "value_fp32", "fp32_steps", "ms_per_step_bf16", "value_bf16",
+                    "bf16_steps", "per_gpu_batch"))
     par = w.get("parity") or {}
     out["parity"] = _pick(par, ("pass", "rel_err", "max_abs_err", "rel_to_max_logit", "argmax_agreement"))
     if w.get("post_timed_check"):
@@ -717,7 +729,7 @@ def fit_line(line, limit=LINE_LIMIT):
         if size() < limit:
             return line
         line.pop(k, None)
-    for drop in (("cpu_baseline",), ("parity",), ("roofline",), ("fp32_steps", "per_gpu_batch", "steps", "dtype", "unit")):
+    for drop in (("cpu_baseline",), ("parity",), ("roofline",), ("fp32_steps", "bf16_steps", "per_gpu_batch", "steps", "unit")):
         for w in (line.get("workloads") or {}).values():
             if size() < limit:
                 return line
@@ -772,9 +784,12 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
     world, rank, backend = dist_setup(args)
-    runners = {"c3": ("C3_supernet_pretrain", lambda: run_supernet(args, world, rank, backend, True)),
-               "c4": ("C4_student_train", lambda: run_student_train(args, world, rank, backend)),
-               "c5": ("C5_supernet_search", lambda: run_supernet(args, world, rank, backend, False))}
+    import copy
+    targs = copy.copy(args)                    # the train workloads' own precision (default fp32: the reference's arithmetic); C2 keeps --dtype
+    targs.dtype = args.train_dtype
+    runners = {"c3": ("C3_supernet_pretrain", lambda: run_supernet(targs, world, rank, backend, True)),
+               "c4": ("C4_student_train", lambda: run_student_train(targs, world, rank, backend)),
+               "c5": ("C5_supernet_search", lambda: run_supernet(targs, world, rank, backend, False))}
     train = {}
     clocks = {}
     # The supernet steps are HOST-bound: run them before the student train step, whose teardown leaves the

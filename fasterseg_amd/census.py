@@ -21,17 +21,37 @@ from ._lib import FS_CONV_TRANSPOSED, CensusEntry, ConvDesc, KernelTime, call
 
 IGEMM, HALO, WGRAD, STATS = 0, 1, 2, 0x100
 FAMILY_NAMES = {IGEMM: "conv_igemm (fwd + dgrad)", HALO: "conv3x3_halo", WGRAD: "conv_wgrad"}
+# The HBM-bound families of a train step, by kernel name (single and grouped forms): priced at their ALGORITHMIC bytes - one read or
+# write of every operand map the pass needs (csrc: FS_NOTE_BYTES) - against the 8 TB/s HBM peak.  VERDICT r5 weak #6: in the round-5 C3
+# step the BatchNorm family (30.9 ms) outweighed conv fwd + dgrad (26.2 ms) and the `roofline` object could not name it.
+HBM_FAMILIES = {
+    "batchnorm (train fwd + bwd)": ("bn_small_fwd", "bn_small_bwd", "bn_group_fwd", "bn_group_bwd", "chan_reduce", "bn_train_apply", "bn_bwd_apply"),
+    "bilinear resample": ("bilinear_fwd", "bilinear_bwd"),
+    "weighted sums / axpy": ("wsum", "wsum_bwd", "wsum_dot", "ew"),
+}
+
+
+def hbm_family_of(kernel_name):
+    """Family of a census kernel name ('bn_small_fwd_group_kernel' -> 'batchnorm (train fwd + bwd)'), or None."""
+    base = kernel_name[:-len("_kernel")] if kernel_name.endswith("_kernel") else kernel_name
+    if base.endswith("_group"):
+        base = base[:-len("_group")]
+    for fam, names in HBM_FAMILIES.items():
+        if base in names:
+            return fam
+    return None
 
 
 @contextlib.contextmanager
 def recording(level=1):
-    """with recording() as rec: <issue one step>  ->  rec.entries = [(family, ConvDesc, count, ms)], rec.kernels = {name: (count, ms)}
-    level 2 times every launch (ms is 0 at level 1)."""
+    """with recording() as rec: <issue one step>  ->  rec.entries = [(family, ConvDesc, count, ms)], rec.kernels = {name: (count, ms)},
+    rec.kernel_bytes = {name: algorithmic HBM bytes of those launches}.  level 2 times every launch (ms is 0 at level 1)."""
     lib = _lib.lib()
 
     class _Rec:
         entries = []
         kernels = {}
+        kernel_bytes = {}
     rec = _Rec()
     lib.fs_census_enable(level)
     try:
@@ -53,6 +73,7 @@ def recording(level=1):
         kb = (KernelTime * max(nk, 1))()
         nk = min(nk, lib.fs_census_read_kernels(ctypes.cast(kb, ctypes.c_void_p), nk))
         rec.kernels = {kb[i].name.decode(): (int(kb[i].count), float(kb[i].ms)) for i in range(nk)}
+        rec.kernel_bytes = {kb[i].name.decode(): float(kb[i].bytes) for i in range(nk)}     # algorithmic HBM bytes (0: not priced)
 
 
 def conv_flops(d):
@@ -179,19 +200,47 @@ def roofline_timed(rec, dtype_name, peak_tflops, peak_hbm_gbs=8000.0, extra_entr
     if not fams:
         return None, {}, {}
     kernel_ms = sum(ms for _, ms in rec.kernels.values()) + sum(e[3] for e in extra_entries)
+    # the HBM-bound families: launches, device time and algorithmic bytes per kernel name, summed per family
+    hbm = {}
+    kbytes = getattr(rec, "kernel_bytes", {})
+    for name, (count, ms) in rec.kernels.items():
+        fam = hbm_family_of(name)
+        if fam is None or ms <= 0:
+            continue
+        h = hbm.setdefault(fam, dict(ms=0.0, bytes=0.0, launches=0))
+        h["ms"] += ms
+        h["bytes"] += kbytes.get(name, 0.0)
+        h["launches"] += count
     dom_id, dom = max(fams.items(), key=lambda kv: kv[1]["ms"])
-    ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-    roof = {"kernel": FAMILY_NAMES[dom_id], "bound": "mfma", "achieved": round(ach, 2), "peak": peak_tflops, "unit": "TFLOP/s",
-            "frac": round(ach / peak_tflops, 5), "launches_per_step": dom["launches"], "distinct_shapes": dom["shapes"],
-            "avg_launch_us": round(dom["ms"] / dom["launches"] * 1e3, 3), "share_of_kernel_time": round(dom["ms"] / max(kernel_ms, 1e-9), 4),
-            "alg_flops_per_launch": dom["flops"] / dom["launches"], "alg_bytes_per_launch": dom["bytes"] / dom["launches"],
-            "achieved_GBps": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9, 1), "traffic": None, "flops_coverage": 1.0,
-            "method": "one eager step at census level 2: every launch of the family timed by its own start/stop HIP event pair "
-                      "(hipExtLaunchKernelGGL) on the launch stream; achieved = sum FLOPs / sum durations of ALL launches"}
+    hbm_name, hbm_dom = max(hbm.items(), key=lambda kv: kv[1]["ms"]) if hbm else (None, None)
+    method = ("one eager step at census level 2: every launch of the family timed by its own start/stop HIP event pair "
+              "(hipExtLaunchKernelGGL) on the launch stream; achieved = sum of algorithmic work / sum of durations of ALL launches; the "
+              "family is the largest by device time among ALL families of the step (convolutions AND BatchNorm / resample / weighted sums)")
+    if hbm_dom is not None and hbm_dom["ms"] > dom["ms"] and hbm_dom["bytes"] > 0:
+        ach = hbm_dom["bytes"] / (hbm_dom["ms"] * 1e-3) / 1e9
+        roof = {"kernel": hbm_name, "bound": "hbm", "achieved": round(ach, 1), "peak": peak_hbm_gbs, "unit": "GB/s",
+                "frac": round(ach / peak_hbm_gbs, 5), "launches_per_step": hbm_dom["launches"],
+                "avg_launch_us": round(hbm_dom["ms"] / hbm_dom["launches"] * 1e3, 3),
+                "share_of_kernel_time": round(hbm_dom["ms"] / max(kernel_ms, 1e-9), 4),
+                "alg_bytes_per_launch": hbm_dom["bytes"] / hbm_dom["launches"], "traffic": None, "flops_coverage": 1.0, "method": method}
+    else:
+        ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        roof = {"kernel": FAMILY_NAMES[dom_id], "bound": "mfma", "achieved": round(ach, 2), "peak": peak_tflops, "unit": "TFLOP/s",
+                "frac": round(ach / peak_tflops, 5), "launches_per_step": dom["launches"], "distinct_shapes": dom["shapes"],
+                "avg_launch_us": round(dom["ms"] / dom["launches"] * 1e3, 3), "share_of_kernel_time": round(dom["ms"] / max(kernel_ms, 1e-9), 4),
+                "alg_flops_per_launch": dom["flops"] / dom["launches"], "alg_bytes_per_launch": dom["bytes"] / dom["launches"],
+                "achieved_GBps": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9, 1), "traffic": None, "flops_coverage": 1.0, "method": method}
     families = {FAMILY_NAMES[k]: {"ms_per_step": round(v["ms"], 3), "launches": v["launches"], "shapes": v["shapes"],
                                   "avg_us": round(v["ms"] / v["launches"] * 1e3, 2),
                                   "TFLOPs": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
                                   "frac_of_mfma_peak": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / peak_tflops, 5)} for k, v in fams.items()}
+    for name, h in hbm.items():
+        families[name] = {"ms_per_step": round(h["ms"], 3), "launches": h["launches"], "avg_us": round(h["ms"] / h["launches"] * 1e3, 2),
+                          "alg_GB": round(h["bytes"] / 1e9, 4), "GBps": round(h["bytes"] / (h["ms"] * 1e-3) / 1e9, 1),
+                          "frac_of_hbm_peak": round(h["bytes"] / (h["ms"] * 1e-3) / 1e9 / peak_hbm_gbs, 5)}
+    # the step against the roofs: every family at its own roof (convolutions at the MFMA peak, the HBM-bound families at 8 TB/s)
+    ideal_ms = sum(v["flops"] / (peak_tflops * 1e12) * 1e3 for v in fams.values()) + sum(h["bytes"] / (peak_hbm_gbs * 1e9) * 1e3 for h in hbm.values())
+    roof["step_ideal_ms"] = round(ideal_ms, 4)
     kernels = {name: {"launches": c, "ms_per_step": round(ms, 3), "avg_us": round(ms / max(c, 1) * 1e3, 2)}
                for name, (c, ms) in sorted(rec.kernels.items(), key=lambda kv: -kv[1][1])}
     return roof, families, kernels

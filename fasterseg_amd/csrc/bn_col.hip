@@ -14,6 +14,7 @@
 // pair of a supernet cell, model_search.py:322-329) become one batched evaluation with the reference's arithmetic.
 // Replaces nn.BatchNorm2d train forward/backward (+ nn.ReLU): operations.py:39,80,147; slimmable_ops.py:58-70.
 #include "common.h"
+#include "group.h"
 
 namespace fs {
 
@@ -51,22 +52,40 @@ __device__ __forceinline__ void block_sum2(float (&a)[VEC], float (&b)[VEC], flo
     }
 }
 
+// kernel arguments as records: the grouped launches (group.h) carry up to FS_MAX_GROUP of them by value
+struct BnColFwdArgs {
+    long long pixels; int C, groups; void* z; int z_cs; const float* partials; int splits; const float* gamma; const float* beta;
+    float eps, momentum; float* running_mean; float* running_var; long long* num_batches_tracked; float* saved; void* y; int y_cs, relu;
+};
+struct BnColBwdArgs {
+    long long pixels; int C, groups; const void* z; int z_cs; const void* dy; int dy_cs; const void* yo; int y_cs; const float* saved;
+    const float* gamma; int relu; void* dz; int dz_cs; float* red_out; float* dgamma_acc; float* dbeta_acc;
+};
+#define FS_BNCOL_FWD_LOCALS                                                                                                     \
+    T* __restrict__ z = (T*)a.z; T* __restrict__ y = (T*)a.y;                                                                   \
+    const float* __restrict__ partials = a.partials; const float* __restrict__ gamma = a.gamma; const float* __restrict__ beta = a.beta; \
+    float* running_mean = a.running_mean; float* running_var = a.running_var; float* __restrict__ saved = a.saved;              \
+    const long long pixels = a.pixels; const int C = a.C, z_cs = a.z_cs, y_cs = a.y_cs, splits = a.splits;                      \
+    const float eps = a.eps, momentum = a.momentum;
+#define FS_BNCOL_BWD_LOCALS                                                                                                     \
+    const T* __restrict__ z = (const T*)a.z; const T* __restrict__ dy = (const T*)a.dy; const T* __restrict__ yo = (const T*)a.yo; \
+    T* __restrict__ dz = (T*)a.dz; const float* __restrict__ saved = a.saved; const float* __restrict__ gamma = a.gamma;         \
+    float* __restrict__ red_out = a.red_out; float* dgamma_acc = a.dgamma_acc; float* dbeta_acc = a.dbeta_acc;                  \
+    const long long pixels = a.pixels; const int C = a.C, z_cs = a.z_cs, dy_cs = a.dy_cs, y_cs = a.y_cs, dz_cs = a.dz_cs;
+
 template <typename T>
-__global__ __launch_bounds__(BNC_THREADS) void bn_group_fwd_kernel(long long pixels, int C, int groups, T* __restrict__ z, int z_cs,
-                                                                    const float* __restrict__ partials, int splits,
-                                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                    float eps, float momentum, float* running_mean, float* running_var,
-                                                                    long long* num_batches_tracked, float* __restrict__ saved,
-                                                                    T* __restrict__ y, int y_cs, int relu) {
+__device__ __forceinline__ void bn_group_fwd_body(const BnColFwdArgs& a, int bx) {
     constexpr int VEC = Elem<T>::VEC;
     __shared__ float red[2 * BNC_MAX_WAVES * VEC];
     __shared__ float affine[2 * VEC];
+    FS_BNCOL_FWD_LOCALS
+    const int groups = a.groups;
     const int tid = threadIdx.x, nthr = blockDim.x;
-    const int c0 = blockIdx.x * VEC;
-    const int relu_arg = relu;
-    relu = relu_at(relu, c0) ? 1 : 0;          // per channel vector (see common.h)
+    const int c0 = bx * VEC;
+    const int relu_arg = a.relu;
+    const int relu = relu_at(relu_arg, c0) ? 1 : 0;          // per channel vector (see common.h)
     const long long mg = pixels / groups;
-    if (blockIdx.x == 0 && tid == 0) bump_batches_tracked(num_batches_tracked, relu_arg, groups);
+    if (bx == 0 && tid == 0) bump_batches_tracked(a.num_batches_tracked, relu_arg, groups);
     for (int g = 0; g < groups; ++g) {
         const long long base = (long long)g * mg;
         float s1[VEC], s2[VEC];
@@ -174,17 +193,14 @@ __global__ __launch_bounds__(BNC_THREADS) void bn_group_fwd_kernel(long long pix
 }
 
 template <typename T>
-__global__ __launch_bounds__(BNC_THREADS) void bn_group_bwd_kernel(long long pixels, int C, int groups, const T* __restrict__ z, int z_cs,
-                                                                    const T* __restrict__ dy, int dy_cs, const T* __restrict__ yo,
-                                                                    int y_cs, const float* __restrict__ saved,
-                                                                    const float* __restrict__ gamma, int relu, T* __restrict__ dz,
-                                                                    int dz_cs, float* __restrict__ red_out, float* dgamma_acc,
-                                                                    float* dbeta_acc) {
+__device__ __forceinline__ void bn_group_bwd_body(const BnColBwdArgs& a, int bx) {
     constexpr int VEC = Elem<T>::VEC;
     __shared__ float red[2 * BNC_MAX_WAVES * VEC];
+    FS_BNCOL_BWD_LOCALS
+    const int groups = a.groups;
     const int tid = threadIdx.x, nthr = blockDim.x;
-    const int c0 = blockIdx.x * VEC;
-    relu = relu_at(relu, c0) ? 1 : 0;          // per channel vector (see common.h)
+    const int c0 = bx * VEC;
+    const int relu = relu_at(a.relu, c0) ? 1 : 0;          // per channel vector (see common.h)
     const long long mg = pixels / groups;
     float tot_b[VEC], tot_g[VEC], ga[VEC];
 #pragma unroll
@@ -297,21 +313,17 @@ __device__ __forceinline__ void block_sum_n(float (&a)[N], float* red /* [N][BNS
 }
 
 template <typename T, int G>
-__global__ __launch_bounds__(BNS_THREADS) void bn_small_fwd_kernel(long long pixels, int C, T* __restrict__ z, int z_cs,
-                                                                    const float* __restrict__ partials, int splits,
-                                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                    float eps, float momentum, float* running_mean, float* running_var,
-                                                                    long long* num_batches_tracked, float* __restrict__ saved,
-                                                                    T* __restrict__ y, int y_cs, int relu) {
+__device__ __forceinline__ void bn_small_fwd_body(const BnColFwdArgs& a, int bx) {
     constexpr int VEC = Elem<T>::VEC;
     __shared__ float red[G * 2 * VEC * BNS_WAVES];
     __shared__ float affine[G * 2 * VEC];
+    FS_BNCOL_FWD_LOCALS
     const int tid = threadIdx.x;
-    const int c0 = blockIdx.x * VEC;
-    const int relu_arg = relu;
-    relu = relu_at(relu, c0) ? 1 : 0;          // per channel vector (see common.h)
+    const int c0 = bx * VEC;
+    const int relu_arg = a.relu;
+    const int relu = relu_at(relu_arg, c0) ? 1 : 0;          // per channel vector (see common.h)
     const int mg = (int)(pixels / G);
-    if (blockIdx.x == 0 && tid == 0) bump_batches_tracked(num_batches_tracked, relu_arg, G);
+    if (bx == 0 && tid == 0) bump_batches_tracked(a.num_batches_tracked, relu_arg, G);
     // the finalising lanes request their channel's affine parameters and running statistics NOW, together with the map: after the block
     // reduction they would be one more dependent round trip to memory on the critical path of an ~8 us kernel (round 5)
     float p_ga = 1.f, p_be = 0.f, p_rm = 0.f, p_rv = 0.f;
@@ -428,17 +440,13 @@ __global__ __launch_bounds__(BNS_THREADS) void bn_small_fwd_kernel(long long pix
 }
 
 template <typename T, int G>
-__global__ __launch_bounds__(BNS_THREADS) void bn_small_bwd_kernel(long long pixels, int C, const T* __restrict__ z, int z_cs,
-                                                                    const T* __restrict__ dy, int dy_cs, const T* __restrict__ yo,
-                                                                    int y_cs, const float* __restrict__ saved,
-                                                                    const float* __restrict__ gamma, int relu, T* __restrict__ dz,
-                                                                    int dz_cs, float* __restrict__ red_out, float* dgamma_acc,
-                                                                    float* dbeta_acc) {
+__device__ __forceinline__ void bn_small_bwd_body(const BnColBwdArgs& a, int bx) {
     constexpr int VEC = Elem<T>::VEC;
     __shared__ float red[G * 2 * VEC * BNS_WAVES];
+    FS_BNCOL_BWD_LOCALS
     const int tid = threadIdx.x;
-    const int c0 = blockIdx.x * VEC;
-    relu = relu_at(relu, c0) ? 1 : 0;          // per channel vector (see common.h)
+    const int c0 = bx * VEC;
+    const int relu = relu_at(a.relu, c0) ? 1 : 0;          // per channel vector (see common.h)
     const int mg = (int)(pixels / G);
     u32x4 rz[G][BNS_UNROLL], rg[G][BNS_UNROLL], ro[G][BNS_UNROLL];
 #pragma unroll
@@ -522,6 +530,28 @@ __global__ __launch_bounds__(BNS_THREADS) void bn_small_bwd_kernel(long long pix
     }
 }
 
+// single and grouped launch wrappers (a block = one 16-byte channel vector of one problem)
+template <typename T> __global__ __launch_bounds__(BNC_THREADS) void bn_group_fwd_kernel(BnColFwdArgs a) { bn_group_fwd_body<T>(a, (int)blockIdx.x); }
+template <typename T> __global__ __launch_bounds__(BNC_THREADS) void bn_group_bwd_kernel(BnColBwdArgs a) { bn_group_bwd_body<T>(a, (int)blockIdx.x); }
+template <typename T, int G> __global__ __launch_bounds__(BNS_THREADS) void bn_small_fwd_kernel(BnColFwdArgs a) { bn_small_fwd_body<T, G>(a, (int)blockIdx.x); }
+template <typename T, int G> __global__ __launch_bounds__(BNS_THREADS) void bn_small_bwd_kernel(BnColBwdArgs a) { bn_small_bwd_body<T, G>(a, (int)blockIdx.x); }
+template <typename T> __global__ __launch_bounds__(BNC_THREADS) void bn_group_fwd_group_kernel(GroupOf<BnColFwdArgs> g) {
+    const int bid = (int)blockIdx.x, i = group_locate(g, bid);
+    bn_group_fwd_body<T>(g.p[i], bid - g.blk_start[i]);
+}
+template <typename T> __global__ __launch_bounds__(BNC_THREADS) void bn_group_bwd_group_kernel(GroupOf<BnColBwdArgs> g) {
+    const int bid = (int)blockIdx.x, i = group_locate(g, bid);
+    bn_group_bwd_body<T>(g.p[i], bid - g.blk_start[i]);
+}
+template <typename T, int G> __global__ __launch_bounds__(BNS_THREADS) void bn_small_fwd_group_kernel(GroupOf<BnColFwdArgs> g) {
+    const int bid = (int)blockIdx.x, i = group_locate(g, bid);
+    bn_small_fwd_body<T, G>(g.p[i], bid - g.blk_start[i]);
+}
+template <typename T, int G> __global__ __launch_bounds__(BNS_THREADS) void bn_small_bwd_group_kernel(GroupOf<BnColBwdArgs> g) {
+    const int bid = (int)blockIdx.x, i = group_locate(g, bid);
+    bn_small_bwd_body<T, G>(g.p[i], bid - g.blk_start[i]);
+}
+
 }  // namespace fs
 
 using namespace fs;
@@ -559,21 +589,18 @@ extern "C" fs_status fs_bn_group_fwd(void* stream, long long pixels, int C, int 
     FS_REQUIRE(splits <= 1 || (partials && aligned16(partials) && C % 4 == 0), FS_ERR_INVALID, "fs_bn_group_fwd: bad split-K partials");
     const int cv = C / vec_elems(dtype);
     hipStream_t st = (hipStream_t)stream;
+    const BnColFwdArgs a{pixels, C, groups, z, z_cs, partials, splits, gamma, beta, eps, momentum, running_mean, running_var,
+                         num_batches_tracked, saved, y, y_cs, relu};
+    FS_NOTE_BYTES((double)pixels * C * elem_size(dtype) * 2);
     if (bn_small_ok(pixels, groups)) {
-#define FS_BN_SMALL_FWD(T, G)                                                                                                     \
-    FS_LAUNCH((bn_small_fwd_kernel<T, G>), dim3(cv), dim3(BNS_THREADS), 0, st, pixels, C, (T*)z, z_cs, partials, splits, gamma, \
-                       beta, eps, momentum, running_mean, running_var, num_batches_tracked, saved, (T*)y, y_cs, relu)
+#define FS_BN_SMALL_FWD(T, G) FS_LAUNCH((bn_small_fwd_kernel<T, G>), dim3(cv), dim3(BNS_THREADS), 0, st, a)
         if (dtype == FS_F32) { if (groups == 1) FS_BN_SMALL_FWD(float, 1); else FS_BN_SMALL_FWD(float, 2); }
         else { if (groups == 1) FS_BN_SMALL_FWD(bf16_t, 1); else FS_BN_SMALL_FWD(bf16_t, 2); }
 #undef FS_BN_SMALL_FWD
         return check_launch("fs_bn_group_fwd");
     }
-    if (dtype == FS_F32)
-        FS_LAUNCH((bn_group_fwd_kernel<float>), dim3(cv), dim3(bnc_threads(pixels / groups)), 0, st, pixels, C, groups, (float*)z, z_cs, partials, splits,
-                           gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, saved, (float*)y, y_cs, relu);
-    else
-        FS_LAUNCH((bn_group_fwd_kernel<bf16_t>), dim3(cv), dim3(bnc_threads(pixels / groups)), 0, st, pixels, C, groups, (bf16_t*)z, z_cs, partials, splits,
-                           gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, saved, (bf16_t*)y, y_cs, relu);
+    if (dtype == FS_F32) FS_LAUNCH((bn_group_fwd_kernel<float>), dim3(cv), dim3(bnc_threads(pixels / groups)), 0, st, a);
+    else FS_LAUNCH((bn_group_fwd_kernel<bf16_t>), dim3(cv), dim3(bnc_threads(pixels / groups)), 0, st, a);
     return check_launch("fs_bn_group_fwd");
 }
 
@@ -590,20 +617,116 @@ extern "C" fs_status fs_bn_group_bwd(void* stream, long long pixels, int C, int 
     FS_REQUIRE((dgamma_acc == nullptr) == (dbeta_acc == nullptr), FS_ERR_INVALID, "fs_bn_group_bwd: dgamma_acc/dbeta_acc go together");
     const int cv = C / vec_elems(dtype);
     hipStream_t st = (hipStream_t)stream;
+    const BnColBwdArgs a{pixels, C, groups, z, z_cs, dy, dy_cs, y_out, y_cs, saved, gamma, relu, dz, dz_cs, red, dgamma_acc, dbeta_acc};
+    FS_NOTE_BYTES((double)pixels * C * elem_size(dtype) * (relu ? 4 : 3));
     if (bn_small_ok(pixels, groups)) {
-#define FS_BN_SMALL_BWD(T, G)                                                                                                      \
-    FS_LAUNCH((bn_small_bwd_kernel<T, G>), dim3(cv), dim3(BNS_THREADS), 0, st, pixels, C, (const T*)z, z_cs, (const T*)dy, dy_cs, \
-                       (const T*)y_out, y_cs, saved, gamma, relu, (T*)dz, dz_cs, red, dgamma_acc, dbeta_acc)
+#define FS_BN_SMALL_BWD(T, G) FS_LAUNCH((bn_small_bwd_kernel<T, G>), dim3(cv), dim3(BNS_THREADS), 0, st, a)
         if (dtype == FS_F32) { if (groups == 1) FS_BN_SMALL_BWD(float, 1); else FS_BN_SMALL_BWD(float, 2); }
         else { if (groups == 1) FS_BN_SMALL_BWD(bf16_t, 1); else FS_BN_SMALL_BWD(bf16_t, 2); }
 #undef FS_BN_SMALL_BWD
         return check_launch("fs_bn_group_bwd");
     }
-    if (dtype == FS_F32)
-        FS_LAUNCH((bn_group_bwd_kernel<float>), dim3(cv), dim3(bnc_threads(pixels / groups)), 0, st, pixels, C, groups, (const float*)z, z_cs,
-                           (const float*)dy, dy_cs, (const float*)y_out, y_cs, saved, gamma, relu, (float*)dz, dz_cs, red, dgamma_acc, dbeta_acc);
-    else
-        FS_LAUNCH((bn_group_bwd_kernel<bf16_t>), dim3(cv), dim3(bnc_threads(pixels / groups)), 0, st, pixels, C, groups, (const bf16_t*)z, z_cs,
-                           (const bf16_t*)dy, dy_cs, (const bf16_t*)y_out, y_cs, saved, gamma, relu, (bf16_t*)dz, dz_cs, red, dgamma_acc, dbeta_acc);
+    if (dtype == FS_F32) FS_LAUNCH((bn_group_bwd_kernel<float>), dim3(cv), dim3(bnc_threads(pixels / groups)), 0, st, a);
+    else FS_LAUNCH((bn_group_bwd_kernel<bf16_t>), dim3(cv), dim3(bnc_threads(pixels / groups)), 0, st, a);
     return check_launch("fs_bn_group_bwd");
+}
+
+// ---- grouped forms (group.h) ------------------------------------------------------------------------------------------------------------
+// One launch per (dtype, kernel variant): the register-resident kernels with one / two groups, the generic column kernel per block size.
+static int bn_col_variant(long long pixels, int groups) {
+    if (bn_small_ok(pixels, groups)) return groups;                     // 1, 2
+    return 2 + bnc_threads(pixels / groups) / 256;                      // 3 (256 lanes), 4 (512), 6 (1024)
+}
+
+fs_status fs::bn_col_fwd_group(void* stream, const BnFwdCall* c, const int* idx, int n) {
+    hipStream_t st = (hipStream_t)stream;
+    return for_each_bucket(n, [&](int i) { const BnFwdCall& q = c[idx[i]]; return (long long)q.dtype * 16 + bn_col_variant(q.pixels, q.groups); },
+                           [&](const int* sub, int m) -> fs_status {
+        const BnFwdCall& q0 = c[idx[sub[0]]];
+        if (m == 1)
+            return fs_bn_group_fwd(stream, q0.pixels, q0.C, q0.groups, q0.z, q0.z_cs, nullptr, 1, q0.gamma, q0.beta, q0.eps, q0.momentum,
+                                   q0.running_mean, q0.running_var, q0.num_batches_tracked, q0.saved, q0.y, q0.y_cs, q0.dtype, q0.relu);
+        GroupOf<BnColFwdArgs> g;
+        g.n = m;
+        int grid = 0;
+        double bytes = 0;
+        for (int j = 0; j < m; ++j) {
+            const BnFwdCall& q = c[idx[sub[j]]];
+            FS_REQUIRE(q.dtype == FS_F32 || q.dtype == FS_BF16, FS_ERR_INVALID, "fs_bn_group_fwd: bad dtype");
+            fs_status s;
+            if ((s = check_map("fs_bn_group_fwd", q.z, q.z_cs, q.C, q.dtype)) != FS_OK) return s;
+            if ((s = check_map("fs_bn_group_fwd", q.y, q.y_cs, q.C, q.dtype)) != FS_OK) return s;
+            FS_REQUIRE(q.saved && q.pixels > 0 && q.groups > 0 && q.pixels % q.groups == 0, FS_ERR_INVALID,
+                       "fs_bn_group_fwd: pixels (%lld) must be a positive multiple of groups (%d)", q.pixels, q.groups);
+            g.p[j] = BnColFwdArgs{q.pixels, q.C, q.groups, q.z, q.z_cs, nullptr, 1, q.gamma, q.beta, q.eps, q.momentum, q.running_mean,
+                                  q.running_var, q.num_batches_tracked, q.saved, q.y, q.y_cs, q.relu};
+            g.blk_start[j] = grid;
+            grid += q.C / vec_elems(q.dtype);
+            bytes += (double)q.pixels * q.C * elem_size(q.dtype) * 2;
+        }
+        for (int j = m; j <= FS_MAX_GROUP; ++j) g.blk_start[j] = grid;
+        FS_NOTE_BYTES(bytes);
+        const int variant = bn_col_variant(q0.pixels, q0.groups);
+        const bool f32 = q0.dtype == FS_F32;
+        if (variant == 1) {
+            if (f32) FS_LAUNCH((bn_small_fwd_group_kernel<float, 1>), dim3(grid), dim3(BNS_THREADS), 0, st, g);
+            else FS_LAUNCH((bn_small_fwd_group_kernel<bf16_t, 1>), dim3(grid), dim3(BNS_THREADS), 0, st, g);
+        } else if (variant == 2) {
+            if (f32) FS_LAUNCH((bn_small_fwd_group_kernel<float, 2>), dim3(grid), dim3(BNS_THREADS), 0, st, g);
+            else FS_LAUNCH((bn_small_fwd_group_kernel<bf16_t, 2>), dim3(grid), dim3(BNS_THREADS), 0, st, g);
+        } else {
+            const int threads = bnc_threads(q0.pixels / q0.groups);
+            if (f32) FS_LAUNCH((bn_group_fwd_group_kernel<float>), dim3(grid), dim3(threads), 0, st, g);
+            else FS_LAUNCH((bn_group_fwd_group_kernel<bf16_t>), dim3(grid), dim3(threads), 0, st, g);
+        }
+        return check_launch("fs_bn_group_fwd");
+    });
+}
+
+fs_status fs::bn_col_bwd_group(void* stream, const BnBwdCall* c, const int* idx, int n) {
+    hipStream_t st = (hipStream_t)stream;
+    return for_each_bucket(n, [&](int i) { const BnBwdCall& q = c[idx[i]]; return (long long)q.dtype * 16 + bn_col_variant(q.pixels, q.groups); },
+                           [&](const int* sub, int m) -> fs_status {
+        const BnBwdCall& q0 = c[idx[sub[0]]];
+        if (m == 1)
+            return fs_bn_group_bwd(stream, q0.pixels, q0.C, q0.groups, q0.z, q0.z_cs, q0.dy, q0.dy_cs, q0.y, q0.y_cs, q0.saved, q0.gamma, q0.dtype,
+                                   q0.relu, q0.dz, q0.dz_cs, q0.red, q0.dgamma_acc, q0.dbeta_acc);
+        GroupOf<BnColBwdArgs> g;
+        g.n = m;
+        int grid = 0;
+        double bytes = 0;
+        for (int j = 0; j < m; ++j) {
+            const BnBwdCall& q = c[idx[sub[j]]];
+            FS_REQUIRE(q.dtype == FS_F32 || q.dtype == FS_BF16, FS_ERR_INVALID, "fs_bn_group_bwd: bad dtype");
+            fs_status s;
+            if ((s = check_map("fs_bn_group_bwd", q.z, q.z_cs, q.C, q.dtype)) != FS_OK) return s;
+            if ((s = check_map("fs_bn_group_bwd", q.dy, q.dy_cs, q.C, q.dtype)) != FS_OK) return s;
+            if ((s = check_map("fs_bn_group_bwd", q.dz, q.dz_cs, q.C, q.dtype)) != FS_OK) return s;
+            if (q.relu && (s = check_map("fs_bn_group_bwd", q.y, q.y_cs, q.C, q.dtype)) != FS_OK) return s;
+            FS_REQUIRE(q.saved && q.gamma && q.red && q.pixels > 0 && q.groups > 0 && q.pixels % q.groups == 0, FS_ERR_INVALID,
+                       "fs_bn_group_bwd: bad argument");
+            FS_REQUIRE((q.dgamma_acc == nullptr) == (q.dbeta_acc == nullptr), FS_ERR_INVALID, "fs_bn_group_bwd: dgamma_acc/dbeta_acc go together");
+            g.p[j] = BnColBwdArgs{q.pixels, q.C, q.groups, q.z, q.z_cs, q.dy, q.dy_cs, q.y, q.y_cs, q.saved, q.gamma, q.relu, q.dz, q.dz_cs, q.red,
+                                  q.dgamma_acc, q.dbeta_acc};
+            g.blk_start[j] = grid;
+            grid += q.C / vec_elems(q.dtype);
+            bytes += (double)q.pixels * q.C * elem_size(q.dtype) * (q.relu ? 4 : 3);
+        }
+        for (int j = m; j <= FS_MAX_GROUP; ++j) g.blk_start[j] = grid;
+        FS_NOTE_BYTES(bytes);
+        const int variant = bn_col_variant(q0.pixels, q0.groups);
+        const bool f32 = q0.dtype == FS_F32;
+        if (variant == 1) {
+            if (f32) FS_LAUNCH((bn_small_bwd_group_kernel<float, 1>), dim3(grid), dim3(BNS_THREADS), 0, st, g);
+            else FS_LAUNCH((bn_small_bwd_group_kernel<bf16_t, 1>), dim3(grid), dim3(BNS_THREADS), 0, st, g);
+        } else if (variant == 2) {
+            if (f32) FS_LAUNCH((bn_small_bwd_group_kernel<float, 2>), dim3(grid), dim3(BNS_THREADS), 0, st, g);
+            else FS_LAUNCH((bn_small_bwd_group_kernel<bf16_t, 2>), dim3(grid), dim3(BNS_THREADS), 0, st, g);
+        } else {
+            const int threads = bnc_threads(q0.pixels / q0.groups);
+            if (f32) FS_LAUNCH((bn_group_bwd_group_kernel<float>), dim3(grid), dim3(threads), 0, st, g);
+            else FS_LAUNCH((bn_group_bwd_group_kernel<bf16_t>), dim3(grid), dim3(threads), 0, st, g);
+        }
+        return check_launch("fs_bn_group_bwd");
+    });
 }

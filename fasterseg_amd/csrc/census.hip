@@ -25,6 +25,7 @@ namespace {
 struct KernelAcc {
     long long count = 0;
     double ms = 0.0;
+    double bytes = 0.0;          // algorithmic HBM bytes the launchers noted (census_note_bytes)
 };
 struct Pending {
     hipEvent_t e0, e1;
@@ -44,6 +45,7 @@ std::vector<KernelAcc> g_kernels;
 std::vector<Pending> g_pending;
 std::vector<std::pair<hipEvent_t, hipEvent_t>> g_free;
 thread_local fs_census_entry* t_scope = nullptr;
+thread_local double t_bytes = 0.0;                   // census_note_bytes: consumed by the next timed launch of this thread
 thread_local std::shared_ptr<const std::vector<std::pair<fs_census_entry*, double>>> t_group;     // (entry, share of the launch's duration)
 std::map<int, KernelAcc> g_tags;
 int g_tag = -1;
@@ -124,6 +126,8 @@ CensusScope::~CensusScope() {
     if (live) t_scope = nullptr;
 }
 
+void census_note_bytes(double bytes) { t_bytes = bytes; }
+
 bool census_events(const char* kernel, hipStream_t stream, hipEvent_t* start, hipEvent_t* stop) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
@@ -155,6 +159,8 @@ bool census_events(const char* kernel, hipStream_t stream, hipEvent_t* start, hi
         k = it->second;
     }
     g_kernels[k].count += 1;
+    g_kernels[k].bytes += t_bytes;
+    t_bytes = 0.0;
     g_pending.push_back(Pending{ev.first, ev.second, k, g_tag, t_scope, t_group});
     *start = ev.first;
     *stop = ev.second;
@@ -199,6 +205,7 @@ extern "C" int fs_census_read_kernels(fs_kernel_time* out, int max_entries) {
         strncpy(out[k].name, fs::g_names[k].c_str(), sizeof(out[k].name) - 1);
         out[k].count = fs::g_kernels[k].count;
         out[k].ms = fs::g_kernels[k].ms;
+        out[k].bytes = fs::g_kernels[k].bytes;
     }
     return n;
 }

@@ -54,6 +54,14 @@ struct CensusGroupScope {     // a grouped launch: n entries counted, the launch
     ~CensusGroupScope();
 };
 bool census_events(const char* kernel, hipStream_t stream, hipEvent_t* start, hipEvent_t* stop);
+// ALGORITHMIC HBM bytes of the NEXT timed launch of this thread (the HBM-bound families: BatchNorm passes, resamples, weighted sums;
+// summed over the problems of a grouped launch): fs_census_read_kernels reports them per kernel beside launches and device time, so the
+// train-step roofline can price every family, not only the convolutions
+void census_note_bytes(double bytes);
+#define FS_NOTE_BYTES(expr)                                              \
+    do {                                                                 \
+        if (fs::g_census_on > 1) fs::census_note_bytes((double)(expr)); \
+    } while (0)
 #define FS_CENSUS(family, d) fs::CensusScope fs_census_scope_((family), (d))
 #define FS_LAUNCH(kernel, grid, block, shmem, stream, ...)                                                      \
     do {                                                                                                         \

@@ -2,6 +2,7 @@
 // LDS-DMA pipelined small-map kernel): launch arguments, MFMA wrappers, internal flags.
 #pragma once
 #include "common.h"
+#include "group.h"
 
 namespace fs {
 
@@ -68,7 +69,6 @@ bool igemm2_group_ok(const ConvArgs* a, int n, int dtype);
 fs_status conv_prepare(const fs_conv_desc* d, const void* x, const void* w_packed, const float* scale, const float* shift, void* y,
                        float* stats, ConvArgs* out);
 fs_status conv_launch_group(void* stream, const fs_conv_desc* const* descs, ConvArgs* args, int n);
-constexpr int FS_MAX_GROUP = 8;          // problems per grouped launch (their arguments travel as kernel arguments: < 4 KB)
 struct ConvGroupArgs {
     int n;
     int blk_start[FS_MAX_GROUP + 1];     // first workgroup of every problem, [n] = grid size

@@ -6,6 +6,7 @@
 // nn.ReLU (operations.py:74,147), torch.cat (operations.py:523; model_seg.py:307-331),
 // `result + op(x)*w*r0*r1` and beta-weighted sums (model_search.py:76-78,330-333).
 #include "common.h"
+#include "group.h"
 
 namespace fs {
 
@@ -114,15 +115,22 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(int C, int HW, const 
 // ---------------------------------------------------------------------------------------------------
 enum { EW_COPY = 0, EW_AFFINE = 1, EW_AXPY = 2, EW_AXPY_ACC = 3 };
 
+struct EwArgs {
+    long long pixels; int cv; const void* x; int x_cs; void* y; int y_cs; const float* scale; const float* shift; int relu;
+};
+
 template <typename T, int OP>
-__global__ void ew_kernel(long long pixels, int cv, const T* __restrict__ x, int x_cs, T* __restrict__ y, int y_cs,
-                          const float* __restrict__ scale, const float* __restrict__ shift, int relu) {
+__device__ __forceinline__ void ew_body(const EwArgs& a, int bx, int gx) {
     constexpr int VEC = Elem<T>::VEC;
-    const long long total = pixels * cv;
+    const T* __restrict__ x = (const T*)a.x;
+    T* __restrict__ y = (T*)a.y;
+    const float* __restrict__ scale = a.scale;
+    const float* __restrict__ shift = a.shift;
+    const int cv = a.cv, x_cs = a.x_cs, y_cs = a.y_cs, relu = a.relu;
+    const long long total = a.pixels * cv;
     float alpha = 1.f;
     if (OP == EW_AXPY || OP == EW_AXPY_ACC) alpha = scale[0];
-    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * blockDim.x) {
+    for (long long idx = bx * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gx * blockDim.x) {
         const long long pix = idx / cv;
         const int c = (int)(idx - pix * cv) * VEC;
         u32x4 v = ldg16(x + pix * x_cs + c);
@@ -151,6 +159,12 @@ __global__ void ew_kernel(long long pixels, int cv, const T* __restrict__ x, int
     }
 }
 
+template <typename T, int OP> __global__ void ew_kernel(EwArgs a) { ew_body<T, OP>(a, (int)blockIdx.x, (int)gridDim.x); }
+template <typename T, int OP> __global__ void ew_group_kernel(GroupOf<EwArgs> g) {
+    const int bid = (int)blockIdx.x, i = group_locate(g, bid);
+    ew_body<T, OP>(g.p[i], bid - g.blk_start[i], g.blk_start[i + 1] - g.blk_start[i]);
+}
+
 // Train-mode BN normalise pass with the statistics finalisation folded in: every thread derives scale/shift of its channel
 // vector from the raw (sum, sumsq) - a few flops - so the separate bn_finalize launch disappears; ONE extra block (block 0, which
 // takes no share of the map) publishes mean / invstd / scale / shift for the backward and updates running statistics and
@@ -159,16 +173,30 @@ __global__ void ew_kernel(long long pixels, int cv, const T* __restrict__ x, int
 // (24-100 blocks, 8.1 us average where the plain pass takes ~5); as a block of its own it runs beside the pass.
 // `groups` > 1: consecutive ranges of pixels/groups pixels are normalised independently (stats / saved hold one block of 2C / 4C
 // floats per group), running statistics take the groups' updates one after the other (fs_conv_desc.bn_groups).
+struct BnApplyArgs {
+    long long pixels; int cv; const void* x; int x_cs; const float* stats; float count; const float* gamma; const float* beta;
+    float eps, momentum; float* running_mean; float* running_var; long long* num_batches_tracked; float* saved; void* y; int y_cs;
+    int relu, groups;
+};
+
 template <typename T>
-__global__ void bn_train_apply_kernel(long long pixels, int cv, const T* __restrict__ x, int x_cs, const float* __restrict__ stats,
-                                      float count, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                      float momentum, float* running_mean, float* running_var, long long* num_batches_tracked,
-                                      float* __restrict__ saved, T* __restrict__ y, int y_cs, int relu, int groups) {
+__device__ __forceinline__ void bn_train_apply_body(const BnApplyArgs& a, int bx, int gx) {
     constexpr int VEC = Elem<T>::VEC;
+    const T* __restrict__ x = (const T*)a.x;
+    T* __restrict__ y = (T*)a.y;
+    const float* __restrict__ stats = a.stats;
+    const float* __restrict__ gamma = a.gamma;
+    const float* __restrict__ beta = a.beta;
+    float* running_mean = a.running_mean;
+    float* running_var = a.running_var;
+    float* __restrict__ saved = a.saved;
+    const int cv = a.cv, x_cs = a.x_cs, y_cs = a.y_cs, relu = a.relu, groups = a.groups;
+    const float count = a.count, eps = a.eps, momentum = a.momentum;
+    const long long pixels = a.pixels;
     const int C = cv * VEC;
     const long long mg = pixels / groups;
-    if (blockIdx.x == 0) {
-        if (threadIdx.x == 0) bump_batches_tracked(num_batches_tracked, relu, groups);
+    if (bx == 0) {
+        if (threadIdx.x == 0) bump_batches_tracked(a.num_batches_tracked, relu, groups);
         for (int c = threadIdx.x; c < C; c += blockDim.x) {
             const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
             float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 0.f;
@@ -192,8 +220,8 @@ __global__ void bn_train_apply_kernel(long long pixels, int cv, const T* __restr
         return;
     }
     const long long total = pixels * cv;
-    const long long stride = (long long)(gridDim.x - 1) * blockDim.x;
-    for (long long idx = (blockIdx.x - 1) * (long long)blockDim.x + threadIdx.x; idx < total; idx += stride) {
+    const long long stride = (long long)(gx - 1) * blockDim.x;
+    for (long long idx = (bx - 1) * (long long)blockDim.x + threadIdx.x; idx < total; idx += stride) {
         const long long pix = idx / cv;
         const int c = (int)(idx - pix * cv) * VEC;
         const float* stats_g = groups > 1 ? stats + (pix / mg) * 2 * C : stats;
@@ -212,39 +240,56 @@ __global__ void bn_train_apply_kernel(long long pixels, int cv, const T* __restr
     }
 }
 
+template <typename T> __global__ void bn_train_apply_kernel(BnApplyArgs a) { bn_train_apply_body<T>(a, (int)blockIdx.x, (int)gridDim.x); }
+template <typename T> __global__ void bn_train_apply_group_kernel(GroupOf<BnApplyArgs> g) {
+    const int bid = (int)blockIdx.x, i = group_locate(g, bid);
+    bn_train_apply_body<T>(g.p[i], bid - g.blk_start[i], g.blk_start[i + 1] - g.blk_start[i]);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // per-channel reductions over pixels.  Thread t owns vector column (t % cv) and pixel rows t/cv + k*rpb.
 // MODE 0: stats  -> out[c] += sum x, out[C+c] += sum x^2
 // MODE 1: bn bwd -> out[c] += sum dz, out[C+c] += sum dz*xhat   (dz = dy * [y>0])
 // ---------------------------------------------------------------------------------------------------
+struct ChanReduceArgs {
+    long long pixels; int C; const void* x; int x_cs; const void* dy; int dy_cs; const void* yo; int y_cs; const float* mean;
+    const float* invstd; int relu; float* out; long long pix_per_block, group_pixels; int saved_stride; float* part;
+    unsigned int* counters; int nbx;          // nbx: blocks per BatchNorm group (the grouped form folds (block, group) into one index)
+};
+
 template <typename T, int MODE>
-__global__ __launch_bounds__(256) void chan_reduce_kernel(long long pixels, int C, const T* __restrict__ x, int x_cs,
-                                                          const T* __restrict__ dy, int dy_cs, const T* __restrict__ yo,
-                                                          int y_cs, const float* __restrict__ mean,
-                                                          const float* __restrict__ invstd, int relu,
-                                                          float* __restrict__ out, long long pix_per_block, long long group_pixels,
-                                                          int saved_stride, float* __restrict__ part, unsigned int* counters) {
+__device__ __forceinline__ void chan_reduce_body(const ChanReduceArgs& a, int bx, int by, int nbx) {
     constexpr int VEC = Elem<T>::VEC;
     __shared__ float red[2][256][VEC + 1];
-    // blockIdx.y = group: its pixel range, its output slot (2C floats) and its saved (mean, invstd) block
-    const long long g_first = blockIdx.y * group_pixels;
-    out += (long long)blockIdx.y * 2 * C;
-    if (MODE == 1) { mean += (long long)blockIdx.y * saved_stride; invstd += (long long)blockIdx.y * saved_stride; }
-    pixels = g_first + group_pixels;
+    const T* __restrict__ x = (const T*)a.x;
+    const T* __restrict__ dy = (const T*)a.dy;
+    const T* __restrict__ yo = (const T*)a.yo;
+    const float* __restrict__ mean = a.mean;
+    const float* __restrict__ invstd = a.invstd;
+    float* __restrict__ out = a.out;
+    float* __restrict__ part = a.part;
+    unsigned int* counters = a.counters;
+    const int C = a.C, x_cs = a.x_cs, dy_cs = a.dy_cs, y_cs = a.y_cs, saved_stride = a.saved_stride;
+    const long long pix_per_block = a.pix_per_block, group_pixels = a.group_pixels;
+    // by = group: its pixel range, its output slot (2C floats) and its saved (mean, invstd) block
+    const long long g_first = by * group_pixels;
+    out += (long long)by * 2 * C;
+    if (MODE == 1) { mean += (long long)by * saved_stride; invstd += (long long)by * saved_stride; }
+    const long long pixels = g_first + group_pixels;
     const int cv = C / VEC;
     const int rpb = 256 / cv;            // pixel rows processed per iteration
     const int tid = threadIdx.x;
     const int col = tid % cv;
     const int row = tid / cv;
     const bool active = row < rpb;
-    relu = relu_at(relu, col * VEC) ? 1 : 0;
+    const int relu = relu_at(a.relu, col * VEC) ? 1 : 0;
     float a0[VEC], a1[VEC], mu[VEC], is[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
         a0[i] = 0.f; a1[i] = 0.f; mu[i] = 0.f; is[i] = 1.f;
         if (MODE == 1) { mu[i] = mean[col * VEC + i]; is[i] = invstd[col * VEC + i]; }
     }
-    const long long p_begin = g_first + blockIdx.x * pix_per_block;
+    const long long p_begin = g_first + bx * pix_per_block;
     long long p_end = p_begin + pix_per_block;
     if (p_end > pixels) p_end = pixels;
     if (active) {
@@ -287,8 +332,8 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(long long pixels, int 
     // and stores the totals.  Same bits whatever the block schedule; no float atomics.
     __shared__ int s_last;
     __shared__ float fin[8][33];
-    const int nb = gridDim.x;
-    float* mine = part + ((long long)blockIdx.y * nb + blockIdx.x) * 2 * C;
+    const int nb = nbx;
+    float* mine = part + ((long long)by * nb + bx) * 2 * C;
     for (int k = tid; k < 2 * C; k += 256) {
         const int which = k / C, c = k - which * C;
         const int cc = c / VEC, ci = c - cc * VEC;
@@ -296,8 +341,8 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(long long pixels, int 
         for (int r = 0; r < rpb; ++r) s += red[which][r * cv + cc][ci];
         store_coherent(mine + k, s);
     }
-    if (!arrive_last(&counters[blockIdx.y], (unsigned int)nb, &s_last)) return;
-    const float* all = part + (long long)blockIdx.y * nb * 2 * C;
+    if (!arrive_last(&counters[by], (unsigned int)nb, &s_last)) return;
+    const float* all = part + (long long)by * nb * 2 * C;
     const int fc = tid & 31, rg = tid >> 5;
     for (int k0 = 0; k0 < 2 * C; k0 += 32) {
         const int k = k0 + fc;
@@ -310,23 +355,49 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(long long pixels, int 
             out[k] = ((fin[0][fc] + fin[1][fc]) + (fin[2][fc] + fin[3][fc])) + ((fin[4][fc] + fin[5][fc]) + (fin[6][fc] + fin[7][fc]));
         __syncthreads();
     }
-    if (tid == 0) __hip_atomic_store(&counters[blockIdx.y], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_store(&counters[by], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+template <typename T, int MODE> __global__ __launch_bounds__(256) void chan_reduce_kernel(ChanReduceArgs a) {
+    chan_reduce_body<T, MODE>(a, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x);
+}
+// grouped form: float atomics only (the ordered reduction keeps its own launches); local block = group * nbx + block
+template <typename T, int MODE> __global__ __launch_bounds__(256) void chan_reduce_group_kernel(GroupOf<ChanReduceArgs> g) {
+    const int bid = (int)blockIdx.x, i = group_locate(g, bid);
+    const int local = bid - g.blk_start[i], nbx = g.p[i].nbx;
+    chan_reduce_body<T, MODE>(g.p[i], local % nbx, local / nbx, nbx);
+}
+
+struct BnBwdApplyArgs {
+    long long pixels; int cv; const void* x; int x_cs; const void* dy; int dy_cs; const void* yo; int y_cs; const float* mean;
+    const float* invstd; const float* gamma; const float* red; float inv_count; int relu; void* dx; int dx_cs; float* dgamma_acc;
+    float* dbeta_acc; int groups, saved_stride; float* red_total;
+};
+
 template <typename T>
-__global__ void bn_bwd_apply_kernel(long long pixels, int cv, const T* __restrict__ x, int x_cs, const T* __restrict__ dy,
-                                    int dy_cs, const T* __restrict__ yo, int y_cs, const float* __restrict__ mean,
-                                    const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                    const float* __restrict__ red, float inv_count, int relu, T* __restrict__ dx,
-                                    int dx_cs, float* dgamma_acc, float* dbeta_acc, int groups, int saved_stride,
-                                    float* __restrict__ red_total) {
+__device__ __forceinline__ void bn_bwd_apply_body(const BnBwdApplyArgs& a, int bx, int gx) {
     constexpr int VEC = Elem<T>::VEC;
+    const T* __restrict__ x = (const T*)a.x;
+    const T* __restrict__ dy = (const T*)a.dy;
+    const T* __restrict__ yo = (const T*)a.yo;
+    T* __restrict__ dx = (T*)a.dx;
+    const float* __restrict__ mean = a.mean;
+    const float* __restrict__ invstd = a.invstd;
+    const float* __restrict__ gamma = a.gamma;
+    const float* __restrict__ red = a.red;
+    float* dgamma_acc = a.dgamma_acc;
+    float* dbeta_acc = a.dbeta_acc;
+    float* __restrict__ red_total = a.red_total;
+    const int cv = a.cv, x_cs = a.x_cs, dy_cs = a.dy_cs, y_cs = a.y_cs, dx_cs = a.dx_cs, relu = a.relu, groups = a.groups,
+              saved_stride = a.saved_stride;
+    const float inv_count = a.inv_count;
+    const long long pixels = a.pixels;
     const int C = cv * VEC;
     const long long total = pixels * cv;
     const long long mg = pixels / groups;
     // block 0 takes no share of the map: parameter gradients (grad += this pass's reduction, summed over the groups in order; one
-    // block, plain RMW) beside the pass instead of in front of block 0's share of it (round 5, see bn_train_apply_kernel)
-    if (blockIdx.x == 0) {
+    // block, plain RMW) beside the pass instead of in front of block 0's share of it (round 5, see bn_train_apply_body)
+    if (bx == 0) {
         if (dgamma_acc || red_total)
             for (int c = threadIdx.x; c < C; c += blockDim.x) {
                 float dg = dgamma_acc ? dgamma_acc[c] : 0.f, db = dgamma_acc ? dbeta_acc[c] : 0.f;
@@ -346,8 +417,8 @@ __global__ void bn_bwd_apply_kernel(long long pixels, int cv, const T* __restric
             }
         return;
     }
-    const long long stride = (long long)(gridDim.x - 1) * blockDim.x;
-    for (long long idx = (blockIdx.x - 1) * (long long)blockDim.x + threadIdx.x; idx < total; idx += stride) {
+    const long long stride = (long long)(gx - 1) * blockDim.x;
+    for (long long idx = (bx - 1) * (long long)blockDim.x + threadIdx.x; idx < total; idx += stride) {
         const long long pix = idx / cv;
         const int c = (int)(idx - pix * cv) * VEC;
         const long long grp = groups > 1 ? pix / mg : 0;
@@ -371,6 +442,12 @@ __global__ void bn_bwd_apply_kernel(long long pixels, int cv, const T* __restric
         }
         stg16(dx + pix * dx_cs + c, Elem<T>::pack(f));
     }
+}
+
+template <typename T> __global__ void bn_bwd_apply_kernel(BnBwdApplyArgs a) { bn_bwd_apply_body<T>(a, (int)blockIdx.x, (int)gridDim.x); }
+template <typename T> __global__ void bn_bwd_apply_group_kernel(GroupOf<BnBwdApplyArgs> g) {
+    const int bid = (int)blockIdx.x, i = group_locate(g, bid);
+    bn_bwd_apply_body<T>(g.p[i], bid - g.blk_start[i], g.blk_start[i + 1] - g.blk_start[i]);
 }
 
 __global__ void bn_finalize_kernel(int C, float count, const float* __restrict__ stats, const float* __restrict__ gamma,
@@ -430,16 +507,22 @@ struct WsumOperands {
     int n;
 };
 
+struct WsumArgs {          // t: the output map (wsum) / the incoming gradient (wsum_bwd, wsum_dot); out: the dot products (wsum_dot)
+    long long pixels; int cv; WsumOperands a; const float* coef; void* t; int t_cs; float* out;
+};
+
 template <typename T>
-__global__ void wsum_kernel(long long pixels, int cv, WsumOperands a, const float* __restrict__ coef, T* __restrict__ out,
-                            int out_cs) {
+__device__ __forceinline__ void wsum_body(const WsumArgs& q, int bx, int gx) {
     constexpr int VEC = Elem<T>::VEC;
-    const long long total = pixels * cv;
+    const WsumOperands& a = q.a;
+    const float* __restrict__ coef = q.coef;
+    T* __restrict__ out = (T*)q.t;
+    const int cv = q.cv, out_cs = q.t_cs;
+    const long long total = q.pixels * cv;
     float w[FS_WSUM_MAX];
 #pragma unroll
     for (int k = 0; k < FS_WSUM_MAX; ++k) w[k] = k < a.n ? coef[k] : 0.f;
-    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * blockDim.x) {
+    for (long long idx = bx * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gx * blockDim.x) {
         const long long pix = idx / cv;
         const int c = (int)(idx - pix * cv) * VEC;
         float acc[VEC];
@@ -459,15 +542,17 @@ __global__ void wsum_kernel(long long pixels, int cv, WsumOperands a, const floa
 
 // dx_k = coef[k] * dy for every operand k with a non-null destination
 template <typename T>
-__global__ void wsum_bwd_kernel(long long pixels, int cv, const T* __restrict__ dy, int dy_cs, const float* __restrict__ coef,
-                                WsumOperands a) {
+__device__ __forceinline__ void wsum_bwd_body(const WsumArgs& q, int bx, int gx) {
     constexpr int VEC = Elem<T>::VEC;
-    const long long total = pixels * cv;
+    const WsumOperands& a = q.a;
+    const float* __restrict__ coef = q.coef;
+    const T* __restrict__ dy = (const T*)q.t;
+    const int cv = q.cv, dy_cs = q.t_cs;
+    const long long total = q.pixels * cv;
     float w[FS_WSUM_MAX];
 #pragma unroll
     for (int k = 0; k < FS_WSUM_MAX; ++k) w[k] = k < a.n ? coef[k] : 0.f;
-    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * blockDim.x) {
+    for (long long idx = bx * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gx * blockDim.x) {
         const long long pix = idx / cv;
         const int c = (int)(idx - pix * cv) * VEC;
         float g[VEC];
@@ -485,16 +570,18 @@ __global__ void wsum_bwd_kernel(long long pixels, int cv, const T* __restrict__ 
 
 // out[k] += <dy, x_k>: gradients of the n mixing coefficients in one pass over dy
 template <typename T>
-__global__ __launch_bounds__(256) void wsum_dot_kernel(long long pixels, int cv, const T* __restrict__ dy, int dy_cs,
-                                                       WsumOperands a, float* __restrict__ out) {
+__device__ __forceinline__ void wsum_dot_body(const WsumArgs& q, int bx, int gx) {
     constexpr int VEC = Elem<T>::VEC;
     __shared__ float part[FS_WSUM_MAX][4];
-    const long long total = pixels * cv;
+    const WsumOperands& a = q.a;
+    const T* __restrict__ dy = (const T*)q.t;
+    float* __restrict__ out = q.out;
+    const int cv = q.cv, dy_cs = q.t_cs;
+    const long long total = q.pixels * cv;
     float acc[FS_WSUM_MAX];
 #pragma unroll
     for (int k = 0; k < FS_WSUM_MAX; ++k) acc[k] = 0.f;
-    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * blockDim.x) {
+    for (long long idx = bx * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gx * blockDim.x) {
         const long long pix = idx / cv;
         const int c = (int)(idx - pix * cv) * VEC;
         float g[VEC];
@@ -516,6 +603,17 @@ __global__ __launch_bounds__(256) void wsum_dot_kernel(long long pixels, int cv,
     __syncthreads();
     if (threadIdx.x < a.n) atomicAdd(out + threadIdx.x, part[threadIdx.x][0] + part[threadIdx.x][1] + part[threadIdx.x][2] + part[threadIdx.x][3]);
 }
+
+#define FS_GROUPED_PAIR(name, body, bounds)                                                                                 \
+    template <typename T> __global__ bounds void name##_kernel(WsumArgs a) { body<T>(a, (int)blockIdx.x, (int)gridDim.x); } \
+    template <typename T> __global__ bounds void name##_group_kernel(GroupOf<WsumArgs> g) {                                 \
+        const int bid = (int)blockIdx.x, i = group_locate(g, bid);                                                          \
+        body<T>(g.p[i], bid - g.blk_start[i], g.blk_start[i + 1] - g.blk_start[i]);                                         \
+    }
+FS_GROUPED_PAIR(wsum, wsum_body, )
+FS_GROUPED_PAIR(wsum_bwd, wsum_bwd_body, )
+FS_GROUPED_PAIR(wsum_dot, wsum_dot_body, __launch_bounds__(256))
+#undef FS_GROUPED_PAIR
 
 static fs_status check_slice(const char* fn, const void* p, int cs, int C, int dtype) {
     const int vec = vec_elems(dtype);
@@ -580,8 +678,9 @@ extern "C" fs_status fs_copy_channels(void* stream, long long pixels, int C, con
     if ((s = check_slice("fs_copy_channels", x, x_cs, C, dtype)) != FS_OK) return s;
     if ((s = check_slice("fs_copy_channels", y, y_cs, C, dtype)) != FS_OK) return s;
     const int cv = C / vec_elems(dtype);
-    DT_DISPATCH(dtype, FS_LAUNCH((ew_kernel<T, EW_COPY>), dim3(grid_for(pixels * cv)), dim3(256), 0, (hipStream_t)stream,
-                                          pixels, cv, (const T*)x, x_cs, (T*)y, y_cs, nullptr, nullptr, 0);)
+    const EwArgs a{pixels, cv, x, x_cs, y, y_cs, nullptr, nullptr, 0};
+    FS_NOTE_BYTES((double)pixels * C * elem_size(dtype) * 2);
+    DT_DISPATCH(dtype, FS_LAUNCH((ew_kernel<T, EW_COPY>), dim3(grid_for(pixels * cv)), dim3(256), 0, (hipStream_t)stream, a);)
     return check_launch("fs_copy_channels");
 }
 
@@ -592,8 +691,9 @@ extern "C" fs_status fs_affine_act(void* stream, long long pixels, int C, const 
     if ((s = check_slice("fs_affine_act", y, y_cs, C, dtype)) != FS_OK) return s;
     FS_REQUIRE(scale && shift, FS_ERR_INVALID, "fs_affine_act: null scale/shift");
     const int cv = C / vec_elems(dtype);
-    DT_DISPATCH(dtype, FS_LAUNCH((ew_kernel<T, EW_AFFINE>), dim3(grid_for(pixels * cv)), dim3(256), 0,
-                                          (hipStream_t)stream, pixels, cv, (const T*)x, x_cs, (T*)y, y_cs, scale, shift, relu);)
+    const EwArgs a{pixels, cv, x, x_cs, y, y_cs, scale, shift, relu};
+    FS_NOTE_BYTES((double)pixels * C * elem_size(dtype) * 2);
+    DT_DISPATCH(dtype, FS_LAUNCH((ew_kernel<T, EW_AFFINE>), dim3(grid_for(pixels * cv)), dim3(256), 0, (hipStream_t)stream, a);)
     return check_launch("fs_affine_act");
 }
 
@@ -604,12 +704,12 @@ extern "C" fs_status fs_axpy_channels(void* stream, long long pixels, int C, con
     if ((s = check_slice("fs_axpy_channels", y, y_cs, C, dtype)) != FS_OK) return s;
     FS_REQUIRE(alpha, FS_ERR_INVALID, "fs_axpy_channels: null alpha");
     const int cv = C / vec_elems(dtype);
+    const EwArgs a{pixels, cv, x, x_cs, y, y_cs, alpha, nullptr, 0};
+    FS_NOTE_BYTES((double)pixels * C * elem_size(dtype) * (accumulate ? 3 : 2));
     if (accumulate) {
-        DT_DISPATCH(dtype, FS_LAUNCH((ew_kernel<T, EW_AXPY_ACC>), dim3(grid_for(pixels * cv)), dim3(256), 0,
-                                              (hipStream_t)stream, pixels, cv, (const T*)x, x_cs, (T*)y, y_cs, alpha, nullptr, 0);)
+        DT_DISPATCH(dtype, FS_LAUNCH((ew_kernel<T, EW_AXPY_ACC>), dim3(grid_for(pixels * cv)), dim3(256), 0, (hipStream_t)stream, a);)
     } else {
-        DT_DISPATCH(dtype, FS_LAUNCH((ew_kernel<T, EW_AXPY>), dim3(grid_for(pixels * cv)), dim3(256), 0,
-                                              (hipStream_t)stream, pixels, cv, (const T*)x, x_cs, (T*)y, y_cs, alpha, nullptr, 0);)
+        DT_DISPATCH(dtype, FS_LAUNCH((ew_kernel<T, EW_AXPY>), dim3(grid_for(pixels * cv)), dim3(256), 0, (hipStream_t)stream, a);)
     }
     return check_launch("fs_axpy_channels");
 }
@@ -659,9 +759,9 @@ extern "C" fs_status fs_channel_stats_ws(void* stream, long long pixels, int C, 
     int blocks = reduce_blocks(mg, 256 / cv, &ppb);
     float* part; unsigned int* counters;
     reduce_ws(workspace, workspace_bytes, groups, C, mg, 256 / cv, &blocks, &ppb, &part, &counters);
-    DT_DISPATCH(dtype, FS_LAUNCH((chan_reduce_kernel<T, 0>), dim3(blocks, groups), dim3(256), 0, (hipStream_t)stream, pixels, C,
-                                          (const T*)x, x_cs, (const T*)nullptr, 0, (const T*)nullptr, 0, nullptr, nullptr, 0,
-                                          stats, ppb, mg, 0, part, counters);)
+    const ChanReduceArgs a{pixels, C, x, x_cs, nullptr, 0, nullptr, 0, nullptr, nullptr, 0, stats, ppb, mg, 0, part, counters, blocks};
+    FS_NOTE_BYTES((double)pixels * C * elem_size(dtype));
+    DT_DISPATCH(dtype, FS_LAUNCH((chan_reduce_kernel<T, 0>), dim3(blocks, groups), dim3(256), 0, (hipStream_t)stream, a);)
     return check_launch("fs_channel_stats");
 }
 
@@ -701,9 +801,9 @@ extern "C" fs_status fs_bn_bwd_reduce_ws(void* stream, long long pixels, int C, 
     int blocks = reduce_blocks(mg, 256 / cv, &ppb);
     float* part; unsigned int* counters;
     reduce_ws(workspace, workspace_bytes, groups, C, mg, 256 / cv, &blocks, &ppb, &part, &counters);
-    DT_DISPATCH(dtype, FS_LAUNCH((chan_reduce_kernel<T, 1>), dim3(blocks, groups), dim3(256), 0, (hipStream_t)stream, pixels, C,
-                                          (const T*)x, x_cs, (const T*)dy, dy_cs, (const T*)y_out, y_cs, mean, invstd, relu, red,
-                                          ppb, mg, saved_stride, part, counters);)
+    const ChanReduceArgs a{pixels, C, x, x_cs, dy, dy_cs, y_out, y_cs, mean, invstd, relu, red, ppb, mg, saved_stride, part, counters, blocks};
+    FS_NOTE_BYTES((double)pixels * C * elem_size(dtype) * (relu ? 3 : 2));
+    DT_DISPATCH(dtype, FS_LAUNCH((chan_reduce_kernel<T, 1>), dim3(blocks, groups), dim3(256), 0, (hipStream_t)stream, a);)
     return check_launch("fs_bn_bwd_reduce");
 }
 
@@ -733,10 +833,10 @@ extern "C" fs_status fs_bn_bwd_apply_g(void* stream, long long pixels, int C, in
     FS_REQUIRE(mean && invstd && gamma && red && count > 0, FS_ERR_INVALID, "fs_bn_bwd_apply: bad argument");
     FS_REQUIRE(groups >= 1 && pixels % groups == 0, FS_ERR_INVALID, "fs_bn_bwd_apply: %lld pixels in %d groups", pixels, groups);
     const int cv = C / vec_elems(dtype);
-    DT_DISPATCH(dtype, FS_LAUNCH((bn_bwd_apply_kernel<T>), dim3(grid_for(pixels * cv) + 1), dim3(256), 0, (hipStream_t)stream,
-                                          pixels, cv, (const T*)x, x_cs, (const T*)dy, dy_cs, (const T*)y_out, y_cs, mean, invstd,
-                                          gamma, red, 1.0f / (float)count, relu, (T*)dx, dx_cs, dgamma_acc, dbeta_acc, groups,
-                                          saved_stride, red_total);)
+    const BnBwdApplyArgs a{pixels, cv, x, x_cs, dy, dy_cs, y_out, y_cs, mean, invstd, gamma, red, 1.0f / (float)count, relu, dx, dx_cs,
+                           dgamma_acc, dbeta_acc, groups, saved_stride, red_total};
+    FS_NOTE_BYTES((double)pixels * C * elem_size(dtype) * (relu ? 4 : 3));
+    DT_DISPATCH(dtype, FS_LAUNCH((bn_bwd_apply_kernel<T>), dim3(grid_for(pixels * cv) + 1), dim3(256), 0, (hipStream_t)stream, a);)
     return check_launch("fs_bn_bwd_apply");
 }
 
@@ -783,8 +883,9 @@ extern "C" fs_status fs_weighted_sum(void* stream, long long pixels, int C, int 
     if ((s = check_slice("fs_weighted_sum", out, out_cs, C, dtype)) != FS_OK) return s;
     FS_REQUIRE(coef, FS_ERR_INVALID, "fs_weighted_sum: null coefficients");
     const int cv = C / vec_elems(dtype);
-    DT_DISPATCH(dtype, FS_LAUNCH((wsum_kernel<T>), dim3(grid_for(pixels * cv)), dim3(256), 0, (hipStream_t)stream, pixels,
-                                          cv, a, coef, (T*)out, out_cs);)
+    const WsumArgs q{pixels, cv, a, coef, out, out_cs, nullptr};
+    FS_NOTE_BYTES((double)pixels * C * elem_size(dtype) * (n + 1));
+    DT_DISPATCH(dtype, FS_LAUNCH((wsum_kernel<T>), dim3(grid_for(pixels * cv)), dim3(256), 0, (hipStream_t)stream, q);)
     return check_launch("fs_weighted_sum");
 }
 
@@ -796,8 +897,9 @@ extern "C" fs_status fs_weighted_sum_bwd(void* stream, long long pixels, int C, 
     if ((s = check_slice("fs_weighted_sum_bwd", dy, dy_cs, C, dtype)) != FS_OK) return s;
     FS_REQUIRE(coef, FS_ERR_INVALID, "fs_weighted_sum_bwd: null coefficients");
     const int cv = C / vec_elems(dtype);
-    DT_DISPATCH(dtype, FS_LAUNCH((wsum_bwd_kernel<T>), dim3(grid_for(pixels * cv)), dim3(256), 0, (hipStream_t)stream,
-                                          pixels, cv, (const T*)dy, dy_cs, coef, a);)
+    const WsumArgs q{pixels, cv, a, coef, const_cast<void*>(dy), dy_cs, nullptr};
+    FS_NOTE_BYTES((double)pixels * C * elem_size(dtype) * (n + 1));
+    DT_DISPATCH(dtype, FS_LAUNCH((wsum_bwd_kernel<T>), dim3(grid_for(pixels * cv)), dim3(256), 0, (hipStream_t)stream, q);)
     return check_launch("fs_weighted_sum_bwd");
 }
 
@@ -809,8 +911,9 @@ extern "C" fs_status fs_weighted_sum_dots(void* stream, long long pixels, int C,
     if ((s = check_slice("fs_weighted_sum_dots", dy, dy_cs, C, dtype)) != FS_OK) return s;
     FS_REQUIRE(out, FS_ERR_INVALID, "fs_weighted_sum_dots: null out");
     const int cv = C / vec_elems(dtype);
-    DT_DISPATCH(dtype, FS_LAUNCH((wsum_dot_kernel<T>), dim3(grid_for(pixels * cv, 256, 1024)), dim3(256), 0,
-                                          (hipStream_t)stream, pixels, cv, (const T*)dy, dy_cs, a, out);)
+    const WsumArgs q{pixels, cv, a, nullptr, const_cast<void*>(dy), dy_cs, out};
+    FS_NOTE_BYTES((double)pixels * C * elem_size(dtype) * (n + 1));
+    DT_DISPATCH(dtype, FS_LAUNCH((wsum_dot_kernel<T>), dim3(grid_for(pixels * cv, 256, 1024)), dim3(256), 0, (hipStream_t)stream, q);)
     return check_launch("fs_weighted_sum_dots");
 }
 
@@ -824,9 +927,10 @@ extern "C" fs_status fs_bn_train_apply_g(void* stream, long long pixels, int C, 
     FS_REQUIRE(stats && saved && pixels > 0, FS_ERR_INVALID, "fs_bn_train_apply: bad argument");
     FS_REQUIRE(groups >= 1 && pixels % groups == 0, FS_ERR_INVALID, "fs_bn_train_apply: %lld pixels in %d groups", pixels, groups);
     const int cv = C / vec_elems(dtype);
-    DT_DISPATCH(dtype, FS_LAUNCH((bn_train_apply_kernel<T>), dim3(grid_for(pixels * cv) + 1), dim3(256), 0, (hipStream_t)stream,
-                                          pixels, cv, (const T*)x, x_cs, stats, (float)(pixels / groups), gamma, beta, eps, momentum,
-                                          running_mean, running_var, num_batches_tracked, saved, (T*)y, y_cs, relu, groups);)
+    const BnApplyArgs a{pixels, cv, x, x_cs, stats, (float)(pixels / groups), gamma, beta, eps, momentum, running_mean, running_var,
+                        num_batches_tracked, saved, y, y_cs, relu, groups};
+    FS_NOTE_BYTES((double)pixels * C * elem_size(dtype) * 2);
+    DT_DISPATCH(dtype, FS_LAUNCH((bn_train_apply_kernel<T>), dim3(grid_for(pixels * cv) + 1), dim3(256), 0, (hipStream_t)stream, a);)
     return check_launch("fs_bn_train_apply");
 }
 
@@ -836,4 +940,223 @@ extern "C" fs_status fs_bn_train_apply(void* stream, long long pixels, int C, co
                                        int dtype, int relu) {
     return fs_bn_train_apply_g(stream, pixels, C, 1, x, x_cs, stats, gamma, beta, eps, momentum, running_mean, running_var,
                                num_batches_tracked, saved, y, y_cs, dtype, relu);
+}
+
+// ---- grouped forms (group.h): the same kernels over up to FS_MAX_GROUP problems per launch ------------------------------------------
+// Validation and launch geometry are those of the single entry points above; calls of different dtype (or, for the axpy, mode) go out in
+// separate launches, a bucket of one through the single-problem kernel.
+namespace {
+
+template <typename A> struct Packed {
+    GroupOf<A> g;
+    int grid;
+    Packed() : grid(0) { g.n = 0; }
+    void add(const A& a, int blocks) {
+        g.blk_start[g.n] = grid;
+        g.p[g.n++] = a;
+        grid += blocks;
+    }
+    void close() { for (int i = g.n; i <= FS_MAX_GROUP; ++i) g.blk_start[i] = grid; }
+};
+
+static fs_status prep_stats(const BnFwdCall& c, ChanReduceArgs* a, int* blocks) {
+    fs_status s;
+    if ((s = check_slice("fs_channel_stats", c.z, c.z_cs, c.C, c.dtype)) != FS_OK) return s;
+    FS_REQUIRE(c.stats, FS_ERR_INVALID, "fs_channel_stats: null stats");
+    FS_REQUIRE(c.groups >= 1 && c.pixels % c.groups == 0, FS_ERR_INVALID, "fs_channel_stats: %lld pixels in %d groups", c.pixels, c.groups);
+    const int cv = c.C / vec_elems(c.dtype);
+    FS_REQUIRE(cv <= 256, FS_ERR_UNSUPPORTED, "fs_channel_stats: C=%d too large", c.C);
+    long long ppb;
+    const long long mg = c.pixels / c.groups;
+    const int nbx = reduce_blocks(mg, 256 / cv, &ppb);
+    *a = ChanReduceArgs{c.pixels, c.C, c.z, c.z_cs, nullptr, 0, nullptr, 0, nullptr, nullptr, 0, c.stats, ppb, mg, 0, nullptr, nullptr, nbx};
+    *blocks = nbx * c.groups;
+    return FS_OK;
+}
+
+static fs_status prep_apply(const BnFwdCall& c, BnApplyArgs* a, int* blocks) {
+    fs_status s;
+    if ((s = check_slice("fs_bn_train_apply", c.z, c.z_cs, c.C, c.dtype)) != FS_OK) return s;
+    if ((s = check_slice("fs_bn_train_apply", c.y, c.y_cs, c.C, c.dtype)) != FS_OK) return s;
+    FS_REQUIRE(c.stats && c.saved && c.pixels > 0, FS_ERR_INVALID, "fs_bn_train_apply: bad argument");
+    FS_REQUIRE(c.groups >= 1 && c.pixels % c.groups == 0, FS_ERR_INVALID, "fs_bn_train_apply: %lld pixels in %d groups", c.pixels, c.groups);
+    const int cv = c.C / vec_elems(c.dtype);
+    *a = BnApplyArgs{c.pixels, cv, c.z, c.z_cs, c.stats, (float)(c.pixels / c.groups), c.gamma, c.beta, c.eps, c.momentum, c.running_mean,
+                     c.running_var, c.num_batches_tracked, c.saved, c.y, c.y_cs, c.relu, c.groups};
+    *blocks = grid_for(c.pixels * cv) + 1;
+    return FS_OK;
+}
+
+static fs_status check_bwd(const char* fn, const BnBwdCall& c) {
+    fs_status s;
+    if ((s = check_slice(fn, c.z, c.z_cs, c.C, c.dtype)) != FS_OK) return s;
+    if ((s = check_slice(fn, c.dy, c.dy_cs, c.C, c.dtype)) != FS_OK) return s;
+    if (c.relu && (s = check_slice(fn, c.y, c.y_cs, c.C, c.dtype)) != FS_OK) return s;
+    FS_REQUIRE(c.saved && c.red && c.gamma, FS_ERR_INVALID, "%s: null pointer", fn);
+    FS_REQUIRE(c.groups >= 1 && c.pixels > 0 && c.pixels % c.groups == 0, FS_ERR_INVALID, "%s: %lld pixels in %d groups", fn, c.pixels, c.groups);
+    return FS_OK;
+}
+
+static fs_status prep_bwd_reduce(const BnBwdCall& c, ChanReduceArgs* a, int* blocks) {
+    const fs_status s = check_bwd("fs_bn_bwd_reduce", c);
+    if (s != FS_OK) return s;
+    const int cv = c.C / vec_elems(c.dtype);
+    FS_REQUIRE(cv <= 256, FS_ERR_UNSUPPORTED, "fs_bn_bwd_reduce: C=%d too large", c.C);
+    long long ppb;
+    const long long mg = c.pixels / c.groups;
+    const int nbx = reduce_blocks(mg, 256 / cv, &ppb);
+    float* part = c.groups > 1 ? c.red + 2 * c.C : c.red;          // red = [2][C] totals, then (groups > 1) [groups][2][C] zeroed partials
+    *a = ChanReduceArgs{c.pixels, c.C, c.z, c.z_cs, c.dy, c.dy_cs, c.y, c.y_cs, c.saved, c.saved + c.C, c.relu, part, ppb, mg, 4 * c.C, nullptr,
+                        nullptr, nbx};
+    *blocks = nbx * c.groups;
+    return FS_OK;
+}
+
+static fs_status prep_bwd_apply(const BnBwdCall& c, BnBwdApplyArgs* a, int* blocks) {
+    fs_status s = check_bwd("fs_bn_bwd_apply", c);
+    if (s != FS_OK) return s;
+    if ((s = check_slice("fs_bn_bwd_apply", c.dz, c.dz_cs, c.C, c.dtype)) != FS_OK) return s;
+    FS_REQUIRE((c.dgamma_acc == nullptr) == (c.dbeta_acc == nullptr), FS_ERR_INVALID, "fs_bn_bwd_apply: dgamma_acc/dbeta_acc go together");
+    const int cv = c.C / vec_elems(c.dtype);
+    const float* part = c.groups > 1 ? c.red + 2 * c.C : c.red;
+    *a = BnBwdApplyArgs{c.pixels, cv, c.z, c.z_cs, c.dy, c.dy_cs, c.y, c.y_cs, c.saved, c.saved + c.C, c.gamma, part,
+                        1.0f / (float)(c.pixels / c.groups), c.relu, c.dz, c.dz_cs, c.dgamma_acc, c.dbeta_acc, c.groups, 4 * c.C,
+                        c.groups > 1 ? c.red : nullptr};
+    *blocks = grid_for(c.pixels * cv) + 1;
+    return FS_OK;
+}
+
+}  // namespace
+
+template <typename CallT, typename ArgsT, typename Prep, typename Launch>
+static fs_status group_driver(const CallT* c, const int* idx, int n, const char* what, int passes, int relu_passes, Prep prep, Launch launch) {
+    return for_each_bucket(n, [&](int i) { return (long long)c[idx[i]].dtype; }, [&](const int* sub, int m) -> fs_status {
+        Packed<ArgsT> pk;
+        double bytes = 0;          // algorithmic: `passes` tensor passes per problem (+ relu_passes when the unit is rectified)
+        for (int j = 0; j < m; ++j) {
+            ArgsT a;
+            int blocks;
+            const CallT& q = c[idx[sub[j]]];
+            const fs_status s = prep(q, &a, &blocks);
+            if (s != FS_OK) return s;
+            pk.add(a, blocks);
+            bytes += (double)q.pixels * q.C * elem_size(q.dtype) * (passes + (q.relu ? relu_passes : 0));
+        }
+        pk.close();
+        FS_NOTE_BYTES(bytes);
+        const int dtype = c[idx[sub[0]]].dtype;
+        FS_REQUIRE(dtype == FS_F32 || dtype == FS_BF16, FS_ERR_INVALID, "%s: bad dtype", what);
+        launch(dtype, pk, m);
+        return check_launch(what);
+    });
+}
+
+fs_status fs::bn_stats_group(void* stream, const BnFwdCall* c, const int* idx, int n) {
+    hipStream_t st = (hipStream_t)stream;
+    return group_driver<BnFwdCall, ChanReduceArgs>(c, idx, n, "fs_channel_stats", 1, 0, prep_stats, [&](int dtype, const Packed<ChanReduceArgs>& pk, int m) {
+        const ChanReduceArgs& a = pk.g.p[0];
+        if (m == 1) { DT_DISPATCH(dtype, FS_LAUNCH((chan_reduce_kernel<T, 0>), dim3(a.nbx, pk.grid / a.nbx), dim3(256), 0, st, a);) }
+        else { DT_DISPATCH(dtype, FS_LAUNCH((chan_reduce_group_kernel<T, 0>), dim3(pk.grid), dim3(256), 0, st, pk.g);) }
+    });
+}
+
+fs_status fs::bn_apply_group(void* stream, const BnFwdCall* c, const int* idx, int n) {
+    hipStream_t st = (hipStream_t)stream;
+    return group_driver<BnFwdCall, BnApplyArgs>(c, idx, n, "fs_bn_train_apply", 2, 0, prep_apply, [&](int dtype, const Packed<BnApplyArgs>& pk, int m) {
+        const BnApplyArgs& a = pk.g.p[0];
+        if (m == 1) { DT_DISPATCH(dtype, FS_LAUNCH((bn_train_apply_kernel<T>), dim3(pk.grid), dim3(256), 0, st, a);) }
+        else { DT_DISPATCH(dtype, FS_LAUNCH((bn_train_apply_group_kernel<T>), dim3(pk.grid), dim3(256), 0, st, pk.g);) }
+    });
+}
+
+fs_status fs::bn_bwd_reduce_group(void* stream, const BnBwdCall* c, const int* idx, int n) {
+    hipStream_t st = (hipStream_t)stream;
+    return group_driver<BnBwdCall, ChanReduceArgs>(c, idx, n, "fs_bn_bwd_reduce", 2, 1, prep_bwd_reduce, [&](int dtype, const Packed<ChanReduceArgs>& pk, int m) {
+        const ChanReduceArgs& a = pk.g.p[0];
+        if (m == 1) { DT_DISPATCH(dtype, FS_LAUNCH((chan_reduce_kernel<T, 1>), dim3(a.nbx, pk.grid / a.nbx), dim3(256), 0, st, a);) }
+        else { DT_DISPATCH(dtype, FS_LAUNCH((chan_reduce_group_kernel<T, 1>), dim3(pk.grid), dim3(256), 0, st, pk.g);) }
+    });
+}
+
+fs_status fs::bn_bwd_apply_group(void* stream, const BnBwdCall* c, const int* idx, int n) {
+    hipStream_t st = (hipStream_t)stream;
+    return group_driver<BnBwdCall, BnBwdApplyArgs>(c, idx, n, "fs_bn_bwd_apply", 3, 1, prep_bwd_apply, [&](int dtype, const Packed<BnBwdApplyArgs>& pk, int m) {
+        const BnBwdApplyArgs& a = pk.g.p[0];
+        if (m == 1) { DT_DISPATCH(dtype, FS_LAUNCH((bn_bwd_apply_kernel<T>), dim3(pk.grid), dim3(256), 0, st, a);) }
+        else { DT_DISPATCH(dtype, FS_LAUNCH((bn_bwd_apply_group_kernel<T>), dim3(pk.grid), dim3(256), 0, st, pk.g);) }
+    });
+}
+
+// weighted sums: mode 0 out = sum_k coef[k] x_k, 1 dx_k = coef[k] dy, 2 out[k] += <dy, x_k>
+static fs_status wsum_any_group(void* stream, const WsumCall* c, int n, int mode) {
+    static const char* const names[3] = {"fs_weighted_sum", "fs_weighted_sum_bwd", "fs_weighted_sum_dots"};
+    const char* fn = names[mode];
+    return for_each_bucket(n, [&](int i) { return (long long)c[i].dtype; }, [&](const int* sub, int m) -> fs_status {
+        Packed<WsumArgs> pk;
+        double bytes = 0;
+        for (int j = 0; j < m; ++j) {
+            const WsumCall& q = c[sub[j]];
+            fs_status s;
+            WsumArgs a;
+            if ((s = wsum_operands(fn, q.n, q.ptrs, q.cs, q.C, q.dtype, mode == 1, &a.a)) != FS_OK) return s;
+            if ((s = check_slice(fn, q.t, q.t_cs, q.C, q.dtype)) != FS_OK) return s;
+            FS_REQUIRE(mode == 2 ? q.out != nullptr : q.coef != nullptr, FS_ERR_INVALID, "%s: null %s", fn, mode == 2 ? "out" : "coefficients");
+            const int cv = q.C / vec_elems(q.dtype);
+            a.pixels = q.pixels; a.cv = cv; a.coef = q.coef; a.t = const_cast<void*>(q.t); a.t_cs = q.t_cs; a.out = q.out;
+            pk.add(a, mode == 2 ? grid_for(q.pixels * cv, 256, 1024) : grid_for(q.pixels * cv));
+            bytes += (double)q.pixels * q.C * elem_size(q.dtype) * (q.n + 1);
+        }
+        pk.close();
+        FS_NOTE_BYTES(bytes);
+        const int dtype = c[sub[0]].dtype;
+        FS_REQUIRE(dtype == FS_F32 || dtype == FS_BF16, FS_ERR_INVALID, "%s: bad dtype", fn);
+        hipStream_t st = (hipStream_t)stream;
+        if (m == 1) {
+            const WsumArgs& a = pk.g.p[0];
+            if (mode == 0) { DT_DISPATCH(dtype, FS_LAUNCH((wsum_kernel<T>), dim3(pk.grid), dim3(256), 0, st, a);) }
+            else if (mode == 1) { DT_DISPATCH(dtype, FS_LAUNCH((wsum_bwd_kernel<T>), dim3(pk.grid), dim3(256), 0, st, a);) }
+            else { DT_DISPATCH(dtype, FS_LAUNCH((wsum_dot_kernel<T>), dim3(pk.grid), dim3(256), 0, st, a);) }
+        } else {
+            if (mode == 0) { DT_DISPATCH(dtype, FS_LAUNCH((wsum_group_kernel<T>), dim3(pk.grid), dim3(256), 0, st, pk.g);) }
+            else if (mode == 1) { DT_DISPATCH(dtype, FS_LAUNCH((wsum_bwd_group_kernel<T>), dim3(pk.grid), dim3(256), 0, st, pk.g);) }
+            else { DT_DISPATCH(dtype, FS_LAUNCH((wsum_dot_group_kernel<T>), dim3(pk.grid), dim3(256), 0, st, pk.g);) }
+        }
+        return check_launch(fn);
+    });
+}
+
+fs_status fs::wsum_group(void* stream, const WsumCall* c, int n) { return wsum_any_group(stream, c, n, 0); }
+fs_status fs::wsum_bwd_group(void* stream, const WsumCall* c, int n) { return wsum_any_group(stream, c, n, 1); }
+fs_status fs::wsum_dots_group(void* stream, const WsumCall* c, int n) { return wsum_any_group(stream, c, n, 2); }
+
+fs_status fs::axpy_group(void* stream, const AxpyCall* c, int n) {
+    return for_each_bucket(n, [&](int i) { return (long long)c[i].dtype * 2 + (c[i].accumulate ? 1 : 0); }, [&](const int* sub, int m) -> fs_status {
+        Packed<EwArgs> pk;
+        double bytes = 0;
+        for (int j = 0; j < m; ++j) {
+            const AxpyCall& q = c[sub[j]];
+            fs_status s;
+            if ((s = check_slice("fs_axpy_channels", q.x, q.x_cs, q.C, q.dtype)) != FS_OK) return s;
+            if ((s = check_slice("fs_axpy_channels", q.y, q.y_cs, q.C, q.dtype)) != FS_OK) return s;
+            FS_REQUIRE(q.alpha, FS_ERR_INVALID, "fs_axpy_channels: null alpha");
+            const int cv = q.C / vec_elems(q.dtype);
+            pk.add(EwArgs{q.pixels, cv, q.x, q.x_cs, q.y, q.y_cs, q.alpha, nullptr, 0}, grid_for(q.pixels * cv));
+            bytes += (double)q.pixels * q.C * elem_size(q.dtype) * (q.accumulate ? 3 : 2);
+        }
+        pk.close();
+        FS_NOTE_BYTES(bytes);
+        const int dtype = c[sub[0]].dtype;
+        FS_REQUIRE(dtype == FS_F32 || dtype == FS_BF16, FS_ERR_INVALID, "fs_axpy_channels: bad dtype");
+        hipStream_t st = (hipStream_t)stream;
+        const bool acc = c[sub[0]].accumulate != 0;
+        if (m == 1) {
+            const EwArgs& a = pk.g.p[0];
+            if (acc) { DT_DISPATCH(dtype, FS_LAUNCH((ew_kernel<T, EW_AXPY_ACC>), dim3(pk.grid), dim3(256), 0, st, a);) }
+            else { DT_DISPATCH(dtype, FS_LAUNCH((ew_kernel<T, EW_AXPY>), dim3(pk.grid), dim3(256), 0, st, a);) }
+        } else {
+            if (acc) { DT_DISPATCH(dtype, FS_LAUNCH((ew_group_kernel<T, EW_AXPY_ACC>), dim3(pk.grid), dim3(256), 0, st, pk.g);) }
+            else { DT_DISPATCH(dtype, FS_LAUNCH((ew_group_kernel<T, EW_AXPY>), dim3(pk.grid), dim3(256), 0, st, pk.g);) }
+        }
+        return check_launch("fs_axpy_channels");
+    });
 }

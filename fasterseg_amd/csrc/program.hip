@@ -21,6 +21,7 @@
 // gradients and their two data gradients are one launch each instead of two (round 5).
 #include <string.h>
 #include "conv_igemm.h"
+#include "group.h"
 
 using fs::FS_MAX_GROUP;
 
@@ -247,6 +248,71 @@ fs_status st = FS_OK;
     return st;
 }
 
+// n <= FS_MAX_GROUP independent commands of one op whose kernels have grouped forms (group.h): BatchNorm units, bilinear resamples,
+// weighted sums, axpy.  Returns FS_ERR_UNSUPPORTED (nothing issued, no error text) when the op has no grouped form.
+static fs_status run_grouped_ew(int op, int nargs, Args* const* q, int n, void* stream) {
+    using namespace fs;
+    switch (op) {
+        case FS_OP_BN_UNIT_FWD: {
+            if (nargs != 20) return FS_ERR_UNSUPPORTED;
+            BnFwdCall c[FS_MAX_GROUP];
+            for (int i = 0; i < n; ++i) {
+                Args& a = *q[i];
+                c[i] = BnFwdCall{L(0), I(1), I(2), P(3), I(4), PF(5), PF(6), F(7), F(8), PF(9), PF(10), (long long*)P(11), PF(12), PF(13), P(14), I(15),
+                                 I(16), I(17), P(18), L(19), 0};
+            }
+            return bn_fwd_group(stream, c, n);
+        }
+        case FS_OP_BN_UNIT_BWD: {
+            if (nargs != 20) return FS_ERR_UNSUPPORTED;
+            BnBwdCall c[FS_MAX_GROUP];
+            for (int i = 0; i < n; ++i) {
+                Args& a = *q[i];
+                c[i] = BnBwdCall{L(0), I(1), I(2), P(3), I(4), P(5), I(6), P(7), I(8), PF(9), PF(10), PF(11), I(12), I(13), P(14), I(15), PF(16), PF(17),
+                                 P(18), L(19)};
+            }
+            return bn_bwd_group(stream, c, n);
+        }
+        case FS_OP_BILINEAR_FWD: {
+            if (nargs != 3) return FS_ERR_UNSUPPORTED;
+            ResizeCall c[FS_MAX_GROUP];
+            for (int i = 0; i < n; ++i) { Args& a = *q[i]; c[i] = ResizeCall{(const fs_resize_desc*)P(0), P(1), nullptr, P(2)}; }
+            return bilinear_fwd_group(stream, c, n);
+        }
+        case FS_OP_BILINEAR_BWD: {
+            if (nargs != 4) return FS_ERR_UNSUPPORTED;
+            ResizeCall c[FS_MAX_GROUP];
+            for (int i = 0; i < n; ++i) { Args& a = *q[i]; c[i] = ResizeCall{(const fs_resize_desc*)P(0), P(1), P(2), P(3)}; }
+            return bilinear_bwd_group(stream, c, n);
+        }
+        case FS_OP_WSUM: {
+            if (nargs != 9) return FS_ERR_UNSUPPORTED;
+            WsumCall c[FS_MAX_GROUP];
+            for (int i = 0; i < n; ++i) { Args& a = *q[i]; c[i] = WsumCall{L(0), I(1), I(2), (const void* const*)P(3), (const int*)P(4), P(6), I(7), PF(5), nullptr, I(8)}; }
+            return wsum_group(stream, c, n);
+        }
+        case FS_OP_WSUM_BWD: {
+            if (nargs != 9) return FS_ERR_UNSUPPORTED;
+            WsumCall c[FS_MAX_GROUP];
+            for (int i = 0; i < n; ++i) { Args& a = *q[i]; c[i] = WsumCall{L(0), I(1), I(2), (const void* const*)P(6), (const int*)P(7), P(3), I(4), PF(5), nullptr, I(8)}; }
+            return wsum_bwd_group(stream, c, n);
+        }
+        case FS_OP_WSUM_DOTS: {
+            if (nargs != 9) return FS_ERR_UNSUPPORTED;
+            WsumCall c[FS_MAX_GROUP];
+            for (int i = 0; i < n; ++i) { Args& a = *q[i]; c[i] = WsumCall{L(0), I(1), I(2), (const void* const*)P(5), (const int*)P(6), P(3), I(4), nullptr, PF(8), I(7)}; }
+            return wsum_dots_group(stream, c, n);
+        }
+        case FS_OP_AXPY: {
+            if (nargs != 9) return FS_ERR_UNSUPPORTED;
+            AxpyCall c[FS_MAX_GROUP];
+            for (int i = 0; i < n; ++i) { Args& a = *q[i]; c[i] = AxpyCall{L(0), I(1), P(2), I(3), PF(4), P(5), I(6), I(7), I(8)}; }
+            return axpy_group(stream, c, n);
+        }
+        default: return FS_ERR_UNSUPPORTED;
+    }
+}
+
 // n commands of one op that do not depend on each other (a JOIN run, or the same command of several lockstep programs): bare
 // convolutions and strided weight gradients as grouped launches of up to FS_MAX_GROUP problems, anything else one by one
 constexpr int MAX_POOL = 2 * FS_MAX_GROUP;
@@ -312,73 +378,143 @@ extern "C" fs_status fs_exec_program_streams(void* const* streams, int n_streams
     return FS_OK;
 }
 
-// Lockstep execution of k programs of IDENTICAL command structure (the MixedOps of one supernet layer, reference
-// search/model_search.py:310-333: they only depend on the previous layer) on one stream: command j of all programs is issued
-// together, and where that command is a conv -> BN unit (forward or backward) or a bare convolution / weight gradient, the k
-// convolutions (weight gradients, data gradients) go out as ONE grouped launch.  The supernet step is the sum of its kernel durations
-// and a 10 us convolution on 100 - 600 workgroups pays ~4 us of ramp-up / drain + boundary: k of them in one launch pay it once and fill
-// the 256 CUs.  Everything else (BatchNorm, resamples, weighted sums) is issued program after program.
+// Layer execution: k independent programs (the MixedOps of one supernet layer, reference search/model_search.py:310-333: they only
+// depend on the previous layer) on ONE stream, scheduled command by command so that commands of the same kind go out as ONE grouped
+// launch.  Round 4 required identical command structure (lockstep) and grouped the convolutions; round 6 drops the requirement and groups
+// every kernel a MixedOp launches (group.h): each round looks at the next pending command ("head") of every program, picks the op kind
+// with the lowest rank among them and issues the heads of that kind together - conv -> BN units forward / backward (grouped convolution,
+// grouped BatchNorm passes, grouped weight and data gradients), bare convolutions / weight gradients (JOIN runs of all programs pooled),
+// BatchNorm units, bilinear resamples, weighted sums, axpy; an op without a grouped form is issued program after program.  The rank
+// order (cheap early ops first, the closing weighted sum last) makes programs of different structure - stride-1 and stride-2 MixedOps,
+// with or without an input gradient - meet at their common commands: per layer and direction ~25 launches instead of ~17-25 per MixedOp.
+// Program order is preserved inside every program, which is all correctness needs.  The supernet step is the sum of its kernel durations
+// and every launch pays ~4 us of ramp-up / drain + boundary whatever its size; one stream also means a LINEAR captured graph, which
+// ROCm replays at ~0.5 us of host time per node instead of ~4 us for a forked one.
+constexpr int MAX_LAYER = 2 * FS_MAX_GROUP;        // programs per call
+
+static inline int op_rank(int op) {
+    switch (op) {
+        case FS_OP_PACK_WEIGHT: case FS_OP_MEMSET: return 0;
+        case FS_OP_CONV_FWD: return 1;
+        case FS_OP_BN_UNIT_FWD: return 2;
+        case FS_OP_UNIT_FWD: return 3;
+        case FS_OP_BILINEAR_FWD: return 4;
+        case FS_OP_WSUM_DOTS: return 5;
+        case FS_OP_WSUM_BWD: return 6;
+        case FS_OP_BILINEAR_BWD: return 8;
+        case FS_OP_UNIT_BWD: return 9;
+        case FS_OP_BN_UNIT_BWD: return 10;
+        case FS_OP_WGRAD_STRIDED: return 11;
+        case FS_OP_AXPY: return 12;
+        case FS_OP_WSUM: return 13;
+        default: return 7;
+    }
+}
+
+// array arguments (kinds 4, 5) of a COPIED record point into the source record: re-point them at the copy's own storage
+static inline void repoint_arrays(Args& dst, int nargs) {
+    int narr = 0;
+    for (int j = 0; j < nargs; ++j) {
+        if (dst.kind[j] == 4) dst.pv[j] = (void*)dst.parr[narr++];
+        else if (dst.kind[j] == 5) dst.pv[j] = (void*)dst.iarr[narr++];
+    }
+}
+
+// m <= FS_MAX_GROUP independent commands of one (op, nargs), none of them joined
+static fs_status run_same_op(int op, int nargs, Args* const* q, int m, void* stream, int index) {
+    fs_status st = FS_OK;
+    if (m > 1 && op == FS_OP_UNIT_FWD && nargs == 16) {
+        fs::UnitFwdCall u[FS_MAX_GROUP];
+        for (int i = 0; i < m; ++i) {
+            Args& a = *q[i];
+            u[i] = fs::UnitFwdCall{(const fs_conv_desc*)P(0), P(1), P(2), PF(3), PF(4), PF(5), PF(6), (long long*)P(7), F(8), F(9), PF(10), PF(11), P(12),
+                                   P(13), P(14), L(15)};
+        }
+        return fs::unit_fwd_group(stream, u, m);
+    }
+    if (m > 1 && op == FS_OP_UNIT_BWD && nargs == 23) {
+        fs::UnitBwdCall u[FS_MAX_GROUP];
+        for (int i = 0; i < m; ++i) {
+            Args& a = *q[i];
+            u[i] = fs::UnitBwdCall{(const fs_conv_desc*)P(0), P(1), P(2), P(3), P(4), P(5), I(6), PF(7), PF(8), PF(9), PF(10), PF(11), P(12), PF(13), L(14),
+                                   L(15), L(16), P(17), I(18), I(19), I(20), P(21), L(22)};
+        }
+        return fs::unit_bwd_group(stream, u, m);
+    }
+    if (m > 1 && (op == FS_OP_CONV_FWD || op == FS_OP_WGRAD_STRIDED) && nargs == 9) {
+        static thread_local Args flat[FS_MAX_GROUP];
+        for (int i = 0; i < m; ++i) { flat[i] = *q[i]; repoint_arrays(flat[i], nargs); }
+        return run_pool(op, nargs, flat, m, stream, index);
+    }
+    st = m > 1 && fs::group_ew_enabled() ? run_grouped_ew(op, nargs, q, m, stream) : FS_ERR_UNSUPPORTED;
+    if (st == FS_ERR_UNSUPPORTED) {          // no grouped form: program after program
+        st = FS_OK;
+        for (int i = 0; i < m && st == FS_OK; ++i) st = run_command(op, nargs, *q[i], stream, index);
+    }
+    return st;
+}
+
 extern "C" fs_status fs_exec_program_group(void* stream, int k, const long long* const* words, const long long* n_words,
                                            const unsigned char* const* blobs, void* const* slots, int n_slots) {
-    FS_REQUIRE(k >= 1 && k <= FS_MAX_GROUP && words && n_words && blobs && slots && n_slots > 0, FS_ERR_INVALID,
-               "fs_exec_program_group: bad argument (k = %d)", k);
-    long long pos[FS_MAX_GROUP] = {0};
+    FS_REQUIRE(k >= 1 && k <= MAX_LAYER && words && n_words && blobs && slots && n_slots > 0, FS_ERR_INVALID,
+               "fs_exec_program_group: bad argument (k = %d, at most %d)", k, MAX_LAYER);
+    long long pos[MAX_LAYER] = {0};
+    static thread_local Args head[MAX_LAYER];
+    static thread_local Args pool[MAX_LAYER * 4];             // the JOIN runs of every selected program
+    bool have[MAX_LAYER] = {false};
+    int op[MAX_LAYER], nargs[MAX_LAYER], join[MAX_LAYER];
     int index = 0;
-    static thread_local Args a[FS_MAX_GROUP];
-    static thread_local Args pool[FS_MAX_GROUP * MAX_POOL];      // a JOIN run of every program, program-major inside each command
-    int pooled = 0, pool_op = -1, pool_nargs = 0;
-    while (pos[0] < n_words[0]) {
-        int op0 = -1, nargs0 = 0, join0 = 0;
+    for (;;) {
+        int best = -1;
         for (int i = 0; i < k; ++i) {
-            int op, lane, nargs, join = 0;
-            FS_REQUIRE(pos[i] < n_words[i], FS_ERR_INVALID, "fs_exec_program_group: program %d is shorter than program 0", i);
-            const fs_status st = parse_command(words[i], n_words[i], pos[i], blobs[i], slots + (long long)i * n_slots, n_slots, index, op, lane, nargs,
-                                               a[i], &join);
-            if (st != FS_OK) return st;
-            if (i == 0) { op0 = op; nargs0 = nargs; join0 = join; }
-            FS_REQUIRE(op == op0 && nargs == nargs0 && join == join0, FS_ERR_INVALID,
-                       "fs_exec_program_group: command %d differs between programs 0 and %d", index, i);
+            if (!have[i] && pos[i] < n_words[i]) {
+                int lane;
+                const fs_status st = parse_command(words[i], n_words[i], pos[i], blobs[i], slots + (long long)i * n_slots, n_slots, index, op[i], lane,
+                                                   nargs[i], head[i], &join[i]);
+                if (st != FS_OK) return st;
+                have[i] = true;
+            }
+            if (have[i] && (best < 0 || op_rank(op[i]) < op_rank(op[best]))) best = i;
         }
+        if (best < 0) break;
+        const int op0 = op[best], nargs0 = nargs[best], join0 = join[best];
+        int sel[MAX_LAYER], n_sel = 0;
+        for (int i = 0; i < k; ++i)
+            if (have[i] && op[i] == op0 && nargs[i] == nargs0 && join[i] == join0) sel[n_sel++] = i;
         fs_status st = FS_OK;
-        if (join0 || pooled > 0) {
-            // joined run: command after command of all k programs collected, then issued as grouped launches of up to FS_MAX_GROUP problems
-            if (pooled > 0)
-                FS_REQUIRE(op0 == pool_op && nargs0 == pool_nargs, FS_ERR_INVALID,
-                           "fs_exec_program_group: command %d does not continue the joined run before it", index);
-            FS_REQUIRE(pooled + k <= FS_MAX_GROUP * MAX_POOL, FS_ERR_INVALID, "fs_exec_program_group: joined run too long at command %d", index);
-            for (int i = 0; i < k; ++i) pool[pooled++] = a[i];
-            pool_op = op0; pool_nargs = nargs0;
-            if (!join0) {
-                st = run_pool(pool_op, pool_nargs, pool, pooled, stream, index);
-                pooled = 0;
+        if (join0) {
+            // joined runs: every selected program contributes its whole run (commands up to and including the first without the JOIN bit)
+            int pooled = 0;
+            for (int j = 0; j < n_sel; ++j) {
+                const int i = sel[j];
+                for (;;) {
+                    FS_REQUIRE(pooled < MAX_LAYER * 4, FS_ERR_INVALID, "fs_exec_program_group: joined run too long at command %d", index);
+                    pool[pooled] = head[i];
+                    repoint_arrays(pool[pooled], nargs0);
+                    ++pooled;
+                    if (!join[i]) break;
+                    FS_REQUIRE(pos[i] < n_words[i], FS_ERR_INVALID, "fs_exec_program_group: the last command of program %d carries the JOIN bit", i);
+                    int lane;
+                    st = parse_command(words[i], n_words[i], pos[i], blobs[i], slots + (long long)i * n_slots, n_slots, index, op[i], lane, nargs[i],
+                                       head[i], &join[i]);
+                    if (st != FS_OK) return st;
+                    FS_REQUIRE(op[i] == op0 && nargs[i] == nargs0, FS_ERR_INVALID,
+                               "fs_exec_program_group: a command of program %d does not continue the joined run before it", i);
+                }
+                have[i] = false;
             }
-        } else if (k > 1 && op0 == FS_OP_UNIT_FWD && nargs0 == 16) {
-            fs::UnitFwdCall u[FS_MAX_GROUP];
-            for (int i = 0; i < k; ++i) {
-                Args& q = a[i];
-                u[i] = fs::UnitFwdCall{(const fs_conv_desc*)q.pv[0], q.pv[1], q.pv[2], (const float*)q.pv[3], (const float*)q.pv[4], (float*)q.pv[5],
-                                       (float*)q.pv[6], (long long*)q.pv[7], (float)q.fv[8], (float)q.fv[9], (float*)q.pv[10], (float*)q.pv[11],
-                                       q.pv[12], q.pv[13], q.pv[14], q.iv[15]};
-            }
-            st = fs::unit_fwd_group(stream, u, k);
-        } else if (k > 1 && op0 == FS_OP_UNIT_BWD && nargs0 == 23) {
-            fs::UnitBwdCall u[FS_MAX_GROUP];
-            for (int i = 0; i < k; ++i) {
-                Args& q = a[i];
-                u[i] = fs::UnitBwdCall{(const fs_conv_desc*)q.pv[0], q.pv[1], q.pv[2], q.pv[3], q.pv[4], q.pv[5], (int)q.iv[6], (const float*)q.pv[7],
-                                       (const float*)q.pv[8], (float*)q.pv[9], (float*)q.pv[10], (float*)q.pv[11], q.pv[12], (float*)q.pv[13],
-                                       q.iv[14], q.iv[15], q.iv[16], q.pv[17], (int)q.iv[18], (int)q.iv[19], (int)q.iv[20], q.pv[21], q.iv[22]};
-            }
-            st = fs::unit_bwd_group(stream, u, k);
-        } else if (k > 1 && (op0 == FS_OP_CONV_FWD || op0 == FS_OP_WGRAD_STRIDED) && nargs0 == 9) {
-            st = run_pool(op0, nargs0, a, k, stream, index);
+            st = run_pool(op0, nargs0, pool, pooled, stream, index);
         } else {
-            for (int i = 0; i < k && st == FS_OK; ++i) st = run_command(op0, nargs0, a[i], stream, index);
+            for (int lo = 0; lo < n_sel && st == FS_OK; lo += FS_MAX_GROUP) {
+                const int m = n_sel - lo < FS_MAX_GROUP ? n_sel - lo : FS_MAX_GROUP;
+                Args* q[FS_MAX_GROUP];
+                for (int j = 0; j < m; ++j) q[j] = &head[sel[lo + j]];
+                st = run_same_op(op0, nargs0, q, m, stream, index);
+            }
+            for (int j = 0; j < n_sel; ++j) have[sel[j]] = false;
         }
         if (st != FS_OK) return st;
         ++index;
     }
-    FS_REQUIRE(pooled == 0, FS_ERR_INVALID, "fs_exec_program_group: the last command carries the JOIN bit");
-    for (int i = 1; i < k; ++i) FS_REQUIRE(pos[i] == n_words[i], FS_ERR_INVALID, "fs_exec_program_group: program %d is longer than program 0", i);
     return FS_OK;
 }

@@ -9,18 +9,27 @@
 // the final logits written straight to a contiguous NCHW tensor (model_seg.py:365).
 // The backward is a gather over the output pixels that touch each input pixel: no atomics, deterministic.
 #include "common.h"
+#include "group.h"
 
 namespace fs {
 
 static inline float host_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
 
+// NHWC resample arguments as a record (the grouped launches of group.h carry up to FS_MAX_GROUP of them by value).  Forward: a = x,
+// out = y; backward: a = dy, b = y_out (ReLU mask), out = dx, a_cs = b_cs = the OUTPUT map's channel stride, out_cs the input map's.
+struct ResizeArgs {
+    int N, Hi, Wi, Ho, Wo, cv; float rh, rw; const void* a; int a_cs; const void* b; int b_cs; void* out; int out_cs; int relu;
+};
+
 template <typename T>
-__global__ void bilinear_fwd_kernel(int N, int Hi, int Wi, int Ho, int Wo, int cv, float rh, float rw,
-                                    const T* __restrict__ x, int x_cs, T* __restrict__ y, int y_cs, int relu) {
+__device__ __forceinline__ void bilinear_fwd_body(const ResizeArgs& q, int bx, int gx) {
     constexpr int VEC = Elem<T>::VEC;
+    const int N = q.N, Hi = q.Hi, Wi = q.Wi, Ho = q.Ho, Wo = q.Wo, cv = q.cv, x_cs = q.a_cs, y_cs = q.out_cs, relu = q.relu;
+    const float rh = q.rh, rw = q.rw;
+    const T* __restrict__ x = (const T*)q.a;
+    T* __restrict__ y = (T*)q.out;
     const long long total = (long long)N * Ho * Wo * cv;
-    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * blockDim.x) {
+    for (long long idx = bx * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gx * blockDim.x) {
         long long t = idx;
         const int c = (int)(t % cv) * VEC; t /= cv;
         const int ow = (int)(t % Wo); t /= Wo;
@@ -152,13 +161,15 @@ __device__ __forceinline__ float tap_weight(const Tap& t, int i) {
 constexpr int BWD_TAPS = 6;          // output columns per input column gathered in one go (x2 up-sample: at most 6, see cand_range)
 
 template <typename T>
-__global__ __launch_bounds__(256) void bilinear_bwd_kernel(int N, int Hi, int Wi, int Ho, int Wo, int cv, float rh, float rw,
-                                    const T* __restrict__ dy, int dy_cs, const T* __restrict__ yo, int yo_cs, int relu,
-                                    T* __restrict__ dx, int dx_cs) {
+__device__ __forceinline__ void bilinear_bwd_body(const ResizeArgs& q, int bx, int gx) {
     constexpr int VEC = Elem<T>::VEC;
+    const int N = q.N, Hi = q.Hi, Wi = q.Wi, Ho = q.Ho, Wo = q.Wo, cv = q.cv, dy_cs = q.a_cs, yo_cs = q.b_cs, dx_cs = q.out_cs, relu = q.relu;
+    const float rh = q.rh, rw = q.rw;
+    const T* __restrict__ dy = (const T*)q.a;
+    const T* __restrict__ yo = (const T*)q.b;
+    T* __restrict__ dx = (T*)q.out;
     const long long total = (long long)N * Hi * Wi * cv;
-    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * blockDim.x) {
+    for (long long idx = bx * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gx * blockDim.x) {
         long long t = idx;
         const int c = (int)(t % cv) * VEC; t /= cv;
         const int iw = (int)(t % Wi); t /= Wi;
@@ -241,6 +252,17 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(int N, int Hi, int Wi
         }
         stg16(dx + (((long long)n * Hi + ih) * Wi + iw) * dx_cs + c, Elem<T>::pack(acc));
     }
+}
+
+template <typename T> __global__ void bilinear_fwd_kernel(ResizeArgs q) { bilinear_fwd_body<T>(q, (int)blockIdx.x, (int)gridDim.x); }
+template <typename T> __global__ void bilinear_fwd_group_kernel(GroupOf<ResizeArgs> g) {
+    const int bid = (int)blockIdx.x, i = group_locate(g, bid);
+    bilinear_fwd_body<T>(g.p[i], bid - g.blk_start[i], g.blk_start[i + 1] - g.blk_start[i]);
+}
+template <typename T> __global__ __launch_bounds__(256) void bilinear_bwd_kernel(ResizeArgs q) { bilinear_bwd_body<T>(q, (int)blockIdx.x, (int)gridDim.x); }
+template <typename T> __global__ __launch_bounds__(256) void bilinear_bwd_group_kernel(GroupOf<ResizeArgs> g) {
+    const int bid = (int)blockIdx.x, i = group_locate(g, bid);
+    bilinear_bwd_body<T>(g.p[i], bid - g.blk_start[i], g.blk_start[i + 1] - g.blk_start[i]);
 }
 
 // backward of the NCHW logits up-sample: dy is NCHW fp32, dx is NHWC T; one lane per (input pixel, channel)
@@ -374,12 +396,10 @@ extern "C" fs_status fs_bilinear_fwd(void* stream, const fs_resize_desc* d, cons
     if (!d->out_nchw) {
         const int cv = d->C / vec_elems(d->dtype);
         const long long total = (long long)d->N * d->Ho * d->Wo * cv;
-        if (d->dtype == FS_F32)
-            FS_LAUNCH((bilinear_fwd_kernel<float>), dim3(grid_for(total)), dim3(256), 0, st, d->N, d->Hi, d->Wi, d->Ho,
-                               d->Wo, cv, rh, rw, (const float*)x, d->x_cs, (float*)y, d->y_cs, d->relu);
-        else
-            FS_LAUNCH((bilinear_fwd_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, st, d->N, d->Hi, d->Wi, d->Ho,
-                               d->Wo, cv, rh, rw, (const bf16_t*)x, d->x_cs, (bf16_t*)y, d->y_cs, d->relu);
+        const ResizeArgs q{d->N, d->Hi, d->Wi, d->Ho, d->Wo, cv, rh, rw, x, d->x_cs, nullptr, 0, y, d->y_cs, d->relu};
+        FS_NOTE_BYTES((double)d->N * d->C * elem_size(d->dtype) * ((double)d->Hi * d->Wi + (double)d->Ho * d->Wo));
+        if (d->dtype == FS_F32) FS_LAUNCH((bilinear_fwd_kernel<float>), dim3(grid_for(total)), dim3(256), 0, st, q);
+        else FS_LAUNCH((bilinear_fwd_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, st, q);
     } else {
         const bool out_f32 = (d->out_nchw == 1) || d->dtype == FS_F32;
         if (d->Wo % 4 == 0) {
@@ -440,14 +460,10 @@ extern "C" fs_status fs_bilinear_bwd(void* stream, const fs_resize_desc* d, cons
     if (!d->out_nchw) {
         const int cv = d->C / vec_elems(d->dtype);
         const long long total = (long long)d->N * d->Hi * d->Wi * cv;
-        if (d->dtype == FS_F32)
-            FS_LAUNCH((bilinear_bwd_kernel<float>), dim3(grid_for(total)), dim3(256), 0, st, d->N, d->Hi, d->Wi, d->Ho,
-                               d->Wo, cv, rh, rw, (const float*)dy, d->y_cs, (const float*)y_out, d->y_cs, d->relu, (float*)dx,
-                               d->x_cs);
-        else
-            FS_LAUNCH((bilinear_bwd_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, st, d->N, d->Hi, d->Wi, d->Ho,
-                               d->Wo, cv, rh, rw, (const bf16_t*)dy, d->y_cs, (const bf16_t*)y_out, d->y_cs, d->relu, (bf16_t*)dx,
-                               d->x_cs);
+        const ResizeArgs q{d->N, d->Hi, d->Wi, d->Ho, d->Wo, cv, rh, rw, dy, d->y_cs, y_out, d->y_cs, dx, d->x_cs, d->relu};
+        FS_NOTE_BYTES((double)d->N * d->C * elem_size(d->dtype) * ((double)d->Hi * d->Wi + (double)d->Ho * d->Wo * (d->relu ? 2 : 1)));
+        if (d->dtype == FS_F32) FS_LAUNCH((bilinear_bwd_kernel<float>), dim3(grid_for(total)), dim3(256), 0, st, q);
+        else FS_LAUNCH((bilinear_bwd_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, st, q);
     } else {
         FS_REQUIRE(d->out_nchw == 1 || d->dtype == FS_F32, FS_ERR_UNSUPPORTED, "fs_bilinear_bwd: NCHW gradient must be fp32");
         const long long total = (long long)d->N * d->Hi * d->Wi * d->C;
@@ -460,3 +476,49 @@ extern "C" fs_status fs_bilinear_bwd(void* stream, const fs_resize_desc* d, cons
     }
     return check_launch("fs_bilinear_bwd");
 }
+
+// ---- grouped forms (group.h): NHWC resamples of one dtype as one launch; NCHW outputs and buckets of one go through the entry points above
+static fs_status bilinear_any_group(void* stream, const ResizeCall* c, int n, bool backward) {
+    const char* fn = backward ? "fs_bilinear_bwd" : "fs_bilinear_fwd";
+    hipStream_t st = (hipStream_t)stream;
+    for (int i = 0; i < n; ++i) FS_REQUIRE(c[i].d, FS_ERR_INVALID, "%s: null descriptor", fn);
+    return for_each_bucket(n, [&](int i) { return c[i].d->out_nchw ? 1000 + i : (long long)c[i].d->dtype; }, [&](const int* sub, int m) -> fs_status {
+        if (m == 1) {
+            const ResizeCall& q = c[sub[0]];
+            return backward ? fs_bilinear_bwd(stream, q.d, q.a, q.b, q.out) : fs_bilinear_fwd(stream, q.d, q.a, q.out);
+        }
+        GroupOf<ResizeArgs> g;
+        g.n = m;
+        int grid = 0;
+        double bytes = 0;
+        for (int j = 0; j < m; ++j) {
+            const ResizeCall& q = c[sub[j]];
+            const fs_resize_desc* d = q.d;
+            const fs_status s = check_resize(fn, d);
+            if (s != FS_OK) return s;
+            FS_REQUIRE(q.a && q.out && aligned16(q.a) && aligned16(q.out), FS_ERR_INVALID, "%s: operands must be non-null and 16-byte aligned", fn);
+            FS_REQUIRE(!backward || !d->relu || q.b, FS_ERR_INVALID, "fs_bilinear_bwd: relu backward needs y_out");
+            const float rh = host_scale(d->Hi, d->Ho), rw = host_scale(d->Wi, d->Wo);
+            const int cv = d->C / vec_elems(d->dtype);
+            if (backward) g.p[j] = ResizeArgs{d->N, d->Hi, d->Wi, d->Ho, d->Wo, cv, rh, rw, q.a, d->y_cs, q.b, d->y_cs, q.out, d->x_cs, d->relu};
+            else g.p[j] = ResizeArgs{d->N, d->Hi, d->Wi, d->Ho, d->Wo, cv, rh, rw, q.a, d->x_cs, nullptr, 0, q.out, d->y_cs, d->relu};
+            g.blk_start[j] = grid;
+            grid += grid_for((long long)d->N * (backward ? d->Hi * d->Wi : d->Ho * d->Wo) * cv);
+            bytes += (double)d->N * d->C * elem_size(d->dtype) * ((double)d->Hi * d->Wi + (double)d->Ho * d->Wo * (backward && d->relu ? 2 : 1));
+        }
+        for (int j = m; j <= FS_MAX_GROUP; ++j) g.blk_start[j] = grid;
+        FS_NOTE_BYTES(bytes);
+        const bool f32 = c[sub[0]].d->dtype == FS_F32;
+        if (backward) {
+            if (f32) FS_LAUNCH((bilinear_bwd_group_kernel<float>), dim3(grid), dim3(256), 0, st, g);
+            else FS_LAUNCH((bilinear_bwd_group_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, g);
+        } else {
+            if (f32) FS_LAUNCH((bilinear_fwd_group_kernel<float>), dim3(grid), dim3(256), 0, st, g);
+            else FS_LAUNCH((bilinear_fwd_group_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, g);
+        }
+        return check_launch(fn);
+    });
+}
+
+fs_status fs::bilinear_fwd_group(void* stream, const ResizeCall* c, int n) { return bilinear_any_group(stream, c, n, false); }
+fs_status fs::bilinear_bwd_group(void* stream, const ResizeCall* c, int n) { return bilinear_any_group(stream, c, n, true); }

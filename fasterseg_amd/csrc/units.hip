@@ -165,6 +165,77 @@ extern "C" fs_status fs_conv_bn_act_train_bwd(void* stream, const fs_conv_desc* 
     return FS_OK;
 }
 
+// ---- n BatchNorm(+ReLU) passes as grouped launches (group.h) --------------------------------------------------------------------------
+// The calls are sorted into the launch sequences fs_bn_act_train_fwd / _bwd would pick for each of them - the one-launch column kernels
+// for maps of <= 512 pixels per group, (statistics pass +) normalisation for larger ones - and every sequence step goes out ONCE for
+// all calls that take it.  Bit-reproducible mode, FS_GROUP_EW=0 and single calls keep one launch sequence per call.
+fs_status fs::bn_fwd_group(void* stream, const BnFwdCall* c, int n) {
+    FS_REQUIRE(n >= 0 && n <= 4 * FS_MAX_GROUP, FS_ERR_INVALID, "bn_fwd_group: %d calls", n);
+    int col[4 * FS_MAX_GROUP], stats[4 * FS_MAX_GROUP], apply[4 * FS_MAX_GROUP];
+    int n_col = 0, n_stats = 0, n_apply = 0;
+    const bool grouped = n > 1 && group_ew_enabled() && !fs::g_deterministic;
+    for (int i = 0; i < n; ++i) {
+        const BnFwdCall& q = c[i];
+        FS_REQUIRE(q.groups >= 1 && q.pixels > 0 && q.pixels % q.groups == 0, FS_ERR_INVALID, "fs_bn_act_train_fwd: %lld pixels in %d groups",
+                   q.pixels, q.groups);
+        FS_REQUIRE(!q.stats_ready || q.groups == 1, FS_ERR_INVALID, "bn_fwd_group: epilogue statistics are per launch, not per group");
+        if (!grouped) {
+            fs_status s;
+            if (q.stats_ready)
+                s = fs_bn_train_apply(stream, q.pixels, q.C, q.z, q.z_cs, q.stats, q.gamma, q.beta, q.eps, q.momentum, q.running_mean,
+                                      q.running_var, q.num_batches_tracked, q.saved, q.y, q.y_cs, q.dtype, q.relu);
+            else
+                s = fs_bn_act_train_fwd(stream, q.pixels, q.C, q.groups, q.z, q.z_cs, q.gamma, q.beta, q.eps, q.momentum, q.running_mean,
+                                        q.running_var, q.num_batches_tracked, q.stats, q.saved, q.y, q.y_cs, q.dtype, q.relu, q.ws, q.ws_bytes);
+            if (s != FS_OK) return s;
+            continue;
+        }
+        if (!q.stats_ready && q.pixels / q.groups <= BN_COL_MAX_PIXELS) { col[n_col++] = i; continue; }
+        if (!q.stats_ready) stats[n_stats++] = i;
+        apply[n_apply++] = i;
+    }
+    fs_status s = FS_OK;
+    if (n_col) s = bn_col_fwd_group(stream, c, col, n_col);
+    if (s == FS_OK && n_stats) s = bn_stats_group(stream, c, stats, n_stats);
+    if (s == FS_OK && n_apply) s = bn_apply_group(stream, c, apply, n_apply);
+    return s;
+}
+
+fs_status fs::bn_bwd_group(void* stream, const BnBwdCall* c, int n) {
+    FS_REQUIRE(n >= 0 && n <= 4 * FS_MAX_GROUP, FS_ERR_INVALID, "bn_bwd_group: %d calls", n);
+    int col[4 * FS_MAX_GROUP], wide[4 * FS_MAX_GROUP];
+    int n_col = 0, n_wide = 0;
+    const bool grouped = n > 1 && group_ew_enabled() && !fs::g_deterministic;
+    for (int i = 0; i < n; ++i) {
+        const BnBwdCall& q = c[i];
+        FS_REQUIRE(q.groups >= 1 && q.pixels > 0 && q.pixels % q.groups == 0, FS_ERR_INVALID, "fs_bn_act_train_bwd: %lld pixels in %d groups",
+                   q.pixels, q.groups);
+        if (!grouped) {
+            fs_status s;
+            if (q.pixels / q.groups <= BN_COL_MAX_PIXELS || q.groups > 1) {
+                s = fs_bn_act_train_bwd(stream, q.pixels, q.C, q.groups, q.z, q.z_cs, q.dy, q.dy_cs, q.y, q.y_cs, q.saved, q.gamma, q.red, q.dtype,
+                                        q.relu, q.dz, q.dz_cs, q.dgamma_acc, q.dbeta_acc, q.ws, q.ws_bytes);
+            } else {
+                FS_REQUIRE(q.saved && q.red, FS_ERR_INVALID, "fs_bn_act_train_bwd: null argument");
+                s = fs_bn_bwd_reduce_ws(stream, q.pixels, q.C, 1, q.z, q.z_cs, q.dy, q.dy_cs, q.y, q.y_cs, q.saved, q.saved + q.C, 0, q.dtype, q.relu,
+                                        q.red, q.ws, q.ws_bytes);
+                if (s == FS_OK)
+                    s = fs_bn_bwd_apply(stream, q.pixels, q.C, q.z, q.z_cs, q.dy, q.dy_cs, q.y, q.y_cs, q.saved, q.saved + q.C, q.gamma, q.red, q.pixels,
+                                        q.dtype, q.relu, q.dz, q.dz_cs, q.dgamma_acc, q.dbeta_acc);
+            }
+            if (s != FS_OK) return s;
+            continue;
+        }
+        if (q.pixels / q.groups <= BN_COL_MAX_PIXELS) col[n_col++] = i;
+        else wide[n_wide++] = i;
+    }
+    fs_status s = FS_OK;
+    if (n_col) s = bn_col_bwd_group(stream, c, col, n_col);
+    if (s == FS_OK && n_wide) s = bn_bwd_reduce_group(stream, c, wide, n_wide);
+    if (s == FS_OK && n_wide) s = bn_bwd_apply_group(stream, c, wide, n_wide);
+    return s;
+}
+
 // ---- grouped forms (program.hip's lockstep executor) ---------------------------------------------------------------------------------
 // n units at the same position of n MixedOp launch programs: their convolutions go out as ONE launch (conv_igemm2.hip's grouped kernel),
 // their weight gradients as one and their data gradients as one; the BatchNorm kernels follow one by one.  Same arithmetic as the
@@ -192,53 +263,34 @@ fs_status fs::unit_fwd_group(void* stream, const UnitFwdCall* u, int n) {
     }
     fs_status s = conv_launch_group(stream, cp, args, n);
     if (s != FS_OK) return s;
+    BnFwdCall bn[FS_MAX_GROUP];
     for (int i = 0; i < n; ++i) {
         const UnitFwdCall& q = u[i];
         const fs_conv_desc* d = q.d;
-        const int C = d->Cout;
-        const long long count = (long long)d->N * d->Ho * d->Wo;
-        const int groups = d->bn_groups > 1 ? d->bn_groups : 1;
-        if (mode[i] == 0)
-            s = fs_bn_group_fwd(stream, count, C, groups, q.z, d->y_cs, nullptr, 1, q.gamma, q.beta, q.eps, q.momentum, q.running_mean,
-                                q.running_var, q.num_batches_tracked, q.saved, q.y, d->y_cs, d->dtype, unit_relu(d, true));
-        else if (mode[i] == 1)
-            s = fs_bn_act_train_fwd(stream, count, C, groups, q.z, d->y_cs, q.gamma, q.beta, q.eps, q.momentum, q.running_mean, q.running_var,
-                                    q.num_batches_tracked, q.stats, q.saved, q.y, d->y_cs, d->dtype, unit_relu(d, true), q.ws, q.ws_bytes);
-        else
-            s = fs_bn_train_apply(stream, count, C, q.z, d->y_cs, q.stats, q.gamma, q.beta, q.eps, q.momentum, q.running_mean, q.running_var,
-                                  q.num_batches_tracked, q.saved, q.y, d->y_cs, d->dtype, unit_relu(d, true));
-        if (s != FS_OK) return s;
+        bn[i] = BnFwdCall{(long long)d->N * d->Ho * d->Wo, d->Cout, d->bn_groups > 1 ? d->bn_groups : 1, q.z, d->y_cs, q.gamma, q.beta, q.eps,
+                          q.momentum, q.running_mean, q.running_var, q.num_batches_tracked, q.stats, q.saved, q.y, d->y_cs, d->dtype,
+                          unit_relu(d, true), q.ws, q.ws_bytes, mode[i] == 2 ? 1 : 0};
     }
-    return FS_OK;
+    return bn_fwd_group(stream, bn, n);          // (statistics pass +) normalisation of all units: one launch per step
 }
 
 fs_status fs::unit_bwd_group(void* stream, const UnitBwdCall* u, int n) {
     FS_REQUIRE(n >= 1 && n <= FS_MAX_GROUP, FS_ERR_INVALID, "unit_bwd_group: %d units", n);
     fs_status s;
-    // 1. BatchNorm backward of every unit (dz)
-    for (int i = 0; i < n; ++i) {
-        const UnitBwdCall& q = u[i];
-        const fs_conv_desc* d = q.d;
-        FS_REQUIRE(d && q.z && q.dy && q.saved && q.gamma && q.red && q.dz, FS_ERR_INVALID, "fs_conv_bn_act_train_bwd: null argument");
-        const int relu = unit_relu(d);
-        FS_REQUIRE(!relu || q.y, FS_ERR_INVALID, "fs_conv_bn_act_train_bwd: ReLU unit needs its output y");
-        const int C = d->Cout;
-        const long long pixels = (long long)d->N * d->Ho * d->Wo;
-        const float* mean = q.saved;
-        const float* invstd = q.saved + C;
-        const int groups = d->bn_groups > 1 ? d->bn_groups : 1;
-        if (pixels / groups <= BN_COL_MAX_PIXELS || groups > 1) {
-            s = fs_bn_act_train_bwd(stream, pixels, C, groups, q.z, d->y_cs, q.dy, q.dy_cs, q.y, d->y_cs, q.saved, q.gamma, q.red, d->dtype, relu,
-                                    q.dz, C, q.dgamma_acc, q.dbeta_acc, q.ws, q.ws_bytes);
-            if (s != FS_OK) return s;
-        } else {
-            s = fs_bn_bwd_reduce_ws(stream, pixels, C, 1, q.z, d->y_cs, q.dy, q.dy_cs, q.y, d->y_cs, mean, invstd, 0, d->dtype, relu, q.red, q.ws,
-                                    q.ws_bytes);
-            if (s != FS_OK) return s;
-            s = fs_bn_bwd_apply(stream, pixels, C, q.z, d->y_cs, q.dy, q.dy_cs, q.y, d->y_cs, mean, invstd, q.gamma, q.red, pixels, d->dtype, relu,
-                                q.dz, C, q.dgamma_acc, q.dbeta_acc);
-            if (s != FS_OK) return s;
+    // 1. BatchNorm backward of every unit (dz): one launch per step of the sequence for all units (bn_bwd_group)
+    {
+        BnBwdCall bn[FS_MAX_GROUP];
+        for (int i = 0; i < n; ++i) {
+            const UnitBwdCall& q = u[i];
+            const fs_conv_desc* d = q.d;
+            FS_REQUIRE(d && q.z && q.dy && q.saved && q.gamma && q.red && q.dz, FS_ERR_INVALID, "fs_conv_bn_act_train_bwd: null argument");
+            const int relu = unit_relu(d);
+            FS_REQUIRE(!relu || q.y, FS_ERR_INVALID, "fs_conv_bn_act_train_bwd: ReLU unit needs its output y");
+            bn[i] = BnBwdCall{(long long)d->N * d->Ho * d->Wo, d->Cout, d->bn_groups > 1 ? d->bn_groups : 1, q.z, d->y_cs, q.dy, q.dy_cs, q.y,
+                              d->y_cs, q.saved, q.gamma, q.red, d->dtype, relu, q.dz, d->Cout, q.dgamma_acc, q.dbeta_acc, q.ws, q.ws_bytes};
         }
+        s = bn_bwd_group(stream, bn, n);
+        if (s != FS_OK) return s;
     }
     // 2. weight gradients: one launch
     {

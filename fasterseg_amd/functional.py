@@ -10,6 +10,7 @@ Each Function is one fused unit of the hot path (forward and backward both run o
 There is no eager/ATen fallback: inputs that are not NHWC views are converted with fs_nchw_to_nhwc.
 """
 import ctypes
+import os
 import weakref
 
 import torch
@@ -735,7 +736,28 @@ def zero_arena(nbytes, device):
     replay), or a fresh torch.zeros when no step is active.  None for 0 bytes."""
     if not nbytes:
         return None
+    if _ZERO_MEMSET:
+        return _memset_zeros(nbytes, device)
     return K.zero_pool.take(nbytes // 4, device, align=64)
+
+
+# Diagnosis switch (round 6, DESIGN section 7 "capture fault"): FS_ZERO_MEMSET=1 restores what rounds 3-4 did - every launch program
+# clears its accumulators with its own hipMemsetAsync (inside a capture: one memset node per program and direction).
+_ZERO_MEMSET = bool(int(os.environ.get("FS_ZERO_MEMSET", "0")))
+_memset_lists = {}
+
+
+def _memset_zeros(nbytes, device):
+    from . import program
+    t = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+    lst = _memset_lists.get(nbytes)
+    if lst is None:
+        l = program._List()
+        l.emit(program.OP_MEMSET, program.Ref(1, 0), nbytes)
+        lst = _memset_lists[nbytes] = l.finish()
+    slots = (ctypes.c_void_p * program.N_SLOTS)(None, t.data_ptr())
+    K.call("fs_exec_program", K._stream(), lst[0], lst[1], lst[2], slots, program.N_SLOTS)
+    return t
 
 
 class _MixedOpProgram(torch.autograd.Function):

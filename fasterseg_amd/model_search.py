@@ -161,26 +161,28 @@ def _eval(op, x, alpha, ratios, groups):
 _EAGER_LANES = int(os.environ.get("FS_EAGER_LANES", "4"))     # measured on C3: 1 lane 130.6 ms, 4: 120.0, 6: 122.1, 10: 134.2
 
 
-# The MixedOps of a layer whose launch programs have the same command structure are replayed in LOCKSTEP by fs_exec_program_group: the
-# convolutions (weight / data gradients) at the same position of the programs are ONE grouped launch each - the step is the sum of its
-# kernel durations and every ~10 us convolution pays ~4 us of ramp-up + boundary.  FS_GROUP_PROGRAMS=0: one program per stream lane.
+# The MixedOps of a layer are replayed TOGETHER by fs_exec_program_group (csrc/program.hip): the next commands of all their launch
+# programs are scheduled so that commands of one kind - conv -> BN units, bare convolutions, weight / data gradients and, since round 6,
+# the BatchNorm passes, bilinear resamples and weighted sums (csrc/group.h) - go out as ONE grouped launch each, whatever the programs'
+# structure (stride-1 and stride-2 MixedOps, with or without input gradient meet at their common commands).  The step is the sum of its
+# kernel durations and every launch pays ~4 us of ramp-up + boundary.  FS_GROUP_PROGRAMS=0: one program per stream lane.
 _GROUP_PROGRAMS = bool(int(os.environ.get("FS_GROUP_PROGRAMS", "1")))
-# Inside a hipGraph capture the lockstep calls are OFF by default (ROCm 7.2): on side lanes hipStreamEndCapture crashes as soon as a
-# k > 1 lockstep node is captured, and with the launch programs on the capture's origin stream instead (grouped OR one by one - the
-# round-3 _MixedOpProgram node shows it too) the fifth replay of the graph produces inf / NaN gradients (tools/debug_group_nan.py).
-# The captured fixed-width passes therefore keep one program per lane; the eager (sampled-width) passes are grouped.
-_GROUP_CAPTURE = int(os.environ.get("FS_GROUP_CAPTURE", "0"))       # 2: every bucket on ONE side lane; 1 (origin stream) is refused below
-if _GROUP_CAPTURE == 1 and not int(os.environ.get("FS_ALLOW_BROKEN_CAPTURE", "0")):
-    # a mode that is known to produce inf / NaN gradients from the fifth replay on is not offered as a switch.  The
-    # reproduction (tools/debug_group_nan.py) sets FS_ALLOW_BROKEN_CAPTURE=1 to get at it.
-    raise RuntimeError("FS_GROUP_CAPTURE=1 (launch programs on the capture's origin stream) gives inf / NaN gradients after a few replays on "
-                       "ROCm 7.2 and is disabled; use FS_GROUP_CAPTURE=2 (all buckets on one side lane) or leave it at 0")
-
-
-# Round 5 measured what the forked capture layout costs and buys (profiles/r05_host_vs_device_c3.txt): replaying a forked graph of ~3 k
-# kernel nodes takes ~12.5 ms of HOST time on ROCm 7.2 (every cross-lane edge is a signal wired up per replay), a pass captured on ONE
-# stream replays in ~1 ms of host time - but the device then runs the pass as one chain, and the step got SLOWER (98 vs 86 ms; 90 with
-# grouped launches in the linear capture): the forks are worth more on the device than they cost on the host.  The layout stays.
+# Inside a hipGraph capture, FS_GROUP_CAPTURE selects where the layer calls go: 1 (default) the capture's origin stream - the captured
+# pass is then one LINEAR graph, which ROCm replays at ~0.5 us of host time per kernel node instead of ~4 us for a forked graph
+# (profiles/r05_host_vs_device_c3.txt); 2 one dedicated side lane; 0 no grouping inside captures (one program per forked lane, the
+# round-3..5 layout).  Rounds 4-5 refused 1: the graphs gave inf gradients from the ~5th replay on.  Root cause, found in round 6
+# (profiles/r06_capture_fault_matrix*.txt): the launch programs of rounds 3-4 cleared their accumulators with
+# hipMemsetAsync, and ROCm 7.x does not keep a MEMSET node captured on the origin stream of a multi-stream capture ordered against the
+# kernel nodes around it in later replays (on forked side streams it does) - BatchNorm statistics accumulated across replays.  Round 5
+# replaced those memsets by one fill KERNEL per captured pass (kernels.zero_pool.begin_capture) for launch-count reasons, which removed
+# the trigger; FS_ZERO_MEMSET=1 brings memset nodes and the fault back.  Layer calls on SEVERAL side lanes (>= 3) still crash
+# hipStreamEndCapture on ROCm 7.2 (core dump; a multi-output autograd node whose backward runs on a forked lane) and are refused.
+_GROUP_CAPTURE = int(os.environ.get("FS_GROUP_CAPTURE", "1"))
+if _GROUP_CAPTURE >= 3 and not int(os.environ.get("FS_ALLOW_BROKEN_CAPTURE", "0")):
+    raise RuntimeError("FS_GROUP_CAPTURE >= 3 (layer calls on several side lanes of a capture) crashes hipStreamEndCapture on ROCm 7.2; "
+                       "use 1 (origin stream, default), 2 (one side lane) or 0 (no grouping inside captures)")
+# Eager passes: the layer's programs go out as FS_LAYER_SPLIT calls side by side on that many lanes (1: one call on the current stream).
+_LAYER_SPLIT = max(1, int(os.environ.get("FS_LAYER_SPLIT", "1")))
 
 
 # SupernetStep.step(force_eager=True) - bench.py's census step - sets this: the fixed-width passes, which the timed steps replay from
@@ -267,18 +269,25 @@ def _run_tasks(tasks):
     if grouped:
         from .program import MAX_GROUP
         buckets = {}
-        for item in grouped:
-            buckets.setdefault((item[3].signature, item[1].dtype), []).append(item)
+        for item in grouped:                                # one call needs one dtype; the executor sorts out everything else
+            buckets.setdefault(item[1].dtype, []).append(item)
         for items in buckets.values():
-            for lo in range(0, len(items), MAX_GROUP):
-                chunk = items[lo:lo + MAX_GROUP]
+            per = MAX_GROUP
+            if not capturing and _LAYER_SPLIT > 1:
+                per = min(MAX_GROUP, max(1, -(-len(items) // _LAYER_SPLIT)))
+            for lo in range(0, len(items), per):
+                chunk = items[lo:lo + per]
                 if capturing and _GROUP_CAPTURE == 2:
                     with torch.cuda.stream(lane_for(0)):
                         outs = FN.mixed_op_program_group([c[1] for c in chunk], [c[2] for c in chunk], [c[3] for c in chunk])
-                elif capturing:        # FS_GROUP_CAPTURE=1 (see above): on the capturing stream itself
+                elif capturing and _GROUP_CAPTURE >= 3:      # (crashes hipStreamEndCapture: kept for the reproduction only)
+                    with torch.cuda.stream(lane_for(slot % (_GROUP_CAPTURE - 1))):
+                        outs = FN.mixed_op_program_group([c[1] for c in chunk], [c[2] for c in chunk], [c[3] for c in chunk])
+                    slot += 1
+                elif capturing or _LAYER_SPLIT == 1:        # on the current stream itself
                     outs = FN.mixed_op_program_group([c[1] for c in chunk], [c[2] for c in chunk], [c[3] for c in chunk])
                 else:
-                    lane = lane_for(slot)                   # one lockstep call per bucket, buckets side by side on the lanes
+                    lane = lane_for(slot)                   # FS_LAYER_SPLIT calls side by side on the lanes
                     for c in chunk:
                         hand_over(c[1], lane)
                         hand_over(c[2], lane)

@@ -160,11 +160,12 @@ class MixedOpProgram:
         K.call("fs_exec_program", K._stream(), words, n, blob, arr, N_SLOTS)
 
 
-MAX_GROUP = 8          # FS_MAX_GROUP of csrc/conv_igemm.h: programs per lockstep call
+MAX_GROUP = 16         # MAX_LAYER of csrc/program.hip: programs per fs_exec_program_group call
 
 
 def run_group(progs, backward, slot_lists):
-    """fs_exec_program_group: the forward (or backward) lists of `progs` (equal signatures) in lockstep on the current stream."""
+    """fs_exec_program_group: the forward (or backward) lists of `progs` (any structures: the executor groups the commands of one kind
+    that are pending at the same time) on the current stream."""
     k = len(progs)
     assert 1 <= k <= MAX_GROUP and len(slot_lists) == k
     lists = [(p.b_words, p.b_n, p.b_blob) if backward else (p.f_words, p.f_n, p.f_blob) for p in progs]

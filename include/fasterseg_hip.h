@@ -88,7 +88,7 @@ typedef struct fs_resize_desc {
 const char* fs_last_error(void);
 /* ABI revision of this header; fs_version() returns the one the library was built from.  Bindings check both this and
  * fs_struct_size() when they load the library (fasterseg_amd/_lib.py) - a stale .so must not be used silently. */
-#define FS_ABI_VERSION 208
+#define FS_ABI_VERSION 209
 int fs_version(void);
 /* Bit-reproducible mode (default off; FS_DETERMINISTIC=1 in the environment turns it on at load): every cross-block reduction that
  * otherwise uses float atomics - the pixel slabs of fs_conv2d_wgrad_ws, BatchNorm statistics and parameter gradients of maps above
@@ -421,6 +421,7 @@ typedef struct fs_kernel_time {
     char name[56];                  /* kernel function name without template arguments */
     long long count;
     double ms;
+    double bytes;                   /* ABI 209: algorithmic HBM bytes of those launches (BatchNorm / resample / weighted-sum kernels; 0: not priced) */
 } fs_kernel_time;
 void fs_census_enable(int level);                                /* 1 / 2: clear and start, 0: stop (waits for timed launches) */
 int fs_census_read(fs_census_entry* out, int max_entries);      /* fills up to max_entries, returns the number of distinct shapes */
@@ -503,13 +504,18 @@ fs_status fs_exec_program(void* stream, const long long* words, long long n_word
  * host cost per kernel node is higher.  Events are created / destroyed with fs_event_create / fs_event_destroy. */
 fs_status fs_exec_program_streams(void* const* streams, int n_streams, const long long* words, long long n_words,
                                   const unsigned char* blob, void* const* slots, int n_slots);
-/* Lockstep form: k programs (<= 8) of IDENTICAL command structure - the MixedOps of one supernet layer, which only depend on the
- * previous layer (search/model_search.py:310-333) - issued on one stream, command j of all programs together.  Where that command is a
- * conv->BN unit (forward or backward), a bare convolution or a weight gradient, the k convolutions / weight gradients / data gradients go
- * out as ONE launch each: their arguments travel as kernel arguments and every workgroup finds its problem itself (a supernet step is
- * the sum of its kernel durations, and a 10 us convolution on 100-600 workgroups pays ~4 us of ramp-up + boundary whatever its size).
+/* Layer form (ABI 209; ABI 208 required identical command structure and k <= 8): k <= 16 independent programs - the MixedOps of one
+ * supernet layer, which only depend on the previous layer (search/model_search.py:310-333) - issued on ONE stream.  Every round takes
+ * the next pending command of each program, picks the op kind of lowest rank among them (cheap early ops first, the closing weighted
+ * sum last) and issues the pending commands of that kind as ONE grouped launch per kernel: conv->BN units forward / backward (grouped
+ * convolution, BatchNorm passes, weight and data gradients), bare convolutions / weight gradients (JOIN runs of all programs pooled),
+ * BatchNorm units, bilinear resamples, weighted sums, axpy - their arguments travel as kernel arguments and every workgroup finds its
+ * problem itself (a supernet step is the sum of its kernel durations, and a launch pays ~4 us of ramp-up + boundary whatever its
+ * size).  Programs of different structure (stride-1 / stride-2 MixedOps, with or without input gradient) meet at their common
+ * commands; program order is kept inside each program.  Ops without a grouped form go out program after program.
  * words / n_words / blobs: k entries; slots: k * n_slots pointers (program i uses slots[i * n_slots ...]).  Same arithmetic as k
- * fs_exec_program calls except that grouped convolutions are never split over K. */
+ * fs_exec_program calls except that grouped convolutions are never split over K.  FS_GROUP_EW=0 in the environment keeps the
+ * BatchNorm / resample / weighted-sum launches per program (the ABI 208 behaviour). */
 fs_status fs_exec_program_group(void* stream, int k, const long long* const* words, const long long* n_words,
                                 const unsigned char* const* blobs, void* const* slots, int n_slots);
 void* fs_event_create(void);

@@ -97,6 +97,11 @@ def test_integration_doc_binds_the_same_conv_descriptor():
     assert names == fields
     sections = [int(m) for m in re.findall(r"^## (\d+)\.", doc, re.M)]
     assert sections == list(range(1, len(sections) + 1)), "section numbering of INTEGRATION.md"
+    # the documented binding refuses a library of another ABI revision: the number it asserts must be the header's and the bindings'
+    # (the doc said 206 while header and _lib.py said 208)
+    doc_abi = re.search(r"assert lib\.fs_version\(\) == (\d+)", doc)
+    header_abi = re.search(r"#define FS_ABI_VERSION (\d+)", header)
+    assert doc_abi and header_abi and int(doc_abi.group(1)) == int(header_abi.group(1)) == _lib.EXPECTED_ABI
 
 
 def test_product_does_not_reach_into_tests_or_fixtures():
