@@ -403,7 +403,21 @@ def _timed_census(args, world, rank, step_fn, extra_entries=(), workload=None):
     roof, families, kernels = census.roofline_timed(rec, args.dtype, PEAK_TFLOPS[args.dtype], PEAK_HBM_GBS, extra_entries)
     if roof is not None and workload and args.dtype == "bf16":
         roof["traffic"] = step_traffic(workload, STEP_FAMILY_KERNELS.get(roof["kernel"], ()), kernels)
-    return {"roofline": roof, "kernel_families": families, "kernels_in_step": kernels}
+    out = {"roofline": roof, "kernel_families": families, "kernels_in_step": kernels}
+    if roof is not None and roof.get("step_ideal_ms"):
+        # the whole step against the roofs (the analogue of C2's frame_roofline): every family at its own roof - convolutions at the dense
+        # MFMA peak of the step's dtype, BatchNorm / resample / weighted-sum passes at 8 TB/s - over the measured step; `frac` is filled in by
+        # the caller, who knows ms_per_step of the timed region
+        out["step_roofline"] = {"ideal_ms": roof["step_ideal_ms"], "launches": sum(k["launches"] for k in kernels.values()),
+                                "kernel_ms": round(sum(k["ms_per_step"] for k in kernels.values()), 3)}
+    return out
+
+
+def _close_step_roofline(line):
+    sr = line.get("step_roofline")
+    if sr and line.get("ms_per_step"):
+        sr["frac"] = round(sr["ideal_ms"] / line["ms_per_step"], 5)
+        sr["note"] = "sum over families of algorithmic work / roof (convs: dense MFMA peak of the dtype; BN, resample, weighted sums: 8 TB/s) / ms_per_step"
 
 
 def _other_leg(args, world, make_stepper, run_of, batch):
@@ -471,6 +485,7 @@ def run_student_train(args, world, rank, backend):
         timed = _timed_census(args, world, rank, lambda: stepper.step(imgs, target), extra, workload="c4")
         if timed:
             line.update(timed)
+            _close_step_roofline(line)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # the same step on the CPU oracle, on a 2-image sample (teacher eval forward + student train forward/backward)
         nb = 2
@@ -612,6 +627,7 @@ def run_supernet(args, world, rank, backend, pretrain):
         timed = _timed_census(args, world, rank, eager_step, workload="c3" if pretrain else "c5")
         if timed:
             line.update(timed)
+            _close_step_roofline(line)
     else:
         eager_step()
     eager_loss = float(eager_next[0][0])
@@ -680,6 +696,8 @@ def compact_workload(w):
         out["parity"]["after_timed"] = bool(w["post_timed_check"].get("pass"))
     if w.get("roofline"):
         out["roofline"] = _pick(w["roofline"], _ROOF_KEYS)
+    if w.get("step_roofline"):
+        out["step_roofline"] = _pick(w["step_roofline"], ("ideal_ms", "frac", "launches"))
     if w.get("cpu_baseline"):
         out["cpu_baseline"] = _pick(w["cpu_baseline"], _CPU_KEYS)
     return out
@@ -729,7 +747,7 @@ def fit_line(line, limit=LINE_LIMIT):
         if size() < limit:
             return line
         line.pop(k, None)
-    for drop in (("cpu_baseline",), ("parity",), ("roofline",), ("fp32_steps", "bf16_steps", "per_gpu_batch", "steps", "unit")):
+    for drop in (("step_roofline",), ("cpu_baseline",), ("parity",), ("roofline",), ("fp32_steps", "bf16_steps", "per_gpu_batch", "steps", "unit")):
         for w in (line.get("workloads") or {}).values():
             if size() < limit:
                 return line

@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_build")
 LIB = os.path.join(HERE, "libfasterseg_hip.so")
 SOURCES = ["api.cpp", "census.hip", "conv_igemm.hip", "conv_igemm2.hip", "conv3x3_halo.hip", "zoom_cell.hip", "elementwise.hip", "bn_col.hip", "resize.hip", "stem.hip", "wgrad.hip", "units.hip", "optim.hip", "program.hip", "loss.hip", "loss_up.hip", "eval.hip"]
-HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_igemm.h"), os.path.join(CSRC, "group.h"), os.path.join(os.path.dirname(HERE), "include", "fasterseg_hip.h")]
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "bn_bodies.h"), os.path.join(CSRC, "conv_igemm.h"), os.path.join(CSRC, "group.h"), os.path.join(os.path.dirname(HERE), "include", "fasterseg_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 if os.environ.get("FS_BUILD_PROBES", "0") not in ("", "0"):
     # measurement-only kernel instantiations (conv_igemm2 ablations / 6- and 8-stage rings: tools/conv_sweep.py codes 107, 108, 120-133);

@@ -551,27 +551,70 @@ bool igemm2_group_ok(const ConvArgs* a, int n, int dtype) {
     return true;
 }
 
+// FS_IGEMM2_GROUP_CFG=<0|4|5|6>: one tile configuration for every grouped launch; FS_IGEMM2_GROUP_MODEL=0: the round-4 choice (fewest
+// staged bytes); FS_IGEMM2_GROUP_LPT=0: problems in caller order (measurement switches, tools/step_time.py)
+static int g_group_cfg = [] { const char* e = getenv("FS_IGEMM2_GROUP_CFG"); return e ? atoi(e) : -1; }();
+static int g_group_model = [] { const char* e = getenv("FS_IGEMM2_GROUP_MODEL"); return e ? atoi(e) : 1; }();
+static int g_group_lpt = [] { const char* e = getenv("FS_IGEMM2_GROUP_LPT"); return e ? atoi(e) : 1; }();
+
+// estimated clocks of ONE workgroup of problem `a` in tile (bm, bn): per 128-byte K stage the larger of the operand fill (L2 -> LDS at
+// ~35 bytes / clock / CU, profiles/r04_lds_dma_fill.csv) and the MFMA time of the tile's 32 x 32 sub-tiles spread over the four waves
+// (32x32x16 bf16: 32 clocks per 16 of K; 32x32x2 fp32: 64 clocks per 2 of K), plus a fixed part (tables, epilogue, ring fill)
+static double group_block_clocks(const ConvArgs& a, int es, int bm, int bn) {
+    const double steps = (a.R * a.S * (a.Cin * es / 16) + 7) / 8 * ((a.flags & FS_CONV_TRANSPOSED) ? 0.25 : 1.0);
+    const double fill = (bm + bn) * 128.0 / 35.0;
+    const double mfma = (bm / 32) * (bn / 32) * (es == 4 ? 1024.0 : 128.0) / 4.0;
+    static const double fixed = [] { const char* e = getenv("FS_IGEMM2_GROUP_FIXED"); return e ? atof(e) : 1200.0; }();
+    return fixed + steps * (fill > mfma ? fill : mfma);
+}
+
 bool igemm2_group_launch(hipStream_t st, ConvArgs* a, int n, int dtype) {
     if (!igemm2_group_ok(a, n, dtype)) return false;
     const int es = elem_size(dtype);
-    // one tile shape for the whole group: the one that stages the fewest bytes (the group fills the chip, the fill rate is the bound)
+    // One tile shape for the whole group.  Round 4 took the one that stages the fewest bytes (the bf16 launches are bound by the operand
+    // fill).  Round 6: the modelled time of the launch - all workgroups' clocks spread over the CUs they can occupy, never less than the
+    // longest single workgroup - which also sees the matrix-core time (fp32: 8x the bf16 clocks per K, so padded tiles cost more than
+    // staged bytes) and the tail of a group whose problems differ 8x in K.
     static const int cand[4] = {0, 5, 6, 4};
     int cfg = 0;
     double best = 1e300;
     for (int ci = 0; ci < 4; ++ci) {
         const int bm = CFG2[cand[ci]].bm, bn = CFG2[cand[ci]].bn;
-        double bytes = 0;
+        double cost = 0, longest = 0, blocks = 0;
         for (int i = 0; i < n; ++i) {
-            const double steps = (a[i].R * a[i].S * (a[i].Cin * es / 16) + 7) / 8 * ((a[i].flags & FS_CONV_TRANSPOSED) ? 0.25 : 1.0);
-            bytes += (double)igemm2_tiles_m(a[i], bm) * ((a[i].Cout + bn - 1) / bn) * (steps + 6.0) * (bm + bn);     // + 6: a block's fixed cost
+            const double tiles = (double)igemm2_tiles_m(a[i], bm) * ((a[i].Cout + bn - 1) / bn);
+            if (g_group_model) {
+                const double clk = group_block_clocks(a[i], es, bm, bn);
+                cost += tiles * clk;
+                blocks += tiles;
+                if (clk > longest) longest = clk;
+            } else {
+                const double steps = (a[i].R * a[i].S * (a[i].Cin * es / 16) + 7) / 8 * ((a[i].flags & FS_CONV_TRANSPOSED) ? 0.25 : 1.0);
+                cost += tiles * (steps + 6.0) * (bm + bn);     // + 6: a block's fixed cost
+            }
         }
-        if (bytes < best) { best = bytes; cfg = cand[ci]; }
+        if (g_group_model) {
+            const double rounds = blocks > 256 ? blocks / 256.0 : 1.0;          // (one workgroup per CU at a time)
+            cost = cost / blocks * rounds;
+            if (cost < longest) cost = longest;
+        }
+        if (cost < best) { best = cost; cfg = cand[ci]; }
+    }
+    if (g_group_cfg >= 0 && (g_group_cfg == 0 || (g_group_cfg >= 4 && g_group_cfg <= 6))) cfg = g_group_cfg;
+    // longest workgroups first: the hardware hands out workgroups in index order, so the short problems fill the tail of the launch
+    int order[FS_MAX_GROUP];
+    for (int i = 0; i < n; ++i) order[i] = i;
+    if (g_group_lpt) {
+        double clk[FS_MAX_GROUP];
+        for (int i = 0; i < n; ++i) clk[i] = group_block_clocks(a[i], es, CFG2[cfg].bm, CFG2[cfg].bn);
+        for (int i = 1; i < n; ++i)
+            for (int j = i; j > 0 && clk[order[j]] > clk[order[j - 1]]; --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
     }
     ConvGroupArgs grp;
     grp.n = n;
     int grid = 0;
     for (int i = 0; i < n; ++i) {
-        grp.p[i] = a[i];
+        grp.p[i] = a[order[i]];
         grp.blk_start[i] = grid;
         grid += igemm2_configure(grp.p[i], es, CFG2[cfg].bm, CFG2[cfg].bn, 1, nullptr);
     }

@@ -7,6 +7,7 @@
 // `result + op(x)*w*r0*r1` and beta-weighted sums (model_search.py:76-78,330-333).
 #include "common.h"
 #include "group.h"
+#include "bn_bodies.h"
 
 namespace fs {
 
@@ -173,73 +174,6 @@ template <typename T, int OP> __global__ void ew_group_kernel(GroupOf<EwArgs> g)
 // (24-100 blocks, 8.1 us average where the plain pass takes ~5); as a block of its own it runs beside the pass.
 // `groups` > 1: consecutive ranges of pixels/groups pixels are normalised independently (stats / saved hold one block of 2C / 4C
 // floats per group), running statistics take the groups' updates one after the other (fs_conv_desc.bn_groups).
-struct BnApplyArgs {
-    long long pixels; int cv; const void* x; int x_cs; const float* stats; float count; const float* gamma; const float* beta;
-    float eps, momentum; float* running_mean; float* running_var; long long* num_batches_tracked; float* saved; void* y; int y_cs;
-    int relu, groups;
-};
-
-template <typename T>
-__device__ __forceinline__ void bn_train_apply_body(const BnApplyArgs& a, int bx, int gx) {
-    constexpr int VEC = Elem<T>::VEC;
-    const T* __restrict__ x = (const T*)a.x;
-    T* __restrict__ y = (T*)a.y;
-    const float* __restrict__ stats = a.stats;
-    const float* __restrict__ gamma = a.gamma;
-    const float* __restrict__ beta = a.beta;
-    float* running_mean = a.running_mean;
-    float* running_var = a.running_var;
-    float* __restrict__ saved = a.saved;
-    const int cv = a.cv, x_cs = a.x_cs, y_cs = a.y_cs, relu = a.relu, groups = a.groups;
-    const float count = a.count, eps = a.eps, momentum = a.momentum;
-    const long long pixels = a.pixels;
-    const int C = cv * VEC;
-    const long long mg = pixels / groups;
-    if (bx == 0) {
-        if (threadIdx.x == 0) bump_batches_tracked(a.num_batches_tracked, relu, groups);
-        for (int c = threadIdx.x; c < C; c += blockDim.x) {
-            const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-            float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 0.f;
-            for (int g_ = 0; g_ < groups; ++g_) {
-                const float* st = stats + (long long)g_ * 2 * C;
-                float* sv = saved + (long long)g_ * 4 * C;
-                const float m = st[c] / count;
-                const float var = fmaxf(st[C + c] / count - m * m, 0.f);
-                const float is = 1.0f / sqrtf(var + eps);
-                sv[c] = m;
-                sv[C + c] = is;
-                sv[2 * C + c] = g * is;
-                sv[3 * C + c] = b - m * g * is;
-                rm = (1.f - momentum) * rm + momentum * m;
-                const float unbiased = count > 1.f ? var * (count / (count - 1.f)) : var;
-                rv = (1.f - momentum) * rv + momentum * unbiased;
-            }
-            if (running_mean) running_mean[c] = rm;
-            if (running_var) running_var[c] = rv;
-        }
-        return;
-    }
-    const long long total = pixels * cv;
-    const long long stride = (long long)(gx - 1) * blockDim.x;
-    for (long long idx = (bx - 1) * (long long)blockDim.x + threadIdx.x; idx < total; idx += stride) {
-        const long long pix = idx / cv;
-        const int c = (int)(idx - pix * cv) * VEC;
-        const float* stats_g = groups > 1 ? stats + (pix / mg) * 2 * C : stats;
-        float f[VEC];
-        Elem<T>::unpack(ldg16(x + pix * x_cs + c), f);
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-            const float m = stats_g[c + i] / count;
-            const float var = fmaxf(stats_g[C + c + i] / count - m * m, 0.f);
-            const float is = 1.0f / sqrtf(var + eps);
-            const float sc = (gamma ? gamma[c + i] : 1.f) * is;
-            const float o = f[i] * sc + ((beta ? beta[c + i] : 0.f) - m * sc);
-            f[i] = relu_at(relu, c) ? fmaxf(o, 0.f) : o;
-        }
-        stg16(y + pix * y_cs + c, Elem<T>::pack(f));
-    }
-}
-
 template <typename T> __global__ void bn_train_apply_kernel(BnApplyArgs a) { bn_train_apply_body<T>(a, (int)blockIdx.x, (int)gridDim.x); }
 template <typename T> __global__ void bn_train_apply_group_kernel(GroupOf<BnApplyArgs> g) {
     const int bid = (int)blockIdx.x, i = group_locate(g, bid);
@@ -251,113 +185,6 @@ template <typename T> __global__ void bn_train_apply_group_kernel(GroupOf<BnAppl
 // MODE 0: stats  -> out[c] += sum x, out[C+c] += sum x^2
 // MODE 1: bn bwd -> out[c] += sum dz, out[C+c] += sum dz*xhat   (dz = dy * [y>0])
 // ---------------------------------------------------------------------------------------------------
-struct ChanReduceArgs {
-    long long pixels; int C; const void* x; int x_cs; const void* dy; int dy_cs; const void* yo; int y_cs; const float* mean;
-    const float* invstd; int relu; float* out; long long pix_per_block, group_pixels; int saved_stride; float* part;
-    unsigned int* counters; int nbx;          // nbx: blocks per BatchNorm group (the grouped form folds (block, group) into one index)
-};
-
-template <typename T, int MODE>
-__device__ __forceinline__ void chan_reduce_body(const ChanReduceArgs& a, int bx, int by, int nbx) {
-    constexpr int VEC = Elem<T>::VEC;
-    __shared__ float red[2][256][VEC + 1];
-    const T* __restrict__ x = (const T*)a.x;
-    const T* __restrict__ dy = (const T*)a.dy;
-    const T* __restrict__ yo = (const T*)a.yo;
-    const float* __restrict__ mean = a.mean;
-    const float* __restrict__ invstd = a.invstd;
-    float* __restrict__ out = a.out;
-    float* __restrict__ part = a.part;
-    unsigned int* counters = a.counters;
-    const int C = a.C, x_cs = a.x_cs, dy_cs = a.dy_cs, y_cs = a.y_cs, saved_stride = a.saved_stride;
-    const long long pix_per_block = a.pix_per_block, group_pixels = a.group_pixels;
-    // by = group: its pixel range, its output slot (2C floats) and its saved (mean, invstd) block
-    const long long g_first = by * group_pixels;
-    out += (long long)by * 2 * C;
-    if (MODE == 1) { mean += (long long)by * saved_stride; invstd += (long long)by * saved_stride; }
-    const long long pixels = g_first + group_pixels;
-    const int cv = C / VEC;
-    const int rpb = 256 / cv;            // pixel rows processed per iteration
-    const int tid = threadIdx.x;
-    const int col = tid % cv;
-    const int row = tid / cv;
-    const bool active = row < rpb;
-    const int relu = relu_at(a.relu, col * VEC) ? 1 : 0;
-    float a0[VEC], a1[VEC], mu[VEC], is[VEC];
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-        a0[i] = 0.f; a1[i] = 0.f; mu[i] = 0.f; is[i] = 1.f;
-        if (MODE == 1) { mu[i] = mean[col * VEC + i]; is[i] = invstd[col * VEC + i]; }
-    }
-    const long long p_begin = g_first + bx * pix_per_block;
-    long long p_end = p_begin + pix_per_block;
-    if (p_end > pixels) p_end = pixels;
-    if (active) {
-        for (long long pix = p_begin + row; pix < p_end; pix += rpb) {
-            float f[VEC];
-            Elem<T>::unpack(ldg16(x + pix * x_cs + col * VEC), f);
-            if (MODE == 0) {
-#pragma unroll
-                for (int i = 0; i < VEC; ++i) { a0[i] += f[i]; a1[i] += f[i] * f[i]; }
-            } else {
-                float g[VEC];
-                Elem<T>::unpack(ldg16(dy + pix * dy_cs + col * VEC), g);
-                if (relu) {
-                    float o[VEC];
-                    Elem<T>::unpack(ldg16(yo + pix * y_cs + col * VEC), o);
-#pragma unroll
-                    for (int i = 0; i < VEC; ++i) g[i] = o[i] > 0.f ? g[i] : 0.f;
-                }
-#pragma unroll
-                for (int i = 0; i < VEC; ++i) { a0[i] += g[i]; a1[i] += g[i] * (f[i] - mu[i]) * is[i]; }
-            }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) { red[0][tid][i] = a0[i]; red[1][tid][i] = a1[i]; }
-    __syncthreads();
-    // column sums: thread t < cv*VEC*2 reduces one (which, channel)
-    if (part == nullptr) {
-        for (int k = tid; k < 2 * C; k += 256) {
-            const int which = k / C, c = k - which * C;
-            const int cc = c / VEC, ci = c - cc * VEC;
-            float s = 0.f;
-            for (int r = 0; r < rpb; ++r) s += red[which][r * cv + cc][ci];
-            atomicAdd(out + which * C + c, s);
-        }
-        return;
-    }
-    // Deterministic form: the block's 2C column sums go to its slot of the workspace; the block that arrives LAST at the group's
-    // counter (integer atomic) adds the slots up in block order - eight interleaved row groups per column, combined in a fixed tree -
-    // and stores the totals.  Same bits whatever the block schedule; no float atomics.
-    __shared__ int s_last;
-    __shared__ float fin[8][33];
-    const int nb = nbx;
-    float* mine = part + ((long long)by * nb + bx) * 2 * C;
-    for (int k = tid; k < 2 * C; k += 256) {
-        const int which = k / C, c = k - which * C;
-        const int cc = c / VEC, ci = c - cc * VEC;
-        float s = 0.f;
-        for (int r = 0; r < rpb; ++r) s += red[which][r * cv + cc][ci];
-        store_coherent(mine + k, s);
-    }
-    if (!arrive_last(&counters[by], (unsigned int)nb, &s_last)) return;
-    const float* all = part + (long long)by * nb * 2 * C;
-    const int fc = tid & 31, rg = tid >> 5;
-    for (int k0 = 0; k0 < 2 * C; k0 += 32) {
-        const int k = k0 + fc;
-        float s = 0.f;
-        if (k < 2 * C)
-            for (int b = rg; b < nb; b += 8) s += load_coherent(all + (long long)b * 2 * C + k);
-        fin[rg][fc] = s;
-        __syncthreads();
-        if (rg == 0 && k < 2 * C)
-            out[k] = ((fin[0][fc] + fin[1][fc]) + (fin[2][fc] + fin[3][fc])) + ((fin[4][fc] + fin[5][fc]) + (fin[6][fc] + fin[7][fc]));
-        __syncthreads();
-    }
-    if (tid == 0) __hip_atomic_store(&counters[by], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 template <typename T, int MODE> __global__ __launch_bounds__(256) void chan_reduce_kernel(ChanReduceArgs a) {
     chan_reduce_body<T, MODE>(a, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x);
 }
@@ -448,6 +275,42 @@ template <typename T> __global__ void bn_bwd_apply_kernel(BnBwdApplyArgs a) { bn
 template <typename T> __global__ void bn_bwd_apply_group_kernel(GroupOf<BnBwdApplyArgs> g) {
     const int bid = (int)blockIdx.x, i = group_locate(g, bid);
     bn_bwd_apply_body<T>(g.p[i], bid - g.blk_start[i], g.blk_start[i + 1] - g.blk_start[i]);
+}
+
+// ---- mixed grouped launches: the problems of ONE launch take different bodies (bn_bodies.h) ---------------------------------------------
+// forward, first launch: column kernels of small maps (kind 1 / 2 = one / two groups), statistics passes (3), normalisation of maps
+// whose statistics the convolution's epilogue already left (0).  Backward, first launch: column kernels (1 / 2), reduction passes (3).
+struct BnMixedArgs {
+    int kind;
+    union {
+        BnColFwdArgs colf;
+        BnColBwdArgs colb;
+        BnApplyArgs app;
+        ChanReduceArgs red;
+    } u;
+};
+
+template <typename T> __global__ __launch_bounds__(256) void bn_fwd_mixed_group_kernel(GroupOf<BnMixedArgs> g) {
+    const int bid = (int)blockIdx.x, i = group_locate(g, bid);
+    const int local = bid - g.blk_start[i];
+    const BnMixedArgs& p = g.p[i];
+    switch (p.kind) {          // (uniform over the workgroup)
+        case 1: bn_small_fwd_body<T, 1>(p.u.colf, local); break;
+        case 2: bn_small_fwd_body<T, 2>(p.u.colf, local); break;
+        case 3: chan_reduce_body<T, 0>(p.u.red, local % p.u.red.nbx, local / p.u.red.nbx, p.u.red.nbx); break;
+        default: bn_train_apply_body<T>(p.u.app, local, g.blk_start[i + 1] - g.blk_start[i]); break;
+    }
+}
+
+template <typename T> __global__ __launch_bounds__(256) void bn_bwd_mixed_group_kernel(GroupOf<BnMixedArgs> g) {
+    const int bid = (int)blockIdx.x, i = group_locate(g, bid);
+    const int local = bid - g.blk_start[i];
+    const BnMixedArgs& p = g.p[i];
+    switch (p.kind) {
+        case 1: bn_small_bwd_body<T, 1>(p.u.colb, local); break;
+        case 2: bn_small_bwd_body<T, 2>(p.u.colb, local); break;
+        default: chan_reduce_body<T, 1>(p.u.red, local % p.u.red.nbx, local / p.u.red.nbx, p.u.red.nbx); break;
+    }
 }
 
 __global__ void bn_finalize_kernel(int C, float count, const float* __restrict__ stats, const float* __restrict__ gamma,
@@ -1158,5 +1021,90 @@ fs_status fs::axpy_group(void* stream, const AxpyCall* c, int n) {
             else { DT_DISPATCH(dtype, FS_LAUNCH((ew_group_kernel<T, EW_AXPY>), dim3(pk.grid), dim3(256), 0, st, pk.g);) }
         }
         return check_launch("fs_axpy_channels");
+    });
+}
+
+// ---- mixed drivers ---------------------------------------------------------------------------------------------------------------------------
+// kind[i]: 0 normalisation (statistics ready), 1 column kernel (the caller checked bn_small_ok), 3 statistics pass
+fs_status fs::bn_fwd_mixed_group(void* stream, const BnFwdCall* c, const int* idx, const int* kind, int n) {
+    hipStream_t st = (hipStream_t)stream;
+    return for_each_bucket(n, [&](int i) { return (long long)c[idx[i]].dtype; }, [&](const int* sub, int m) -> fs_status {
+        GroupOf<BnMixedArgs> g;
+        g.n = m;
+        int grid = 0;
+        double bytes = 0;
+        for (int j = 0; j < m; ++j) {
+            const BnFwdCall& q = c[idx[sub[j]]];
+            const int kd = kind[sub[j]];
+            BnMixedArgs& p = g.p[j];
+            int blocks = 0;
+            fs_status s;
+            if (kd == 1) {
+                if ((s = check_slice("fs_bn_group_fwd", q.z, q.z_cs, q.C, q.dtype)) != FS_OK) return s;
+                if ((s = check_slice("fs_bn_group_fwd", q.y, q.y_cs, q.C, q.dtype)) != FS_OK) return s;
+                FS_REQUIRE(q.saved && bn_small_ok(q.pixels, q.groups), FS_ERR_INVALID, "fs_bn_group_fwd: bad argument");
+                p.kind = q.groups;
+                p.u.colf = BnColFwdArgs{q.pixels, q.C, q.groups, q.z, q.z_cs, nullptr, 1, q.gamma, q.beta, q.eps, q.momentum, q.running_mean,
+                                        q.running_var, q.num_batches_tracked, q.saved, q.y, q.y_cs, q.relu};
+                blocks = q.C / vec_elems(q.dtype);
+                bytes += (double)q.pixels * q.C * elem_size(q.dtype) * 2;
+            } else if (kd == 3) {
+                if ((s = prep_stats(q, &p.u.red, &blocks)) != FS_OK) return s;
+                p.kind = 3;
+                bytes += (double)q.pixels * q.C * elem_size(q.dtype);
+            } else {
+                if ((s = prep_apply(q, &p.u.app, &blocks)) != FS_OK) return s;
+                p.kind = 0;
+                bytes += (double)q.pixels * q.C * elem_size(q.dtype) * 2;
+            }
+            g.blk_start[j] = grid;
+            grid += blocks;
+        }
+        for (int j = m; j <= FS_MAX_GROUP; ++j) g.blk_start[j] = grid;
+        const int dtype = c[idx[sub[0]]].dtype;
+        FS_REQUIRE(dtype == FS_F32 || dtype == FS_BF16, FS_ERR_INVALID, "bn_fwd_mixed_group: bad dtype");
+        FS_NOTE_BYTES(bytes);
+        DT_DISPATCH(dtype, FS_LAUNCH((bn_fwd_mixed_group_kernel<T>), dim3(grid), dim3(256), 0, st, g);)
+        return check_launch("fs_bn_act_train_fwd (grouped)");
+    });
+}
+
+// kind[i]: 1 column kernel, 3 reduction pass (its bn_bwd_apply follows in bn_bwd_apply_group)
+fs_status fs::bn_bwd_mixed_group(void* stream, const BnBwdCall* c, const int* idx, const int* kind, int n) {
+    hipStream_t st = (hipStream_t)stream;
+    return for_each_bucket(n, [&](int i) { return (long long)c[idx[i]].dtype; }, [&](const int* sub, int m) -> fs_status {
+        GroupOf<BnMixedArgs> g;
+        g.n = m;
+        int grid = 0;
+        double bytes = 0;
+        for (int j = 0; j < m; ++j) {
+            const BnBwdCall& q = c[idx[sub[j]]];
+            BnMixedArgs& p = g.p[j];
+            int blocks = 0;
+            fs_status s;
+            if (kind[sub[j]] == 1) {
+                if ((s = check_bwd("fs_bn_group_bwd", q)) != FS_OK) return s;
+                if ((s = check_slice("fs_bn_group_bwd", q.dz, q.dz_cs, q.C, q.dtype)) != FS_OK) return s;
+                FS_REQUIRE(bn_small_ok(q.pixels, q.groups), FS_ERR_INVALID, "fs_bn_group_bwd: bad argument");
+                FS_REQUIRE((q.dgamma_acc == nullptr) == (q.dbeta_acc == nullptr), FS_ERR_INVALID, "fs_bn_group_bwd: dgamma_acc/dbeta_acc go together");
+                p.kind = q.groups;
+                p.u.colb = BnColBwdArgs{q.pixels, q.C, q.groups, q.z, q.z_cs, q.dy, q.dy_cs, q.y, q.y_cs, q.saved, q.gamma, q.relu, q.dz, q.dz_cs, q.red,
+                                        q.dgamma_acc, q.dbeta_acc};
+                blocks = q.C / vec_elems(q.dtype);
+                bytes += (double)q.pixels * q.C * elem_size(q.dtype) * (q.relu ? 4 : 3);
+            } else {
+                if ((s = prep_bwd_reduce(q, &p.u.red, &blocks)) != FS_OK) return s;
+                p.kind = 3;
+                bytes += (double)q.pixels * q.C * elem_size(q.dtype) * (q.relu ? 3 : 2);
+            }
+            g.blk_start[j] = grid;
+            grid += blocks;
+        }
+        for (int j = m; j <= FS_MAX_GROUP; ++j) g.blk_start[j] = grid;
+        const int dtype = c[idx[sub[0]]].dtype;
+        FS_REQUIRE(dtype == FS_F32 || dtype == FS_BF16, FS_ERR_INVALID, "bn_bwd_mixed_group: bad dtype");
+        FS_NOTE_BYTES(bytes);
+        DT_DISPATCH(dtype, FS_LAUNCH((bn_bwd_mixed_group_kernel<T>), dim3(grid), dim3(256), 0, st, g);)
+        return check_launch("fs_bn_act_train_bwd (grouped)");
     });
 }

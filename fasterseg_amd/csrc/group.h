@@ -85,6 +85,10 @@ fs_status bn_stats_group(void* stream, const BnFwdCall* c, const int* idx, int n
 fs_status bn_apply_group(void* stream, const BnFwdCall* c, const int* idx, int n);
 fs_status bn_bwd_reduce_group(void* stream, const BnBwdCall* c, const int* idx, int n);
 fs_status bn_bwd_apply_group(void* stream, const BnBwdCall* c, const int* idx, int n);
+// ... and the MIXED launches: problems of one launch take different bodies (kind[i]: 0 normalisation, 1 column kernel, 3 statistics /
+// reduction pass), so the BatchNorm forward of all pending units is one launch and the backward two
+fs_status bn_fwd_mixed_group(void* stream, const BnFwdCall* c, const int* idx, const int* kind, int n);
+fs_status bn_bwd_mixed_group(void* stream, const BnBwdCall* c, const int* idx, const int* kind, int n);
 fs_status wsum_group(void* stream, const WsumCall* c, int n);            // out = sum_k coef[k] * ptrs[k]          (t = out map)
 fs_status wsum_bwd_group(void* stream, const WsumCall* c, int n);        // ptrs[k] = coef[k] * t                  (t = dy)
 fs_status wsum_dots_group(void* stream, const WsumCall* c, int n);       // out[k] += <t, ptrs[k]>                 (t = dy)

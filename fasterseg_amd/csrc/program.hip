@@ -18,7 +18,8 @@
 // Op word: bits 0-15 the op code, bits 16-39 the stream lane (multi-stream form), bit 40 JOIN = "independent of the NEXT command, which
 // has the same op": a run of joined bare convolutions (FS_OP_CONV_FWD) or strided weight gradients (FS_OP_WGRAD_STRIDED) goes out as ONE
 // grouped launch - the two 1x1 stride-2 convolutions of a FactorizedReduce (reference search/operations.py:521-526), their two weight
-// gradients and their two data gradients are one launch each instead of two (round 5).
+// gradients and their two data gradients are one launch each instead of two (round 5); round 6: also runs of any op with a grouped
+// form in group.h (the two up-samples of a stride-1 MixedOp's zoomed primitives, operations.py:275,444, forward and backward).
 #include <string.h>
 #include "conv_igemm.h"
 #include "group.h"
@@ -342,7 +343,13 @@ static fs_status run_pool(int op, int nargs, Args* pool, int n, void* stream, in
             }
             st = fs::wgrad_launch_group(stream, m, dp, xs, dys, dws, so, si, ts, q[0].pv[7], q[0].iv[8]);
         } else {
-            for (int i = 0; i < m && st == FS_OK; ++i) st = run_command(op, nargs, q[i], stream, index);
+            Args* qp[FS_MAX_GROUP];
+            for (int i = 0; i < m; ++i) qp[i] = &q[i];
+            st = m > 1 && fs::group_ew_enabled() ? run_grouped_ew(op, nargs, qp, m, stream) : FS_ERR_UNSUPPORTED;
+            if (st == FS_ERR_UNSUPPORTED) {
+                st = FS_OK;
+                for (int i = 0; i < m && st == FS_OK; ++i) st = run_command(op, nargs, q[i], stream, index);
+            }
         }
     }
     return st;

@@ -8,6 +8,7 @@
 // accumulation all happen here or inside the kernels.
 #include <string.h>
 #include "conv_igemm.h"
+#include "bn_bodies.h"
 
 // Maps up to this many pixels per group take the one-launch column-owner BatchNorm (bn_col.hip).  Measured on MI355X
 // (tools/bn_micro.py, bf16, launch + kernel): 96 px 6.3 vs 7.2 us for the two grid-wide launches, 384 px 7.6 vs 7.3, 1536 px
@@ -195,6 +196,27 @@ fs_status fs::bn_fwd_group(void* stream, const BnFwdCall* c, int n) {
         apply[n_apply++] = i;
     }
     fs_status s = FS_OK;
+    if (!grouped) return s;
+    static const bool mixed = [] { const char* e = getenv("FS_GROUP_BN_MIXED"); return !(e && e[0] == '0'); }();
+    if (mixed) {
+        // first launch: column kernels + statistics passes + the normalisation of every map whose statistics are ready; second launch:
+        // the normalisation of the maps that needed a statistics pass.  (Column maps with more than two groups keep their own kernel.)
+        int first[4 * FS_MAX_GROUP], kind[4 * FS_MAX_GROUP], second[4 * FS_MAX_GROUP], rest[4 * FS_MAX_GROUP];
+        int n_first = 0, n_second = 0, n_rest = 0;
+        for (int j = 0; j < n_col; ++j) {
+            if (bn_small_ok(c[col[j]].pixels, c[col[j]].groups)) { first[n_first] = col[j]; kind[n_first++] = 1; }
+            else rest[n_rest++] = col[j];
+        }
+        for (int j = 0; j < n_stats; ++j) { first[n_first] = stats[j]; kind[n_first++] = 3; }
+        for (int j = 0; j < n_apply; ++j) {
+            if (c[apply[j]].stats_ready) { first[n_first] = apply[j]; kind[n_first++] = 0; }
+            else second[n_second++] = apply[j];
+        }
+        if (n_rest) s = bn_col_fwd_group(stream, c, rest, n_rest);
+        if (s == FS_OK && n_first) s = bn_fwd_mixed_group(stream, c, first, kind, n_first);
+        if (s == FS_OK && n_second) s = bn_apply_group(stream, c, second, n_second);
+        return s;
+    }
     if (n_col) s = bn_col_fwd_group(stream, c, col, n_col);
     if (s == FS_OK && n_stats) s = bn_stats_group(stream, c, stats, n_stats);
     if (s == FS_OK && n_apply) s = bn_apply_group(stream, c, apply, n_apply);
@@ -230,6 +252,21 @@ fs_status fs::bn_bwd_group(void* stream, const BnBwdCall* c, int n) {
         else wide[n_wide++] = i;
     }
     fs_status s = FS_OK;
+    if (!grouped) return s;
+    static const bool mixed = [] { const char* e = getenv("FS_GROUP_BN_MIXED"); return !(e && e[0] == '0'); }();
+    if (mixed) {          // first launch: column kernels + reduction passes; second: the input gradients of the maps that were reduced
+        int first[4 * FS_MAX_GROUP], kind[4 * FS_MAX_GROUP], rest[4 * FS_MAX_GROUP];
+        int n_first = 0, n_rest = 0;
+        for (int j = 0; j < n_col; ++j) {
+            if (bn_small_ok(c[col[j]].pixels, c[col[j]].groups)) { first[n_first] = col[j]; kind[n_first++] = 1; }
+            else rest[n_rest++] = col[j];
+        }
+        for (int j = 0; j < n_wide; ++j) { first[n_first] = wide[j]; kind[n_first++] = 3; }
+        if (n_rest) s = bn_col_bwd_group(stream, c, rest, n_rest);
+        if (s == FS_OK && n_first) s = bn_bwd_mixed_group(stream, c, first, kind, n_first);
+        if (s == FS_OK && n_wide) s = bn_bwd_apply_group(stream, c, wide, n_wide);
+        return s;
+    }
     if (n_col) s = bn_col_bwd_group(stream, c, col, n_col);
     if (s == FS_OK && n_wide) s = bn_bwd_reduce_group(stream, c, wide, n_wide);
     if (s == FS_OK && n_wide) s = bn_bwd_apply_group(stream, c, wide, n_wide);

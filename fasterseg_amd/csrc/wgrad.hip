@@ -9,6 +9,7 @@
 //   bf16: tiles stay bf16 in LDS and feed v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate); an operand is 8 consecutive
 //         PIXELS of one channel, i.e. a column of the staged tile: two ds_read_b64_tr_b16 (gfx950's 16-bit transpose read) per
 //         operand - round 3 gathered it with eight ds_read_u16 and was LDS-issue bound.
+#include <type_traits>
 #include "common.h"
 
 namespace fs {
@@ -64,9 +65,20 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int bx, con
     __shared__ __attribute__((aligned(16))) LT sB[KC][LP];         // X   [pixel][ci]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    int wm = wave >> 1, wn = wave & 1;
     const int tile_co = by / p.tiles_ci, tile_ci = by % p.tiles_ci;
     const int co0 = tile_co * BCH, ci0 = tile_ci * BCH;
+    // Narrow tiles (round 6): the supernet's widths are multiples of 16 (32 ... 96 channels x 1, 2, 4), so the last 64-channel tile of a
+    // dimension often holds <= 32 valid channels and the waves of its second half would multiply zeros - (96 / 128)^2 = 56 % of the
+    // MFMAs of a 96 -> 96 gradient are real.  Those waves take the second half of every chunk's PIXELS for the first channel half
+    // instead (the partial sums meet in the fp32 atomics): a narrow tile costs 1/2 (1/4 when both dimensions are narrow) of a full one.
+    // fp32 is bound by its 1/16-rate MFMAs and gains the padding back; not in the bit-reproducible mode (one writer per element).
+    int ksplit = 1, kpart = 0;
+    if (p.part == nullptr) {
+        const bool nco = p.Cout - co0 <= 32, nci = p.Cin - ci0 <= 32;
+        if (nco) { ksplit *= 2; kpart = wm; wm = 0; }
+        if (nci) { kpart = kpart * 2 + wn; ksplit *= 2; wn = 0; }
+    }
     const int tap = bz;
     const int tr = tap / p.S, ts = tap - tr * p.S;
     const long long m_begin = bx * p.slab;
@@ -132,33 +144,42 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int bx, con
             store_chunk();
             __syncthreads();
             if (mc + KC < m_end) load_chunk(mc + KC);
-            if (NATIVE) {
-                // operand = 8 consecutive pixels (k) of one channel = a COLUMN of the [pixel][channel] tile: two ds_read_b64_tr_b16 (the
-                // 16-bit transpose read of gfx950: within a 16-lane group lane t supplies row t >> 2, column quad t & 3 of a [4][16] block
-                // and receives column t of it - tools/probes/tr16_probe.hip) instead of eight ds_read_u16 and their packing
-                typedef __attribute__((ext_vector_type(4))) short s16x4;
-                typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
-                const int g = lane >> 4, t = lane & 15;
-                const bf16_t* pa = reinterpret_cast<const bf16_t*>(&sA[(g >> 1) * 8 + (t >> 2)][wm * 32 + (g & 1) * 16 + (t & 3) * 4]);
-                const bf16_t* pb = reinterpret_cast<const bf16_t*>(&sB[(g >> 1) * 8 + (t >> 2)][wn * 32 + (g & 1) * 16 + (t & 3) * 4]);
+            // this wave's share of the chunk's pixels: [kpart, kpart + 1) * KC / ksplit (compile-time trip counts: the operand reads keep
+            // their immediate offsets)
+            auto mfma_part = [&](auto ks_tag) {
+                constexpr int KS = decltype(ks_tag)::value;
+                constexpr int KN = KC / KS;
+                if constexpr (NATIVE) {
+                    // operand = 8 consecutive pixels (k) of one channel = a COLUMN of the [pixel][channel] tile: two ds_read_b64_tr_b16 (the
+                    // 16-bit transpose read of gfx950: within a 16-lane group lane t supplies row t >> 2, column quad t & 3 of a [4][16] block
+                    // and receives column t of it - tools/probes/tr16_probe.hip) instead of eight ds_read_u16 and their packing
+                    typedef __attribute__((ext_vector_type(4))) short s16x4;
+                    typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+                    const int g = lane >> 4, t = lane & 15;
+                    const bf16_t* pa = reinterpret_cast<const bf16_t*>(&sA[kpart * KN + (g >> 1) * 8 + (t >> 2)][wm * 32 + (g & 1) * 16 + (t & 3) * 4]);
+                    const bf16_t* pb = reinterpret_cast<const bf16_t*>(&sB[kpart * KN + (g >> 1) * 8 + (t >> 2)][wn * 32 + (g & 1) * 16 + (t & 3) * 4]);
 #pragma unroll
-                for (int k = 0; k < KC; k += 16) {
-                    const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(pa + k * LP));
-                    const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(pa + (k + 4) * LP));
-                    const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(pb + k * LP));
-                    const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(pb + (k + 4) * LP));
-                    typedef __attribute__((ext_vector_type(8))) short s16x8;
-                    const s16x8 a = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
-                    const s16x8 b = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc,
-                                                                  0, 0, 0);
+                    for (int k = 0; k < KN; k += 16) {
+                        const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(pa + k * LP));
+                        const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(pa + (k + 4) * LP));
+                        const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(pb + k * LP));
+                        const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(pb + (k + 4) * LP));
+                        typedef __attribute__((ext_vector_type(8))) short s16x8;
+                        const s16x8 a = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+                        const s16x8 b = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc,
+                                                                      0, 0, 0);
+                    }
+                } else {
+                    const float* pa = reinterpret_cast<const float*>(&sA[kpart * KN + (lane >> 5)][0]) + wm * 32 + (lane & 31);
+                    const float* pb = reinterpret_cast<const float*>(&sB[kpart * KN + (lane >> 5)][0]) + wn * 32 + (lane & 31);
+#pragma unroll
+                    for (int k = 0; k < KN; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[k * PITCH], pb[k * PITCH], acc, 0, 0, 0);
                 }
-            } else {
-                const float* pa = reinterpret_cast<const float*>(&sA[lane >> 5][0]) + wm * 32 + (lane & 31);
-                const float* pb = reinterpret_cast<const float*>(&sB[lane >> 5][0]) + wn * 32 + (lane & 31);
-#pragma unroll
-                for (int k = 0; k < KC; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[k * PITCH], pb[k * PITCH], acc, 0, 0, 0);
-            }
+            };
+            if (ksplit == 1) mfma_part(std::integral_constant<int, 1>{});
+            else if (ksplit == 2) mfma_part(std::integral_constant<int, 2>{});
+            else mfma_part(std::integral_constant<int, 4>{});
             __syncthreads();
         }
     }
@@ -244,7 +265,8 @@ extern "C" fs_status fs_conv2d_wgrad_ws(void* stream, const fs_conv_desc* d, con
 }
 
 static fs_status wgrad_prepare(const fs_conv_desc* d, const void* x, const void* dy, float* dw_packed, long long o_stride,
-                               long long i_stride, long long t_stride, void* workspace, long long workspace_bytes, WgradArgs* out, dim3* grid_out) {
+                               long long i_stride, long long t_stride, void* workspace, long long workspace_bytes, WgradArgs* out, dim3* grid_out,
+                               int blocks_wanted = 0) {
     FS_REQUIRE(d && x && dy && dw_packed, FS_ERR_INVALID, "fs_conv2d_wgrad: null argument");
     FS_REQUIRE(d->dtype == FS_F32 || d->dtype == FS_BF16, FS_ERR_INVALID, "fs_conv2d_wgrad: bad dtype");
     const int vec = vec_elems(d->dtype);
@@ -276,7 +298,10 @@ static fs_status wgrad_prepare(const fs_conv_desc* d, const void* x, const void*
     // of >= 8 chunks: 34.7 ms; 512 / 4: 35.1; 256 / 8: 42.1; 4096 / 2: 65.5.  FS_WGRAD_BLOCKS / FS_WGRAD_MIN_CHUNKS override.
     static const int target_blocks = [] { const char* e = getenv("FS_WGRAD_BLOCKS"); return e && atoi(e) > 0 ? atoi(e) : 1024; }();
     static const int min_chunks = [] { const char* e = getenv("FS_WGRAD_MIN_CHUNKS"); return e && atoi(e) > 0 ? atoi(e) : 1; }();
-    long long slabs = (target_blocks + other - 1) / other;
+    // (a grouped launch fills the chip with all its problems together: each problem is asked for its share of the blocks - fewer,
+    // longer slabs, i.e. fewer atomics per gradient element and more chunks per block to pipeline)
+    const int want = blocks_wanted > 0 ? blocks_wanted : target_blocks;
+    long long slabs = (want + other - 1) / other;
     const int KC = d->dtype == FS_F32 ? Chunk<float>::KC : Chunk<bf16_t>::KC;
     const long long slab_min = (long long)min_chunks * KC > SLAB_MIN_PIXELS ? (long long)min_chunks * KC : SLAB_MIN_PIXELS;
     const long long max_slabs = (M + slab_min - 1) / slab_min;
@@ -342,9 +367,20 @@ fs_status fs::wgrad_launch_group(void* stream, int n, const fs_conv_desc* const*
     g.n = n;
     int total = 0;
     double share[WG_MAX_GROUP], sum = 0;
+    // blocks of the whole launch (FS_WGRAD_GROUP_BLOCKS), shared out in proportion to the problems' work.  Measured on the C3 step
+    // (profiles/r06_group_sweeps.txt): every problem at its own 1024 blocks 57.6 ms, 4096 per launch 57.0, 2048 57.4, 1024 54.5, 512 53.2
+    // (bf16: the launch is bound by its fp32 atomics, one per gradient element per slab); fp32 is bound by the MFMAs and does not care.
+    static const int group_blocks = [] { const char* e = getenv("FS_WGRAD_GROUP_BLOCKS"); return e && atoi(e) > 0 ? atoi(e) : 512; }();
+    double work[WG_MAX_GROUP], work_sum = 0;
+    for (int i = 0; i < n; ++i) {
+        work[i] = (double)d[i]->N * d[i]->Ho * d[i]->Wo * ((d[i]->Cout + BCH - 1) / BCH) * ((d[i]->Cin + BCH - 1) / BCH) * d[i]->R * d[i]->S;
+        work_sum += work[i];
+    }
     for (int i = 0; i < n; ++i) {
         dim3 grid;
-        const fs_status ps = wgrad_prepare(d[i], x[i], dy[i], dw[i], o_stride[i], i_stride[i], t_stride[i], nullptr, 0, &g.p[i], &grid);
+        int want = (int)(group_blocks * work[i] / work_sum);
+        if (want < 64) want = 64;
+        const fs_status ps = wgrad_prepare(d[i], x[i], dy[i], dw[i], o_stride[i], i_stride[i], t_stride[i], nullptr, 0, &g.p[i], &grid, want);
         if (ps != FS_OK) return ps;
         g.blk_start[i] = total;
         total += (int)(grid.x * grid.y * grid.z);

@@ -640,7 +640,10 @@ def scale_accumulate(acc, x, coef):
 def _own(grad, for_leaf):
     """Coefficient gradients are slices of the step's zero arena (kernels.zero_pool: valid until the next step clears it).  Every
     consumer inside the product copies or accumulates them (the coefficients are computed tensors: unbind / select / mul backward) -
-    but an AccumulateGrad node of a LEAF with no .grad yet may adopt the incoming tensor as .grad, which must then own its memory."""
+    but an AccumulateGrad node of a LEAF with no .grad yet may adopt the incoming tensor as .grad, which must then own its memory.
+    LIFETIME: a NON-leaf coefficient's gradient that escapes the backward - torch.autograd.grad(loss, coef), coef.retain_grad(),
+    a tensor hook that keeps its argument - is a VIEW of the arena: read or clone it before the next FlatGradientSync.prepare() /
+    zero_pool.reset(), which re-zeroes the arena (inside a captured pass: before the next replay)."""
     return grad.clone() if for_leaf and grad is not None else grad
 
 

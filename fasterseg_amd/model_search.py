@@ -189,6 +189,8 @@ _LAYER_SPLIT = max(1, int(os.environ.get("FS_LAYER_SPLIT", "1")))
 # hipGraphs, then issue the launches the capture would have recorded (ungrouped unless FS_GROUP_CAPTURE), so that the census times the
 # kernels of the timed steps and agrees with a rocprofv3 table of them.
 MIMIC_CAPTURE = False
+# set by train_step.SupernetStep._set_phase while only the ~600 "probe" tensors follow the phase flips (see there)
+FAST_PHASE_ACTIVE = False
 
 _RECORD_STREAM = bool(int(os.environ.get("FS_RECORD_STREAM", "1")))
 
@@ -237,6 +239,12 @@ def _run_tasks(tasks):
             with FN.bn_groups(groups):
                 prog = op._program(FN.as_nhwc(x), coef, widths[0], widths[1])
         if prog is None:
+            # train_step's fast phase flip leaves the cell weights trainable during the architecture phase: correct only while every
+            # MixedOp runs from a launch program (which asks its probe weight); a per-module fallback would compute - and accumulate into
+            # the live flat gradient - weight gradients nobody wants
+            assert not (FAST_PHASE_ACTIVE and op.training and torch.is_grad_enabled() and not op._ops[1].conv1.weight.requires_grad
+                        and any(p.requires_grad for p in op._ops[3].parameters())), \
+                "a MixedOp fell back to the per-module path while only the probe weights carry the phase (FS_FAST_PHASE=0 to disable)"
             op.set_prun_ratio((widths[0], widths[1]))
         group = _GROUP_PROGRAMS and (not capturing or _GROUP_CAPTURE)
         if MIMIC_CAPTURE and not capturing and not _SAMPLING_PASS:

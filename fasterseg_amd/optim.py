@@ -128,4 +128,6 @@ class FlatSGD:
         return self.last_norm
 
     def zero_grad(self, set_to_none=True):
-        pass                                # FlatGradientSync.prepare() owns the gradient buffer
+        """FlatGradientSync.prepare() owns (and clears) the gradient buffer: nothing to zero here.  The .grad views are left in place -
+        dropping them would need FlatGradientSync.invalidate() so that the next prepare() re-points every parameter."""
+        return

@@ -112,17 +112,32 @@ class FlatGradientSync:
         self.handles = {}
         self.pending = [0] * len(self.buckets)
         self._touched = [False] * len(self.params)
-        # point every .grad at its slice: only the parameters sync() hid last time (and anything re-homed since) need touching - the
-        # supernet has ~40 k parameters and the step is host-bound (a full loop is ~1 ms of pure Python per step, twice)
+        # point every .grad at its slice: only the parameters sync() hid last time need touching - the supernet has ~40 k parameters and
+        # the step is host-bound (a full loop is ~1 ms of pure Python per step, twice).  Anything ELSE that drops or re-homes a .grad
+        # between steps (model.zero_grad(), whose default is set_to_none=True; user code) must call invalidate(); as a net under callers
+        # that do not, a spread sample of the parameters is checked here and a mismatch takes the full loop (autograd would
+        # otherwise accumulate into fresh tensors outside the flat buffer, the optimizer would read zeros and training stop silently).
         hidden = self._hidden
+        params, views = self.params, self.views
+        if hidden is not None:
+            hid = set(hidden)
+            n = len(params)
+            for i in range(0, n, max(1, n // 64)):
+                if i not in hid and params[i].grad is not views[i]:
+                    hidden = None
+                    break
         if hidden is None:
-            for p, v in zip(self.params, self.views):
+            for p, v in zip(params, views):
                 p.grad = v
         else:
-            params, views = self.params, self.views
             for i in hidden:
                 params[i].grad = views[i]
         self._hidden = []
+
+    def invalidate(self):
+        """Some .grad was dropped or replaced behind this object's back (zero_grad(set_to_none=True), manual p.grad = None): the next
+        prepare() re-points EVERY parameter at its slice of the flat buffer."""
+        self._hidden = None
 
     def sync(self):
         """Call after backward: finish the all-reduce of every bucket, average, hide untouched parameters from the
@@ -173,9 +188,10 @@ def broadcast_parameters(module, src=0, group=None):
     seen = set()
     for t in list(module.parameters()) + list(module.buffers()):
         t = t.data
-        if t.numel() == 0 or id(t) in seen:
+        key = (t.data_ptr(), t.numel(), t.dtype)      # (`t.data` is a fresh Python object per access: id() never repeats - ADVICE r5)
+        if t.numel() == 0 or key in seen:
             continue
-        seen.add(id(t))
+        seen.add(key)
         by_kind.setdefault((t.dtype, t.device), []).append(t)
     collectives = 0
     for (dtype, device), tensors in by_kind.items():
@@ -188,4 +204,14 @@ def broadcast_parameters(module, src=0, group=None):
         else:
             for t, piece in zip(tensors, pieces):
                 t.copy_(piece)
+    # the scatter-back writes through .data: parameter version counters do not move, so everything keyed on them must be told
+    # (resident filter packs, the supernet's cached beta tables and width read-backs).  Call this BEFORE the first step where possible.
+    from . import functional as FN
+    FN.bump_weights_epoch()
+    if hasattr(module, "note_arch_update"):
+        module.note_arch_update()
+    for m in module.modules():
+        cache = m.__dict__.get("_beta_pos_cache")
+        if cache is not None:
+            cache.clear()
     return collectives

@@ -376,12 +376,13 @@ class _Lowering:
         return y, backward, cout
 
     # -- bilinear resize (align_corners=True) --------------------------------------------------------
-    def resize(self, x, Ho, Wo, relu):
+    def resize(self, x, Ho, Wo, relu, join=False):
+        """join: the NEXT command is another, independent resample (the executor issues the run as one grouped launch)."""
         f = self.f
         y = self.new(f, SAVE, x.N, x.C, Ho, Wo)
-        f.emit(OP_BILINEAR_FWD, _Desc(ResizeDesc(x.N, x.H, x.W, Ho, Wo, x.C, x.cs, y.cs, self.dt, int(relu), 0)), x.ref, y.ref)
+        f.emit(OP_BILINEAR_FWD, _Desc(ResizeDesc(x.N, x.H, x.W, Ho, Wo, x.C, x.cs, y.cs, self.dt, int(relu), 0)), x.ref, y.ref, join=join)
 
-        def backward(dy, need_x, dx_into=None):
+        def backward(dy, need_x, dx_into=None, join=False):
             if not need_x:
                 return None
             bl = self.b
@@ -389,7 +390,7 @@ class _Lowering:
                 raise NotImplementedError("strided gradient into a ReLU-fused resize")
             dx = dx_into if dx_into is not None else self.new(bl, TMPB, x.N, x.C, x.H, x.W)
             bl.emit(OP_BILINEAR_BWD, _Desc(ResizeDesc(x.N, x.H, x.W, Ho, Wo, x.C, dx.cs, dy.cs, self.dt, int(relu), 0)), dy.ref,
-                    y.ref if relu else NULL, dx.ref)
+                    y.ref if relu else NULL, dx.ref, join=join)
             return dx
         return y, backward
 
@@ -501,6 +502,8 @@ _FUSE = bool(int(os.environ.get("FS_FUSE_MIXEDOP", "1")))
 # FactorizedReduce (operations.py:521-526): its two 1x1 stride-2 convolutions, their weight gradients and their data gradients as one
 # grouped launch each (JOIN bit).  FS_JOIN_FR=0: one launch per convolution (the round-4 programs).
 _JOIN_FR = bool(int(os.environ.get("FS_JOIN_FR", "1")))
+# the two up-samples of a stride-1 MixedOp's zoomed primitives, forward and backward, as one grouped launch each (round 6; 0: two launches)
+_JOIN_UP = bool(int(os.environ.get("FS_JOIN_UP", "1")))
 
 
 def _lower_fused(lo, x, mixed, need_x):
@@ -539,8 +542,8 @@ def _lower_fused(lo, x, mixed, need_x):
     y4, bw4 = lo.unit(yb.channels(c, c), du2x.conv2, du2x.bn2, not upsample)
     y2 = yb.channels(0, c)
     bw_up2 = bw_up4 = None
-    if upsample:
-        y2, bw_up2 = lo.resize(y2, x.H, x.W, True)
+    if upsample:          # the two zoomed primitives' up-samples (operations.py:275,444): independent, one grouped launch (JOIN)
+        y2, bw_up2 = lo.resize(y2, x.H, x.W, True, join=_JOIN_UP)
         y4, bw_up4 = lo.resize(y4, x.H, x.W, True)
     outs = [y0, ya.channels(0, c), y2, y3, y4]
     b = lo.b
@@ -552,7 +555,7 @@ def _lower_fused(lo, x, mixed, need_x):
 
     def run_backward():
         if upsample:
-            bw_up2(grads[2], True, dx_into=dcat_b.channels(0, c))
+            bw_up2(grads[2], True, dx_into=dcat_b.channels(0, c), join=_JOIN_UP)
             d4 = bw_up4(grads[4], True)
         else:
             d4 = grads[4]

@@ -218,7 +218,10 @@ class SupernetStep:
             return
         self._phase = phase
         weights = self.weights
-        if self.use_graphs and getattr(self, "_capture_done", False) and _FAST_PHASE:
+        from . import model_search as _ms
+        if self.use_graphs and getattr(self, "_capture_done", False) and _FAST_PHASE and _ms._PROGRAMS:
+            # (only with launch programs: a MixedOp on the per-module path reads requires_grad of EVERY weight - ADVICE r5; _run_tasks
+            # asserts that no MixedOp falls back to it while the subset is in charge)
             # A search iteration flips the phase twice: 80 k requires_grad_ calls = ~16 ms of a host-bound 160 ms step.  Once the
             # fixed-width passes are captured, the flags are only read (a) by autograd for the modules that run module by module in the
             # eager passes - stem, refine, heads - and (b) by MixedOp._program, which asks ONE weight per MixedOp whether the launch
@@ -232,6 +235,7 @@ class SupernetStep:
                 cells = {id(p) for p in self.model.cells.parameters()}
                 self._phase_weights = [p for p in self.weights if id(p) in probe or id(p) not in cells]
             weights = self._phase_weights
+            _ms.FAST_PHASE_ACTIVE = True
         for p in weights:
             p.requires_grad_(phase == "w")
         for p in self.arch_params:
