@@ -130,6 +130,8 @@ _SPECIAL = {
     "fs_workspace_counter_bytes": ([], c_ll),
     "fs_set_deterministic": ([c_int], None),
     "fs_get_deterministic": ([], c_int),
+    "fs_set_fp32_split": ([c_int], None),
+    "fs_get_fp32_split": ([], c_int),
     "fs_census_enable": ([c_int], None),
     "fs_census_read": ([c_vp, c_int], c_int),
     "fs_census_read_kernels": ([c_vp, c_int], c_int),

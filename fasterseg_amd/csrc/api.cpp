@@ -22,6 +22,9 @@ int g_deterministic = [] { const char* e = getenv("FS_DETERMINISTIC"); return (e
 extern "C" void fs_set_deterministic(int on) { fs::g_deterministic = on ? 1 : 0; }
 extern "C" int fs_get_deterministic(void) { return fs::g_deterministic; }
 extern "C" const char* fs_last_error(void) { return fs::g_err; }
+namespace fs { int g_fp32x3 = [] { const char* e = getenv("FS_FP32_X3"); return e ? atoi(e) : 1; }(); }
+extern "C" void fs_set_fp32_split(int on) { fs::g_fp32x3 = on ? 1 : 0; }
+extern "C" int fs_get_fp32_split(void) { return fs::g_fp32x3; }
 extern "C" int fs_version(void) { return FS_ABI_VERSION; }
 /* sizeof of the descriptor structs this library was compiled with (0: conv, 1: resize, 2: zoom, 3: sgd tensor): a binding whose
  * struct layout differs from the header it was written against must fail at load, not read garbage fields. */

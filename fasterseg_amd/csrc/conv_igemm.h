@@ -13,6 +13,8 @@ struct ConvArgs {
     const float* scale;
     const float* shift;
     float* stats;
+    int stats_gp;         // > 0: the batch is M / stats_gp independently normalised groups of stats_gp pixels (fs_conv_desc.bn_groups) and
+                          //   stats holds [group][2][Cout]; needs stats_gp % 32 == 0 (an MFMA sub-tile never straddles two groups); 0: one group
     int H, W, Cin, Cout, S, stride, pad, Ho, Wo;
     int x_cs, y_cs;
     int M, K, HoWo;
@@ -50,6 +52,47 @@ template <> struct Mma<bf16_t> {
                                                     0, 0, 0);
     }
 };
+
+// ---- fp32 x fp32 -> fp32 on the bf16 matrix cores (round 6) -------------------------------------------------------------------------
+// gfx950 runs the fp32 MFMA at 1/16 of the bf16 rate (157 vs 2500 TFLOP/s; CDNA4 dropped xf32), and the reference trains in fp32.  Each
+// fp32 operand is split EXACTLY into three bf16 pieces by truncation (x = h + m + l: 8 + 8 + 8 significant bits; bf16 has fp32's
+// exponent range), and a.b is accumulated from the eight partial products h.h, h.m, m.h, m.m, h.l, l.h, m.l, l.m in the fp32
+// accumulator - only l.l (2^-32 relative) is dropped, every bf16 x bf16 product is exact in fp32, so the result differs from the fp32
+// MFMA's only in the order of the accumulation roundings.  One call contracts 16 values of K with 8 bf16 MFMAs (256 clocks) where the
+// fp32 MFMA needs 8 x 64 = 512; the split costs ~5 VALU per element (and / sub / perm), issued under the MFMAs.
+// x: the lane's 8 K slots (any assignment of K values to (half-wave, slot) that A and B share).
+__device__ __forceinline__ void split3_bf16(const float (&x)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
+    u32x4 hp, mp, lp;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t x0 = __float_as_uint(x[2 * q]), x1 = __float_as_uint(x[2 * q + 1]);
+        const float r0 = x[2 * q] - __uint_as_float(x0 & 0xffff0000u), r1 = x[2 * q + 1] - __uint_as_float(x1 & 0xffff0000u);
+        const uint32_t y0 = __float_as_uint(r0), y1 = __float_as_uint(r1);
+        const float s0 = r0 - __uint_as_float(y0 & 0xffff0000u), s1 = r1 - __uint_as_float(y1 & 0xffff0000u);
+        hp[q] = __builtin_amdgcn_perm(x1, x0, 0x07060302u);          // (high half of x0, high half of x1): two truncated bf16
+        mp[q] = __builtin_amdgcn_perm(y1, y0, 0x07060302u);
+        lp[q] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+    }
+    h = __builtin_bit_cast(bf16x8, hp);
+    m = __builtin_bit_cast(bf16x8, mp);
+    l = __builtin_bit_cast(bf16x8, lp);
+}
+struct Split3 {
+    bf16x8 h, m, l;
+};
+__device__ __forceinline__ void mma_x3(const Split3& a, const Split3& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b.m, c, 0, 0, 0);          // smallest terms first
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.l, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b.h, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.l, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.m, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.h, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.m, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.h, c, 0, 0, 0);
+}
+// FS_FP32_X3 (default 1): the fp32 convolutions and weight gradients use the split form where their tiling allows it
+extern int g_fp32x3;
+constexpr int ABL_X3 = 5;                  // igemm2_body's ABL value of the split form (shares the template slot of the measurement builds)
 
 constexpr int CONV_CLASSES = 0x400;        // internal flag (conv_igemm2): FS_CONV_TRANSPOSED evaluated per output-parity class (no zero taps)
 constexpr int cmax(int a, int b) { return a > b ? a : b; }

@@ -435,13 +435,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
                     }
                 }
             }
-        }
-        if (p.stats) {   // rows beyond M and padded K contribute exact zeros
-            s1 += __shfl_xor(s1, 32, 64);
-            s2 += __shfl_xor(s2, 32, 64);
-            if (lane < 32 && cvalid) {
-                atomicAdd(p.stats + co, s1);
-                atomicAdd(p.stats + p.Cout + co, s2);
+            // statistics: once per wave tile, or (grouped batch) per 32-row sub-tile into its group's slot.  Rows beyond M and padded K
+            // contribute exact zeros.
+            if (p.stats && (p.stats_gp > 0 ? mbase < p.M : i == WM_T - 1)) {
+                s1 += __shfl_xor(s1, 32, 64);
+                s2 += __shfl_xor(s2, 32, 64);
+                if (lane < 32 && cvalid) {
+                    float* st = p.stats + (p.stats_gp > 0 ? (long long)(mbase / p.stats_gp) * 2 * p.Cout : 0);
+                    atomicAdd(st + co, s1);
+                    atomicAdd(st + p.Cout + co, s2);
+                }
+                s1 = 0.f;
+                s2 = 0.f;
             }
         }
     }
@@ -681,6 +686,7 @@ fs_status fs::conv_prepare(const fs_conv_desc* d, const void* x, const void* w_p
     a.scale = scale;
     a.shift = shift;
     a.stats = stats;
+    a.stats_gp = 0;
     a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.S = d->S;
     a.stride = d->stride; a.pad = d->pad; a.Ho = d->Ho; a.Wo = d->Wo;
     a.x_cs = d->x_cs; a.y_cs = d->y_cs;

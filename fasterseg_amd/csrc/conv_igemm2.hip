@@ -248,6 +248,32 @@ __device__ __forceinline__ void igemm2_body(const ConvArgs& p, const int bid, co
     };
     auto mma = [&](const Frags& f) {
         if (ABL == 1) return;
+        if constexpr (ABL == ABL_X3 && sizeof(T) == 4 && KU % 2 == 0) {
+            // fp32 on the bf16 matrix cores (conv_igemm.h): two 32-byte K units = the lane's 8 K slots of one 16-deep contraction
+#pragma unroll
+            for (int kk = 0; kk < KU; kk += 2) {
+                Split3 sa[WM_T], sb[WN_T];
+#pragma unroll
+                for (int i = 0; i < WM_T; ++i) {
+                    float x[8];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { x[q] = __uint_as_float(f.a[kk][i][q]); x[4 + q] = __uint_as_float(f.a[kk + 1][i][q]); }
+                    split3_bf16(x, sa[i].h, sa[i].m, sa[i].l);
+                }
+#pragma unroll
+                for (int j = 0; j < WN_T; ++j) {
+                    float x[8];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { x[q] = __uint_as_float(f.b[kk][j][q]); x[4 + q] = __uint_as_float(f.b[kk + 1][j][q]); }
+                    split3_bf16(x, sb[j].h, sb[j].m, sb[j].l);
+                }
+#pragma unroll
+                for (int i = 0; i < WM_T; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN_T; ++j) mma_x3(sa[i], sb[j], acc[i][j]);
+            }
+            return;
+        }
 #pragma unroll
         for (int kk = 0; kk < KU; ++kk)
 #pragma unroll
@@ -413,13 +439,18 @@ __device__ __forceinline__ void igemm2_body(const ConvArgs& p, const int bid, co
                     }
                 }
             }
-        }
-        if (p.stats) {   // rows beyond M and the K tail contribute exact zeros
-            s1 += __shfl_xor(s1, 32, 64);
-            s2 += __shfl_xor(s2, 32, 64);
-            if (lane < 32 && cvalid) {
-                atomicAdd(p.stats + co, s1);
-                atomicAdd(p.stats + p.Cout + co, s2);
+            // statistics: once per wave tile, or (grouped batch, never a parity-class launch) per 32-row sub-tile into its group's slot.
+            // Rows beyond M and the K tail contribute exact zeros.
+            if (p.stats && (p.stats_gp > 0 ? m0 + rbase < Mc : i == WM_T - 1)) {
+                s1 += __shfl_xor(s1, 32, 64);
+                s2 += __shfl_xor(s2, 32, 64);
+                if (lane < 32 && cvalid) {
+                    float* st = p.stats + (p.stats_gp > 0 ? (long long)((m0 + rbase) / p.stats_gp) * 2 * p.Cout : 0);
+                    atomicAdd(st + co, s1);
+                    atomicAdd(st + p.Cout + co, s2);
+                }
+                s1 = 0.f;
+                s2 = 0.f;
             }
         }
     }
@@ -435,13 +466,13 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(ConvArgs p) {
 // drain + boundary whatever its size): the launch programs of a layer's MixedOps are replayed in lockstep (program.hip) and the
 // convolutions at the same position go out together - the problems' arguments travel as kernel arguments, a workgroup finds its
 // problem with a scalar search over the block prefix and runs the single-problem body on its local block id.
-template <typename T, int WAVES_M, int WAVES_N, int WAVES_K, int WM_T, int WN_T, int NSTAGE>
+template <typename T, int WAVES_M, int WAVES_N, int WAVES_K, int WM_T, int WN_T, int NSTAGE, int ABL = 0>
 __global__ __launch_bounds__(256) void conv_igemm2_group_kernel(ConvGroupArgs g) {
     const int bid = (int)blockIdx.x;
     int i = 0;
 #pragma unroll
     for (int k = 1; k < FS_MAX_GROUP; ++k) i += (k < g.n && bid >= g.blk_start[k]) ? 1 : 0;
-    igemm2_body<T, WAVES_M, WAVES_N, WAVES_K, WM_T, WN_T, NSTAGE, 0>(g.p[i], bid - g.blk_start[i], g.blk_start[i + 1] - g.blk_start[i]);
+    igemm2_body<T, WAVES_M, WAVES_N, WAVES_K, WM_T, WN_T, NSTAGE, ABL>(g.p[i], bid - g.blk_start[i], g.blk_start[i + 1] - g.blk_start[i]);
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------------
@@ -451,7 +482,29 @@ struct Cfg2 {
 static const Cfg2 CFG2[] = {{64, 64}, {128, 64}, {64, 128}, {128, 128}, {32, 32}, {64, 32}, {32, 64}, {32, 32}, {64, 64}};
 [[maybe_unused]] constexpr int NCFG2 = (int)(sizeof(CFG2) / sizeof(CFG2[0]));
 
+// the fp32 instantiations on the bf16 matrix cores (ABL_X3): every configuration whose waves contract >= 2 K units per stage
+static bool launch2_x3(hipStream_t st, const ConvArgs& a, int cfg, int grid) {
+    switch (cfg) {
+        case 0: FS_LAUNCH((conv_igemm2_kernel<float, 2, 2, 1, 1, 1, 4, ABL_X3>), dim3((unsigned)grid), dim3(256), 0, st, a); return true;
+        case 1: FS_LAUNCH((conv_igemm2_kernel<float, 2, 2, 1, 2, 1, 4, ABL_X3>), dim3((unsigned)grid), dim3(256), 0, st, a); return true;
+        case 2: FS_LAUNCH((conv_igemm2_kernel<float, 2, 2, 1, 1, 2, 4, ABL_X3>), dim3((unsigned)grid), dim3(256), 0, st, a); return true;
+        case 3: FS_LAUNCH((conv_igemm2_kernel<float, 2, 2, 1, 2, 2, 3, ABL_X3>), dim3((unsigned)grid), dim3(256), 0, st, a); return true;
+        case 5: FS_LAUNCH((conv_igemm2_kernel<float, 2, 1, 2, 1, 1, 4, ABL_X3>), dim3((unsigned)grid), dim3(256), 0, st, a); return true;
+        case 6: FS_LAUNCH((conv_igemm2_kernel<float, 1, 2, 2, 1, 1, 4, ABL_X3>), dim3((unsigned)grid), dim3(256), 0, st, a); return true;
+        default: return false;
+    }
+}
+static bool launch2_group_x3(hipStream_t st, const ConvGroupArgs& g, int cfg, int grid) {
+    switch (cfg) {
+        case 0: FS_LAUNCH((conv_igemm2_group_kernel<float, 2, 2, 1, 1, 1, 4, ABL_X3>), dim3((unsigned)grid), dim3(256), 0, st, g); return true;
+        case 5: FS_LAUNCH((conv_igemm2_group_kernel<float, 2, 1, 2, 1, 1, 4, ABL_X3>), dim3((unsigned)grid), dim3(256), 0, st, g); return true;
+        case 6: FS_LAUNCH((conv_igemm2_group_kernel<float, 1, 2, 2, 1, 1, 4, ABL_X3>), dim3((unsigned)grid), dim3(256), 0, st, g); return true;
+        default: return false;
+    }
+}
+
 template <typename T> static void launch2(hipStream_t st, const ConvArgs& a, int cfg, int grid) {
+    if (sizeof(T) == 4 && g_fp32x3 && launch2_x3(st, a, cfg, grid)) return;
     switch (cfg) {
         case 0: FS_LAUNCH((conv_igemm2_kernel<T, 2, 2, 1, 1, 1, 4>), dim3((unsigned)grid), dim3(256), 0, st, a); break;    // 64 x 64
         case 1: FS_LAUNCH((conv_igemm2_kernel<T, 2, 2, 1, 2, 1, 4>), dim3((unsigned)grid), dim3(256), 0, st, a); break;    // 128 x 64
@@ -482,6 +535,7 @@ static int g_igemm2_mode = [] { const char* e = getenv("FS_IGEMM2"); return e ? 
 static int g_igemm2_slices = [] { const char* e = getenv("FS_IGEMM2_SLICES"); return e ? atoi(e) : 0; }();   // > 0: force a slice count
 
 template <typename T> static void launch2_group(hipStream_t st, const ConvGroupArgs& g, int cfg, int grid) {
+    if (sizeof(T) == 4 && g_fp32x3 && launch2_group_x3(st, g, cfg, grid)) return;
     switch (cfg) {
         case 0: FS_LAUNCH((conv_igemm2_group_kernel<T, 2, 2, 1, 1, 1, 4>), dim3((unsigned)grid), dim3(256), 0, st, g); break;    // 64 x 64
         case 4: FS_LAUNCH((conv_igemm2_group_kernel<T, 1, 1, 4, 1, 1, 4>), dim3((unsigned)grid), dim3(256), 0, st, g); break;    // 32 x 32, K over 4 waves
@@ -563,7 +617,9 @@ static int g_group_lpt = [] { const char* e = getenv("FS_IGEMM2_GROUP_LPT"); ret
 static double group_block_clocks(const ConvArgs& a, int es, int bm, int bn) {
     const double steps = (a.R * a.S * (a.Cin * es / 16) + 7) / 8 * ((a.flags & FS_CONV_TRANSPOSED) ? 0.25 : 1.0);
     const double fill = (bm + bn) * 128.0 / 35.0;
-    const double mfma = (bm / 32) * (bn / 32) * (es == 4 ? 1024.0 : 128.0) / 4.0;
+    // fp32: 16 fp32 MFMAs of 64 clocks per sub-tile and stage; split form (not in the 32 x 32 tile, whose waves hold one K unit): the
+    // ~5 VALU per operand element bound it at ~2 x 320 clocks
+    const double mfma = (bm / 32) * (bn / 32) * (es == 4 ? ((g_fp32x3 && bm * bn > 1024) ? 640.0 : 1024.0) : 128.0) / 4.0;
     static const double fixed = [] { const char* e = getenv("FS_IGEMM2_GROUP_FIXED"); return e ? atof(e) : 1200.0; }();
     return fixed + steps * (fill > mfma ? fill : mfma);
 }

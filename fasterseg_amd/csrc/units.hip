@@ -179,12 +179,11 @@ fs_status fs::bn_fwd_group(void* stream, const BnFwdCall* c, int n) {
         const BnFwdCall& q = c[i];
         FS_REQUIRE(q.groups >= 1 && q.pixels > 0 && q.pixels % q.groups == 0, FS_ERR_INVALID, "fs_bn_act_train_fwd: %lld pixels in %d groups",
                    q.pixels, q.groups);
-        FS_REQUIRE(!q.stats_ready || q.groups == 1, FS_ERR_INVALID, "bn_fwd_group: epilogue statistics are per launch, not per group");
         if (!grouped) {
             fs_status s;
             if (q.stats_ready)
-                s = fs_bn_train_apply(stream, q.pixels, q.C, q.z, q.z_cs, q.stats, q.gamma, q.beta, q.eps, q.momentum, q.running_mean,
-                                      q.running_var, q.num_batches_tracked, q.saved, q.y, q.y_cs, q.dtype, q.relu);
+                s = fs_bn_train_apply_g(stream, q.pixels, q.C, q.groups, q.z, q.z_cs, q.stats, q.gamma, q.beta, q.eps, q.momentum, q.running_mean,
+                                        q.running_var, q.num_batches_tracked, q.saved, q.y, q.y_cs, q.dtype, q.relu);
             else
                 s = fs_bn_act_train_fwd(stream, q.pixels, q.C, q.groups, q.z, q.z_cs, q.gamma, q.beta, q.eps, q.momentum, q.running_mean,
                                         q.running_var, q.num_batches_tracked, q.stats, q.saved, q.y, q.y_cs, q.dtype, q.relu, q.ws, q.ws_bytes);
@@ -293,10 +292,14 @@ fs_status fs::unit_fwd_group(void* stream, const UnitFwdCall* u, int n) {
         const long long count = (long long)q.d->N * q.d->Ho * q.d->Wo;
         const int groups = q.d->bn_groups > 1 ? q.d->bn_groups : 1;
         FS_REQUIRE(q.d->N % groups == 0, FS_ERR_INVALID, "fs_conv_bn_act_train_fwd: batch %d is not %d equal groups", q.d->N, groups);
+        // (a grouped batch keeps the epilogue statistics when an MFMA sub-tile of 32 rows never straddles two groups: round 6 - the
+        // pair-batched cells' large maps paid a statistics pass AND a second normalisation launch behind it)
         mode[i] = count / groups <= BN_COL_MAX_PIXELS ? 0
-                  : (groups > 1 || (q.ws && fs::g_deterministic) || !stats_in_epilogue(count, q.d->Cout, q.d->dtype)) ? 1 : 2;
+                  : ((groups > 1 && (count / groups) % 32 != 0) || (q.ws && fs::g_deterministic) ||
+                     !stats_in_epilogue(count / groups, q.d->Cout, q.d->dtype)) ? 1 : 2;
         const fs_status s = conv_prepare(&c[i], q.x, q.w, nullptr, nullptr, q.z, mode[i] == 2 ? q.stats : nullptr, &args[i]);
         if (s != FS_OK) return s;
+        if (mode[i] == 2 && groups > 1) args[i].stats_gp = (int)(count / groups);
     }
     fs_status s = conv_launch_group(stream, cp, args, n);
     if (s != FS_OK) return s;

@@ -10,7 +10,7 @@
 //         PIXELS of one channel, i.e. a column of the staged tile: two ds_read_b64_tr_b16 (gfx950's 16-bit transpose read) per
 //         operand - round 3 gathered it with eight ds_read_u16 and was LDS-issue bound.
 #include <type_traits>
-#include "common.h"
+#include "conv_igemm.h"
 
 namespace fs {
 
@@ -29,6 +29,7 @@ struct WgradArgs {
     unsigned int* counters;   // [tile] arrival counters, zero on entry, left zero
     int slabs;
     int grid_y, grid_z;       // tiles_co * tiles_ci, taps (the grouped launch linearises (slab, tile, tap))
+    int x3;                   // fp32: contract on the bf16 matrix cores with three-way split operands (conv_igemm.h split3_bf16)
 };
 
 constexpr int WG_MAX_GROUP = 8;
@@ -173,8 +174,22 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int bx, con
                 } else {
                     const float* pa = reinterpret_cast<const float*>(&sA[kpart * KN + (lane >> 5)][0]) + wm * 32 + (lane & 31);
                     const float* pb = reinterpret_cast<const float*>(&sB[kpart * KN + (lane >> 5)][0]) + wn * 32 + (lane & 31);
+                    if (p.x3) {
+                        // 16 pixels per step: the lane's 8 K slots are pixels k + 2 s (+ 1 in the upper half-wave), the same for both operands
 #pragma unroll
-                    for (int k = 0; k < KN; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[k * PITCH], pb[k * PITCH], acc, 0, 0, 0);
+                        for (int k = 0; k < KN; k += 16) {
+                            float xa[8], xb[8];
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) { xa[q] = pa[(k + 2 * q) * PITCH]; xb[q] = pb[(k + 2 * q) * PITCH]; }
+                            Split3 sa, sb;
+                            split3_bf16(xa, sa.h, sa.m, sa.l);
+                            split3_bf16(xb, sb.h, sb.m, sb.l);
+                            mma_x3(sa, sb, acc);
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < KN; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[k * PITCH], pb[k * PITCH], acc, 0, 0, 0);
+                    }
                 }
             };
             if (ksplit == 1) mfma_part(std::integral_constant<int, 1>{});
@@ -284,6 +299,7 @@ static fs_status wgrad_prepare(const fs_conv_desc* d, const void* x, const void*
     a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.R = d->R; a.S = d->S;
     a.stride = d->stride; a.pad = d->pad; a.Ho = d->Ho; a.Wo = d->Wo;
     a.x_cs = d->x_cs; a.dy_cs = d->y_cs;
+    a.x3 = (d->dtype == FS_F32 && g_fp32x3) ? 1 : 0;
     a.n_seg = d->n_seg > 0 ? d->n_seg : 0;
     a.g_jump = d->n_seg > 0 ? d->g_jump : 0;
     const long long M = (long long)d->N * d->Ho * d->Wo;

@@ -679,12 +679,12 @@ class _PairMerge(torch.autograd.Function):
     both halves of dx with one launch - no slice / zero-pad / add nodes."""
 
     @staticmethod
-    def forward(ctx, coef, x):
+    def forward(ctx, coef, x, dest=None):
         c = coef.detach()
         if c.dtype != torch.float32 or not c.is_contiguous():
             c = c.float().contiguous()
         n = x.shape[0] // 2
-        out = K.weighted_sum([x[:n], x[n:]], c)
+        out = K.weighted_sum([x[:n], x[n:]], c, out=dest[0] if dest else None)
         ctx.coef_leaf = coef.is_leaf
         ctx.save_for_backward(c, x)
         return out
@@ -700,25 +700,137 @@ class _PairMerge(torch.autograd.Function):
             K.weighted_sum_bwd(dy, c, (True, True), outs=[gx[:n], gx[n:]])
         if ctx.needs_input_grad[0]:
             gc = _own(K.weighted_sum_dots(dy, [x[:n], x[n:]]), ctx.coef_leaf)
-        return gc, gx
+        return gc, gx, None
 
 
-def pair_merge(x, coef):
+def pair_merge(x, coef, dest=None):
+    """dest: an NHWC tensor of the result's shape to write into (a PairBuffers half), or None."""
     x = as_nhwc(x)
     assert x.shape[0] % 2 == 0 and coef.numel() == 2
-    return _PairMerge.apply(coef, x)
+    return _PairMerge.apply(coef, x, [dest] if dest is not None else None)
+
+
+class _PairMergeGroup(torch.autograd.Function):
+    """k pair_merge evaluations (the beta mixing of every pair-batched cell output of one supernet layer) as ONE grouped launch forward and
+    one backward (fs_exec_program_group over one-command programs; csrc/group.h wsum_group / wsum_bwd_group)."""
+
+    @staticmethod
+    def forward(ctx, meta, *tensors):
+        from . import program
+        progs, dests = meta
+        k = len(progs)
+        outs, saved, slots = [], [], []
+        for i, prog in enumerate(progs):
+            coef, x = tensors[2 * i], tensors[2 * i + 1]
+            c = coef.detach()
+            if c.dtype != torch.float32 or not c.is_contiguous():
+                c = c.float().contiguous()
+            n2, C, H, W = x.shape
+            out = dests[i] if dests[i] is not None else K.empty_nhwc(n2 // 2, C, H, W, x.dtype, x.device, cs=C)
+            slots.append((None, x.data_ptr(), c.data_ptr(), out.data_ptr(), None, None, None, None, None, None, None, None))
+            outs.append(out)
+            saved += [c, x]
+        program.run_group(progs, False, slots)
+        ctx.progs = progs
+        ctx.coef_leaf = [tensors[2 * i].is_leaf for i in range(k)]
+        ctx.save_for_backward(*saved)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        from . import program
+        progs = ctx.progs
+        saved = ctx.saved_tensors
+        slots, keep, gxs, zbs = [], [], [], []
+        for i, prog in enumerate(progs):
+            c, x = saved[2 * i], saved[2 * i + 1]
+            n2, C, H, W = x.shape
+            dy = dys[i]
+            if not (K.is_nhwc(dy, x.dtype) and K.channel_stride(dy) == C):
+                dy = K.copy_channels(as_nhwc(dy, x.dtype), K.empty_nhwc(n2 // 2, C, H, W, x.dtype, x.device, cs=C))
+            gx = K.empty_nhwc(n2, C, H, W, x.dtype, x.device, cs=C)
+            zb = zero_arena(prog.zb_bytes, x.device)
+            slots.append((None, x.data_ptr(), c.data_ptr(), None, None, dy.data_ptr(), None, gx.data_ptr(), None, None, None,
+                          zb.data_ptr() if zb is not None else None))
+            keep.append(dy)
+            gxs.append(gx)
+            zbs.append(zb)
+        program.run_group(progs, True, slots)
+        grads = [None]
+        for i, prog in enumerate(progs):
+            gc = None
+            if prog.need_coef:
+                gc = _own(zbs[i][:2], ctx.coef_leaf[i])
+            grads += [gc, gxs[i]]
+        return tuple(grads)
+
+
+def pair_merge_group(xs, coefs, dests=None):
+    """[pair_merge(x, coef) for x, coef] in one grouped launch per direction; dests[i]: where result i is written (or None).  Falls back to
+    the single launches when an input is not a dense NHWC map."""
+    from . import program
+    xs = [as_nhwc(x) for x in xs]
+    dests = list(dests) if dests is not None else [None] * len(xs)
+    if len(xs) < 2 or len(xs) > program.MAX_GROUP or any(K.channel_stride(x) != x.shape[1] for x in xs) or not xs[0].is_cuda:
+        return [pair_merge(x, c, d) for x, c, d in zip(xs, coefs, dests)]
+    progs = [program.pair_merge_program(tuple(x.shape), x.dtype, bool(c.requires_grad) and torch.is_grad_enabled()) for x, c in zip(xs, coefs)]
+    flat = []
+    for x, c in zip(xs, coefs):
+        flat += [c, x]
+    return list(_PairMergeGroup.apply((tuple(progs), dests), *flat))
+
+
+class PairBuffers:
+    """Destination planning for batch_pair (round 6).  Every cell output of a supernet layer has exactly ONE consumer cell in the next
+    layer (reference search/model_search.py:310-333: `keep` feeds the same scale, `down` the next one), and a consumer fed from both
+    scales evaluates its MixedOps once on the two inputs concatenated along the batch (batch_pair).  Round 5 copied both inputs into
+    the joint buffer (two launches per pair, 216 per C3 step); now the joint buffer is allocated when its first half is PRODUCED and
+    the producers (the layer call's weighted sums, the beta merges) write straight into their half: `half(key, which, like)` hands out
+    the slice, `joint(a, b)` recognises two halves of one buffer and returns it without a launch."""
+
+    def __init__(self):
+        self.bufs = {}
+
+    def half(self, key, which, shape, dtype, device):
+        """The `which`-th (0 / 1) half of the joint NHWC buffer `key` for halves of `shape` (n, C, H, W), or None when the other half was
+        planned with another shape (the consumer then copies, as before)."""
+        n, c, h, w = shape
+        buf = self.bufs.get(key)
+        if buf is None:
+            buf = self.bufs[key] = K.empty_nhwc(2 * n, c, h, w, dtype, device, cs=c)
+        if tuple(buf.shape) != (2 * n, c, h, w) or buf.dtype != dtype:
+            return None
+        return buf[:n] if which == 0 else buf[n:]
+
+    def joint(self, a, b):
+        n = a.shape[0]
+        for buf in self.bufs.values():
+            if buf.data_ptr() == a.data_ptr() and buf.shape[0] == 2 * n and buf[n:].data_ptr() == b.data_ptr() and a.shape == b.shape \
+                    and a.stride() == buf.stride() and b.stride() == buf.stride():
+                return buf
+        return None
+
+
+_pair_buffers = None          # the PairBuffers of the forward pass in progress (model_search.Network_Multi_Path.forward)
+# [parameters the launch programs of the forward in progress will write in backward, one entry per (program, parameter)] while a caller
+# wants them (train_step: comm / compute overlap of the last pass, parallel.FlatGradientSync.final_pass); [None] marks the log unusable
+_touch_log = None
 
 
 class _BatchPair(torch.autograd.Function):
-    """torch.cat([a, b], dim=0) of two NHWC maps of one shape (one copy launch each); backward = the two halves of dy."""
+    """torch.cat([a, b], dim=0) of two NHWC maps of one shape (one copy launch each - none when the producers already wrote the two
+    halves of one PairBuffers buffer); backward = the two halves of dy."""
 
     @staticmethod
     def forward(ctx, a, b):
         n, c, h, w = a.shape
+        ctx.n = n
+        joint = _pair_buffers.joint(a, b) if _pair_buffers is not None else None
+        if joint is not None:
+            return joint
         out = K.empty_nhwc(2 * n, c, h, w, a.dtype, a.device)
         K.copy_channels(a, out[:n])
         K.copy_channels(b, out[n:])
-        ctx.n = n
         return out
 
     @staticmethod
@@ -781,6 +893,8 @@ class _MixedOpProgram(torch.autograd.Function):
         prog.run(prog.f_words, prog.f_n, prog.f_blob,
                  (None, x.data_ptr(), c.data_ptr(), out.data_ptr(), save.data_ptr(), None, None, None, tmp.data_ptr(),
                   K.stream_workspace(dev)[0], zf.data_ptr() if zf is not None else None, None))
+        if _touch_log is not None:
+            _touch_log.extend(prog.touched)
         ctx.prog = prog
         ctx.coef_leaf = coef.is_leaf
         ctx.save_for_backward(x, c, save)
@@ -823,8 +937,9 @@ class _MixedOpProgramGroup(torch.autograd.Function):
     position of the k programs are one grouped launch each.  One autograd node for the k outputs, so backward is grouped as well."""
 
     @staticmethod
-    def forward(ctx, progs, *tensors):
+    def forward(ctx, meta, *tensors):
         from . import program
+        progs, dests = meta          # dests[i]: a dense NHWC tensor of program i's output shape to write into (a PairBuffers half), or None
         k = len(progs)
         assert len(tensors) == 2 * k
         outs, saved, slots, scratch = [], [], [], []
@@ -837,7 +952,11 @@ class _MixedOpProgramGroup(torch.autograd.Function):
             save = torch.empty(prog.save_bytes, dtype=torch.uint8, device=dev)
             tmp = torch.empty(prog.tmpf_bytes, dtype=torch.uint8, device=dev)
             N, C, H, W = prog.out_shape
-            out = torch.empty_strided((N, C, H, W), (H * W * C, 1, W * C, C), dtype=x.dtype, device=dev)
+            out = dests[i] if dests is not None and dests[i] is not None else None
+            if out is None:
+                out = torch.empty_strided((N, C, H, W), (H * W * C, 1, W * C, C), dtype=x.dtype, device=dev)
+            else:
+                assert tuple(out.shape) == (N, C, H, W) and out.stride() == (H * W * C, 1, W * C, C) and out.dtype == x.dtype
             zf = zero_arena(prog.zf_bytes, dev)
             slots.append((None, x.data_ptr(), c.data_ptr(), out.data_ptr(), save.data_ptr(), None, None, None, tmp.data_ptr(),
                           K.stream_workspace(dev)[0], zf.data_ptr() if zf is not None else None, None))
@@ -846,6 +965,9 @@ class _MixedOpProgramGroup(torch.autograd.Function):
             scratch.append((tmp, zf))             # forward scratch: alive until the launches are enqueued (stream-ordered reuse after)
         program.run_group(progs, False, slots)
         del scratch
+        if _touch_log is not None:
+            for prog in progs:
+                _touch_log.extend(prog.touched)
         ctx.progs = progs
         ctx.coef_leaf = [tensors[2 * i + 1].is_leaf for i in range(k)]
         ctx.save_for_backward(*saved)
@@ -889,12 +1011,13 @@ class _MixedOpProgramGroup(torch.autograd.Function):
         return tuple(grads)
 
 
-def mixed_op_program_group(xs, coefs, progs):
-    """Outputs of k MixedOp programs of equal `signature` executed in lockstep (1 <= k <= program.MAX_GROUP)."""
+def mixed_op_program_group(xs, coefs, progs, dests=None):
+    """Outputs of k MixedOp programs executed together by fs_exec_program_group (1 <= k <= program.MAX_GROUP); dests[i]: where output i
+    is written (a dense NHWC tensor of its shape, e.g. a PairBuffers half), or None."""
     flat = []
     for x, c in zip(xs, coefs):
         flat += [x, c]
-    return _MixedOpProgramGroup.apply(tuple(progs), *flat)
+    return _MixedOpProgramGroup.apply((tuple(progs), list(dests) if dests is not None else None), *flat)
 
 
 def weighted_sum(xs, coef):

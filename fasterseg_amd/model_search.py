@@ -144,6 +144,10 @@ def layer_lanes(stream):
 # of the reference's two evaluations (model_search.py:322-329) at half the launches - the supernet step is launch-bound.
 # FS_PAIR_BATCH=0 evaluates the two inputs one after the other.
 _PAIR_BATCH = bool(int(os.environ.get("FS_PAIR_BATCH", "1")))
+# Round 6: the producers of a pair's two inputs write straight into the halves of the joint buffer (FS_PAIR_DIRECT=0: two copy launches
+# per pair, as in round 5), and the beta merges of a layer's pair-batched cells are one grouped launch (FS_MERGE_GROUP=0: one each).
+_PAIR_DIRECT = bool(int(os.environ.get("FS_PAIR_DIRECT", "1")))
+_MERGE_GROUP = bool(int(os.environ.get("FS_MERGE_GROUP", "1")))
 
 
 def _eval(op, x, alpha, ratios, groups):
@@ -195,8 +199,9 @@ FAST_PHASE_ACTIVE = False
 _RECORD_STREAM = bool(int(os.environ.get("FS_RECORD_STREAM", "1")))
 
 
-def _run_tasks(tasks):
-    """tasks: [(mixed_op, x, alpha, ratios, bn_groups)] -> outputs.  While capturing, every primitive of every task runs on its own
+def _run_tasks(tasks, dest_fn=None):
+    """tasks: [(mixed_op, x, alpha, ratios, bn_groups)] -> outputs.  dest_fn(task index, out shape, dtype, device): a tensor the task's
+    output should be written into (a functional.PairBuffers half), or None - honoured by the grouped launch programs only.  While capturing, every primitive of every task runs on its own
     stream; the alpha-weighted sums follow on the capturing stream after the join.  Eager training passes put whole MixedOp
     programs on side streams."""
     on_gpu = len(tasks) > 1 and tasks[0][1].is_cuda
@@ -246,11 +251,14 @@ def _run_tasks(tasks):
                         and any(p.requires_grad for p in op._ops[3].parameters())), \
                 "a MixedOp fell back to the per-module path while only the probe weights carry the phase (FS_FAST_PHASE=0 to disable)"
             op.set_prun_ratio((widths[0], widths[1]))
+            if FN._touch_log is not None and op.training and torch.is_grad_enabled():
+                FN._touch_log.append(None)          # a MixedOp off the launch programs: its gradient writes are not in the log
         group = _GROUP_PROGRAMS and (not capturing or _GROUP_CAPTURE)
         if MIMIC_CAPTURE and not capturing and not _SAMPLING_PASS:
             group = group and bool(_GROUP_CAPTURE)
         if prog is not None and group:
-            grouped.append((len(pending), FN.as_nhwc(x), coef, prog))
+            dest = dest_fn(len(pending), prog.out_shape, x.dtype, x.device) if dest_fn is not None else None
+            grouped.append((len(pending), FN.as_nhwc(x), coef, prog, dest))
             pending.append(None)
             continue
         if prog is not None:          # the whole MixedOp (five primitives, their sum, and in backward the sum of the five input
@@ -287,20 +295,20 @@ def _run_tasks(tasks):
                 chunk = items[lo:lo + per]
                 if capturing and _GROUP_CAPTURE == 2:
                     with torch.cuda.stream(lane_for(0)):
-                        outs = FN.mixed_op_program_group([c[1] for c in chunk], [c[2] for c in chunk], [c[3] for c in chunk])
+                        outs = FN.mixed_op_program_group([c[1] for c in chunk], [c[2] for c in chunk], [c[3] for c in chunk], [c[4] for c in chunk])
                 elif capturing and _GROUP_CAPTURE >= 3:      # (crashes hipStreamEndCapture: kept for the reproduction only)
                     with torch.cuda.stream(lane_for(slot % (_GROUP_CAPTURE - 1))):
-                        outs = FN.mixed_op_program_group([c[1] for c in chunk], [c[2] for c in chunk], [c[3] for c in chunk])
+                        outs = FN.mixed_op_program_group([c[1] for c in chunk], [c[2] for c in chunk], [c[3] for c in chunk], [c[4] for c in chunk])
                     slot += 1
                 elif capturing or _LAYER_SPLIT == 1:        # on the current stream itself
-                    outs = FN.mixed_op_program_group([c[1] for c in chunk], [c[2] for c in chunk], [c[3] for c in chunk])
+                    outs = FN.mixed_op_program_group([c[1] for c in chunk], [c[2] for c in chunk], [c[3] for c in chunk], [c[4] for c in chunk])
                 else:
                     lane = lane_for(slot)                   # FS_LAYER_SPLIT calls side by side on the lanes
                     for c in chunk:
                         hand_over(c[1], lane)
                         hand_over(c[2], lane)
                     with torch.cuda.stream(lane):
-                        outs = FN.mixed_op_program_group([c[1] for c in chunk], [c[2] for c in chunk], [c[3] for c in chunk])
+                        outs = FN.mixed_op_program_group([c[1] for c in chunk], [c[2] for c in chunk], [c[3] for c in chunk], [c[4] for c in chunk])
                     crossing.extend((o, lane) for o in outs)
                     slot += 1
                 for c, o in zip(chunk, outs):
@@ -810,6 +818,25 @@ class Network_Multi_Path(nn.Module):
 
         out_prev = [[stem(input), None]]  # stem: one cell
         probe = [[_SAMPLED] * len(r) for r in ratios]          # which entries of a cell's (in, out, down) widths are sampled
+        # Every cell output has ONE consumer cell in the next layer; a consumer fed from two scales evaluates once on both inputs
+        # concatenated along the batch.  The joint buffers are planned one layer ahead so that the producers write into their halves
+        # (functional.PairBuffers: no copy launches), and the beta merges of a layer go out as one grouped launch.
+        pair_plan = FN.PairBuffers() if (_PAIR_BATCH and _PAIR_DIRECT and self.training and input.is_cuda and torch.is_grad_enabled()) else None
+        FN._pair_buffers = pair_plan
+        n_layers = len(self.cells)
+
+        def will_pair(i2, j2):
+            if pair_plan is None or i2 >= n_layers or j2 >= len(self.cells[i2]) or j2 == 0 or i2 == j2:
+                return False
+            bp = beta_pos[j2][i2 - j2 - 1]
+            return bool(bp[0] and bp[1])
+
+        def dest_of(i, j, which, shape, dtype, device):
+            """Where output `which` (0 keep, 1 down) of cell j of layer i should be written: its half of the consumer's joint buffer."""
+            jn = j + which
+            if not will_pair(i + 1, jn):
+                return None
+            return pair_plan.half((i + 1, jn), 1 - which, tuple(shape), dtype, device)
         # i: layer | j: scale
         for i, cells in enumerate(self.cells):
             # every MixedOp evaluation of this layer (reference :303-333: cell(out_prev[..], alpha, ratio) = its `_op` and,
@@ -844,21 +871,46 @@ class Network_Multi_Path(nn.Module):
                     if cell._down:
                         tasks.append((cell.downsample, x, a_down, (ratio[0], ratio[2]), groups))
                         slots.append((j, tag, 1))
-            res = dict(zip(slots, _run_tasks(tasks)))
-            out = []
+            def task_dest(t, shape, dtype, device, i=i, slots=slots):
+                j, tag, which = slots[t]
+                if tag == 2:                    # a pair-batched evaluation: its beta merge (below) is what the next layer consumes
+                    return None
+                if not (j == 0 or i == j):      # one of two separately evaluated sources: their weighted sum is the output
+                    return None
+                return dest_of(i, j, which, shape, dtype, device)
+            res = dict(zip(slots, _run_tasks(tasks, task_dest if pair_plan is not None else None)))
+            out = [None] * len(cells)
+            merges = []                         # (j, which, x, beta row): the pair-batched cells' beta merges, one grouped launch
             for j, cell in enumerate(cells):
                 if j == 0:
-                    out.append((res[(0, 1, 0)], res.get((0, 1, 1))))
+                    out[j] = (res[(0, 1, 0)], res.get((0, 1, 1)))
                 elif i == j:
-                    out.append((res[(j, 0, 0)], res.get((j, 0, 1))))
+                    out[j] = (res[(j, 0, 0)], res.get((j, 0, 1)))
                 else:
                     b = beta_rows[j][i - j - 1]
                     if (j, 2, 0) in res:
-                        out.append((FN.pair_merge(res[(j, 2, 0)], b), FN.pair_merge(res[(j, 2, 1)], b) if (j, 2, 1) in res else 0))
+                        out[j] = [None, 0]
+                        merges.append((j, 0, res[(j, 2, 0)], b))
+                        if (j, 2, 1) in res:
+                            merges.append((j, 1, res[(j, 2, 1)], b))
                     else:
-                        out.append((_weighted_sum(b, [res.get((j, 0, 0)), res.get((j, 1, 0))]),
-                                    _weighted_sum(b, [res.get((j, 0, 1)), res.get((j, 1, 1))])))
+                        out[j] = (_weighted_sum(b, [res.get((j, 0, 0)), res.get((j, 1, 0))]),
+                                  _weighted_sum(b, [res.get((j, 0, 1)), res.get((j, 1, 1))]))
+            if merges:
+                dests = None
+                if pair_plan is not None:
+                    dests = []
+                    for j, which, x, b in merges:
+                        n2, C, H, W = x.shape
+                        dests.append(dest_of(i, j, which, (n2 // 2, C, H, W), x.dtype, x.device))
+                if _MERGE_GROUP and len(merges) > 1:
+                    merged = FN.pair_merge_group([m[2] for m in merges], [m[3] for m in merges], dests)
+                else:
+                    merged = [FN.pair_merge(m[2], m[3], dests[k] if dests else None) for k, m in enumerate(merges)]
+                for (j, which, x, b), y in zip(merges, merged):
+                    out[j][which] = y
             out_prev = out
+        FN._pair_buffers = None
         ###################################
         up2 = lambda t: FN.interpolate(t, scale_factor=2)
         out0 = out[0][0]

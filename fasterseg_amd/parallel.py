@@ -51,6 +51,9 @@ class FlatGradientSync:
         self.handles = {}
         self.stage = torch.empty_like(self.flat, dtype=self.comm_dtype) if (self.comm_dtype is not None and self.world > 1) else None
         self._touched = [False] * len(self.params)
+        self._final = None           # final_pass(): writes still expected per bucket in the LAST backward of a multi-pass step
+        self._final_seen = None
+        self.early_launches = 0      # buckets whose all-reduce went out before sync() in the current step (tests, bench)
         self._hidden = None          # indices whose .grad sync() set to None (None: unknown, re-point everything)
         self._index = {id(p): i for i, p in enumerate(self.params)}
         self._hooks = []
@@ -79,6 +82,14 @@ class FlatGradientSync:
                 if (self.passes == 1 and self.pending[b] == self.count[b]
                         and not (self.flat.is_cuda and torch.cuda.is_current_stream_capturing())):
                     self._launch(b)
+                    self.early_launches += 1
+            if self._final is not None:          # the last backward of a multi-pass step (final_pass): one more expected write has happened
+                b = self.bucket_id[i]
+                self._final_seen[b] += 1
+                if (self._final_seen[b] == self._final[b] and b not in self.handles
+                        and not (self.flat.is_cuda and torch.cuda.is_current_stream_capturing())):
+                    self._launch(b)
+                    self.early_launches += 1
         return hook
 
     def _launch(self, b):
@@ -112,6 +123,8 @@ class FlatGradientSync:
         self.handles = {}
         self.pending = [0] * len(self.buckets)
         self._touched = [False] * len(self.params)
+        self._final = self._final_seen = None
+        self.early_launches = 0
         # point every .grad at its slice: only the parameters sync() hid last time need touching - the supernet has ~40 k parameters and
         # the step is host-bound (a full loop is ~1 ms of pure Python per step, twice).  Anything ELSE that drops or re-homes a .grad
         # between steps (model.zero_grad(), whose default is set_to_none=True; user code) must call invalidate(); as a net under callers
@@ -134,6 +147,34 @@ class FlatGradientSync:
                 params[i].grad = views[i]
         self._hidden = []
 
+    def final_pass(self, touches=None, others=None):
+        """Comm / compute overlap for steps that accumulate SEVERAL backward passes (the supernet's `_loss` is four, reference
+        search/train_search.py:246-250): call after the forward of the LAST pass, before its backward.  `touches`: every gradient write
+        that backward will make through the fused accumulation protocol, one entry per (launch program, parameter) - a weight shared by
+        two evaluations appears twice; `others`: parameters autograd accumulates itself (each fires its hook once).  None / None: every
+        parameter once (plain autograd models).  From here on a bucket's all-reduce is launched as soon as the last write this backward
+        makes to it has been ENQUEUED (torch.distributed orders the collective behind the compute stream's work issued so far), i.e.
+        it runs under the rest of the backward; buckets the last pass does not touch at all go out immediately.  Over-estimating the
+        writes only delays a bucket to sync(); the caller must not under-estimate (then skip this call: sync() sends everything).
+        Replayed (hipGraph) final passes cannot use it - their Python hooks do not run (mark_touched re-declares them after the replay)."""
+        if self.passes <= 1:
+            return
+        expected = [0] * len(self.buckets)
+        if touches is None and others is None:
+            for i in range(len(self.params)):
+                expected[self.bucket_id[i]] += 1
+        else:
+            for p in list(touches or ()) + list(others or ()):
+                i = self._index.get(id(p))
+                if i is not None:
+                    expected[self.bucket_id[i]] += 1
+        self._final, self._final_seen = expected, [0] * len(self.buckets)
+        if not (self.flat.is_cuda and torch.cuda.is_current_stream_capturing()):
+            for b, e in enumerate(expected):
+                if e == 0:
+                    self._launch(b)
+                    self.early_launches += 1
+
     def invalidate(self):
         """Some .grad was dropped or replaced behind this object's back (zero_grad(set_to_none=True), manual p.grad = None): the next
         prepare() re-points EVERY parameter at its slice of the flat buffer."""
@@ -147,6 +188,7 @@ class FlatGradientSync:
         if FN._grad_sink is self:
             FN._grad_sink = None
         K.zero_pool.stop()
+        self._final = self._final_seen = None
         for b in range(len(self.buckets)):
             self._launch(b)
         for h in self.handles.values():

@@ -612,3 +612,39 @@ def lower_mixed_op(mixed, x_shape, x_cs, dtype, device, need_x, need_coef, want_
     prog = MixedOpProgram(lo.f, lo.b, (y0.N, y0.C, y0.H, y0.W), touched, need_x, need_coef, gcoef_off, lo.guard)
     prog.fused = fused is not None
     return prog
+
+
+# ---------------------------------------------------------------------------------------------------
+# one-command programs for the grouped beta merges of a supernet layer (functional.pair_merge_group)
+# ---------------------------------------------------------------------------------------------------
+class _MiniProgram:
+    def __init__(self, fwd, bwd, need_coef):
+        self.f_words, self.f_n, self.f_blob, _ = fwd.finish()
+        self.b_words, self.b_n, self.b_blob, b_sizes = bwd.finish()
+        self.zb_bytes = b_sizes.get(ZB, 0)
+        self.need_coef = need_coef
+
+
+_pair_merge_programs = {}
+
+
+def pair_merge_program(x_shape, dtype, need_coef):
+    """out = coef[0] * x[:n] + coef[1] * x[n:] for a dense NHWC x of shape (2n, C, H, W) (slots X, COEF, OUT) and its backward (DY, GX; the
+    two coefficient gradients land in the first two floats of the ZB slice).  Cached per (shape, dtype, need_coef)."""
+    key = (tuple(x_shape), dtype, bool(need_coef))
+    prog = _pair_merge_programs.get(key)
+    if prog is None:
+        n2, C, H, W = x_shape
+        assert n2 % 2 == 0
+        esize = 4 if dtype == torch.float32 else 2
+        dt = K.dtype_code(dtype)
+        pixels = (n2 // 2) * H * W
+        half = pixels * C * esize
+        f, b = _List(ZF), _List(ZB)
+        f.emit(OP_WSUM, pixels, C, 2, [Ref(X, 0), Ref(X, half)], [C, C], Ref(COEF, 0), Ref(OUT, 0), C, dt)
+        if need_coef:
+            gc = b.alloc(TMPB, 4 * 8, zero=True)
+            b.emit(OP_WSUM_DOTS, pixels, C, 2, Ref(DY, 0), C, [Ref(X, 0), Ref(X, half)], [C, C], dt, gc)
+        b.emit(OP_WSUM_BWD, pixels, C, 2, Ref(DY, 0), C, Ref(COEF, 0), [Ref(GX, 0), Ref(GX, half)], [C, C], dt)
+        prog = _pair_merge_programs[key] = _MiniProgram(f, b, bool(need_coef))
+    return prog

@@ -98,6 +98,9 @@ class StudentDistillStep:
 
 import os as _os
 _FAST_PHASE = bool(int(_os.environ.get("FS_FAST_PHASE", "1")))      # 0: flip requires_grad of all ~40 k weights at every phase change
+# gradient all-reduce of the supernet step under the backward of its last (eager) pass: 1 with more than one rank (default), 2 also the
+# bookkeeping on a single rank (tests), 0 every bucket in sync()
+_DP_OVERLAP = int(_os.environ.get("FS_DP_OVERLAP", "1"))
 
 
 class SearchConfig:
@@ -172,6 +175,7 @@ class SupernetStep:
         self.gc_freeze = bool(int(os.environ.get("FS_GC_FREEZE", "1"))) if gc_freeze is None else bool(gc_freeze)
         self.last_arch_ce = None
         self._phase_weights = None
+        self._other_params = None          # weights outside the cells (stem, refinement, heads): autograd accumulates their gradients
         self.architect = None
         if not pretrain:
             if lut is not None:
@@ -322,7 +326,8 @@ class SupernetStep:
         s_imgs.copy_(imgs)
         s_target.copy_(target)
         total = 0
-        for spec in self._specs():
+        specs = self._specs()
+        for spec in specs:
             if self._is_static(spec):
                 g, loss, touched = self.graphs[(phase, spec)]
                 self._select(spec)
@@ -330,7 +335,23 @@ class SupernetStep:
                 if touched is not None:
                     self.sync.mark_touched(touched)
             else:
-                loss = self._run_pass(spec, imgs, target)
+                # the LAST pass of the weight phase, issued eagerly, with more than one rank: its gradient buckets are all-reduced under
+                # its own backward (FlatGradientSync.final_pass) - the launch programs of its forward say which writes
+                # to expect, everything autograd accumulates itself (stem, refinement, heads) is expected once
+                overlap = (phase == "w" and spec == specs[-1] and _DP_OVERLAP and (self.sync.world > 1 or _DP_OVERLAP > 1))
+                from . import functional as FN
+                if overlap:
+                    FN._touch_log = []
+                try:
+                    loss = self._run_pass(spec, imgs, target)
+                    log = FN._touch_log
+                finally:
+                    FN._touch_log = None
+                if overlap and log is not None and all(p is not None for p in log):
+                    if self._other_params is None:
+                        cells = {id(p) for p in self.model.cells.parameters()}
+                        self._other_params = [p for p in self.weights if id(p) not in cells]
+                    self.sync.final_pass(log, [p for p in self._other_params if p.requires_grad])
                 loss.backward()
                 loss = loss.detach()
             total = total + loss

@@ -97,6 +97,13 @@ int fs_version(void);
  * partial sums travel through HBM), 25-30 % of a supernet step. */
 void fs_set_deterministic(int on);
 int fs_get_deterministic(void);
+/* fp32 convolutions and weight gradients on the bf16 matrix cores (ABI 209; default on, FS_FP32_X3=0 in the environment turns it off at
+ * load): gfx950 runs the fp32 MFMA at 1/16 of the bf16 rate, so every fp32 operand is split exactly into three bf16 pieces (8 + 8 + 8
+ * significant bits) and a product is accumulated in fp32 from the eight partial products down to 2^-24 relative - the result differs from
+ * the fp32 MFMA's only in the order of the accumulation roundings, at half the matrix-core clocks.  Applies to fs_conv2d_fwd* (the
+ * LDS-DMA kernel's tiles of 64 rows or channels and more) and fs_conv2d_wgrad*; everything else of the fp32 path is unchanged. */
+void fs_set_fp32_split(int on);
+int fs_get_fp32_split(void);
 int fs_struct_size(int which);   /* 0 fs_conv_desc, 1 fs_resize_desc, 2 fs_zoom_desc, 3 fs_sgd_tensor, 4 fs_logits_desc; -1 otherwise */
 /* test hook: force the tile configuration of fs_conv2d_fwd (0..7; -1 = heuristic).  Not for production use. */
 void fs_debug_force_conv_cfg(int cfg);

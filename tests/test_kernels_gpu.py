@@ -1,7 +1,8 @@
 """Kernel-level parity on a real MI355X: every C-ABI entry point against a plain PyTorch fp32 CPU reference of the
 same op (F.conv2d / F.batch_norm / F.interpolate(align_corners=True) and their autograd), fp32 and bf16.
 
-Tolerances: fp32 kernels use exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), so only summation order differs from the CPU:
+Tolerances: fp32 kernels use exact-fp32 arithmetic - the fp32 MFMA (v_mfma_f32_32x32x2_f32) or, round 6, eight bf16 MFMAs on three-way
+split operands (fs_set_fp32_split; partial products down to 2^-24 relative) - so only summation order differs from the CPU:
 |err| <= 1e-4 + 1e-4*|ref| (north_star asks 1e-3 on logits).  bf16 kernels are checked against the fp32 reference
 evaluated on bf16-rounded operands with |err| <= 2e-2*max|ref| (storage rounding of the output, 2^-8 relative)."""
 import pytest
@@ -231,6 +232,48 @@ def test_conv2d_dgrad_and_wgrad(case, dtype):
         float((got - ref).abs().max()), float(ref.abs().max()))
     if Cp != Cout:
         assert float(gw[Cout:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("cfg", [-1, 100, 101, 103, 105, 106], ids=lambda c: "cfg%d" % c)
+@pytest.mark.parametrize("case", [(2, 96, 16, 32, 96, 3, 1, 1), (1, 48, 24, 40, 80, 3, 2, 1), (3, 384, 4, 8, 384, 3, 1, 1), (2, 64, 8, 12, 32, 1, 1, 0)],
+                         ids=str)
+def test_fp32_on_bf16_matrix_cores_matches_the_fp32_mfma(case, cfg):
+    """Round 6 (fs_set_fp32_split): the fp32 convolution and weight gradient contracted with 8 bf16 MFMAs on three-way split operands
+    against the same kernels on the fp32 MFMA, and both against an fp64 reference: the split form must be as close to fp64 as the native
+    one (same order of magnitude of error: only l.l terms of 2^-32 are dropped), for every tile configuration that has a split form."""
+    from fasterseg_amd import _lib
+    k = K()
+    lib = _lib.lib()
+    N, Cin, H, W, Cout, ks, stride, pad = case
+    x = rnd(N, Cin, H, W, seed=1)
+    w = rnd(Cout, Cin, ks, ks, seed=2, scale=(2.0 / (Cin * ks * ks)) ** 0.5)
+    ref = F.conv2d(x.double(), w.double(), None, stride, pad)
+    dy = rnd(*ref.shape, seed=3)
+    wd = w.double().requires_grad_(True)
+    F.conv2d(x.double(), wd, None, stride, pad).backward(dy.double())
+    xd = k.to_nhwc(x.cuda(), torch.float32)
+    dyd = k.to_nhwc(dy.cuda(), torch.float32)
+    wp = k.pack_weight(w.cuda(), torch.float32)
+    out = {}
+    try:
+        lib.fs_debug_force_conv_cfg(cfg)
+        for split in (0, 1):
+            lib.fs_set_fp32_split(split)
+            assert lib.fs_get_fp32_split() == split
+            y = k.conv2d(xd, wp, Cout, ks, ks, stride, pad, out_hw=tuple(ref.shape[2:]))
+            dw = k.conv2d_wgrad(xd, dyd, ks, ks, stride, pad)
+            gw = torch.zeros(Cout, Cin, ks, ks, device="cuda")
+            k.unpack_weight_grad(dw, gw, Cout, Cin)
+            out[split] = (k.to_nchw(y).double().cpu(), gw.double().cpu())
+    finally:
+        lib.fs_debug_force_conv_cfg(-1)
+        lib.fs_set_fp32_split(1)
+    for which, want in ((0, ref), (1, wd.grad)):
+        scale = float(want.abs().max())
+        e_native = float((out[0][which] - want).abs().max()) / scale
+        e_split = float((out[1][which] - want).abs().max()) / scale
+        assert e_native < 5e-6 and e_split < 5e-6, (which, e_native, e_split)
+        assert e_split <= 4 * e_native + 2e-7, (which, e_native, e_split)          # the split form is as exact as the fp32 MFMA
 
 
 S2_DGRAD_CASES = [

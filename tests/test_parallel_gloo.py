@@ -115,6 +115,68 @@ def test_flat_gradient_sync_two_backward_passes_world2(tmp_path):
             assert torch.allclose(got[k], p.grad, atol=1e-6), (k, float((got[k] - p.grad).abs().max()))
 
 
+def _worker_final_pass(rank, world, port, out):
+    """Two accumulating backward passes with FlatGradientSync.final_pass() before the last one: the buckets go out UNDER the last
+    backward, in the order its gradient writes complete them, and the result is the serial one."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from fasterseg_amd.parallel import FlatGradientSync, broadcast_parameters
+    torch.manual_seed(100 + rank)
+    model = Toy()
+    broadcast_parameters(model)
+    sync = FlatGradientSync(model.parameters(), bucket_mb=0.00002)      # ~5 floats: {unused.*}, {b.*}, {a.bias}, {a.weight}
+    assert len(sync.buckets) >= 3
+    events = []                                         # ("hook", parameter index) / ("launch", bucket) in program order
+    launch = sync._launch
+
+    def logged_launch(b):
+        if b not in sync.handles:
+            events.append(("launch", b))
+        launch(b)
+    sync._launch = logged_launch
+    for i, p in enumerate(sync.params):
+        p.register_post_accumulate_grad_hook(lambda param, i=i: events.append(("hook", i)))
+    g = torch.Generator().manual_seed(7)
+    X, Y = torch.randn(8, 6, generator=g), torch.randn(8, 3, generator=g)
+    xs, ys = X[rank::world], Y[rank::world]
+    sync.prepare(passes=2)
+    ((model(xs) - ys) ** 2).mean().backward()
+    assert not sync.handles, "a bucket was all-reduced before the last backward pass"
+    loss = (3.0 * (model(xs * 0.5) - ys) ** 2).mean()
+    del events[:]
+    used = [p for n, p in model.named_parameters() if not n.startswith("unused")]
+    sync.final_pass(others=used)                        # the buckets of `unused` expect no write: they go out right here
+    n_before = len(sync.handles)
+    loss.backward()
+    n_after = len(sync.handles)
+    last_hook = max(k for k, e in enumerate(events) if e[0] == "hook")
+    first_launch_in_bwd = min((k for k, e in enumerate(events) if e[0] == "launch" and k > 0), default=None)
+    early = sync.early_launches
+    sync.sync()
+    if rank == 0:
+        torch.save({"grads": {k: (None if p.grad is None else p.grad.clone()) for k, p in model.named_parameters()},
+                    "n_before": n_before, "n_after": n_after, "n_buckets": len(sync.buckets), "early": early,
+                    "launch_before_last_write": first_launch_in_bwd is not None and first_launch_in_bwd < last_hook}, out)
+    dist.destroy_process_group()
+
+
+def test_final_pass_overlaps_the_all_reduce_with_the_last_backward_world2(tmp_path):
+    """comm / compute overlap for multi-pass steps - bucket launches happen before the last backward has made its
+    final gradient write, every bucket is out when it returns, and the gradients equal the serial two-pass reference."""
+    out = str(tmp_path / "g.pt")
+    mp.spawn(_worker_final_pass, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    assert got["n_before"] >= 1                          # the untouched parameters' bucket(s) left at final_pass()
+    assert got["launch_before_last_write"]              # ... and a touched bucket left while the backward was still writing others
+    assert got["n_after"] == got["n_buckets"] == got["early"]          # nothing was left for sync()
+    for k, p in _two_pass_reference().named_parameters():
+        g = got["grads"][k]
+        if k.startswith("unused"):
+            assert g is None
+        else:
+            assert torch.allclose(g, p.grad, atol=1e-6), (k, float((g - p.grad).abs().max()))
+
+
 def test_flat_gradient_sync_bf16_buckets_world2(tmp_path):
     """comm_dtype=bf16: the all-reduced gradient equals the fp32 one up to bf16 rounding of each rank's contribution."""
     out = str(tmp_path / "g16.pt")

@@ -315,6 +315,26 @@ def test_supernet_pair_batching_equals_sequential_evaluation():
         assert rel < 2e-2, (k, rel)
 
 
+@pytest.mark.parametrize("use_graphs", [False, True], ids=["eager", "graphed"])
+def test_direct_pair_buffers_and_grouped_merges_equal_the_copying_path(use_graphs):
+    """Round 6: the producers of a doubly-fed cell's two inputs write into the halves of the joint buffer (no copy launches) and a layer's
+    beta merges are one grouped launch - against round 5's two copies per pair and one merge launch per output, eager and captured."""
+    from fasterseg_amd import model_search
+    saved = (model_search._PAIR_DIRECT, model_search._MERGE_GROUP)
+    try:
+        model_search._PAIR_DIRECT = model_search._MERGE_GROUP = False
+        ref_losses, ref_w = _run(use_graphs)
+        model_search._PAIR_DIRECT = model_search._MERGE_GROUP = True
+        new_losses, new_w = _run(use_graphs)
+    finally:
+        model_search._PAIR_DIRECT, model_search._MERGE_GROUP = saved
+    for a, b in zip(ref_losses, new_losses):
+        assert abs(a - b) <= 5e-3 * abs(a), (ref_losses, new_losses)
+    for k in ref_w:
+        rel = float((ref_w[k] - new_w[k]).norm() / (ref_w[k].norm() + 1e-12))
+        assert rel < 2e-2, (k, rel)
+
+
 def test_prewarmed_programs_cover_every_random_width_draw():
     """After the first graphed step SupernetStep.prewarm_programs() has lowered every width combination of every MixedOp call
     site: later steps, whose "random" passes draw new widths each time, build no further program."""
