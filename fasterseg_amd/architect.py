@@ -29,6 +29,7 @@ class Architect(object):
         self.latency = 0
         self.latency_supernet = 0
         self.grad_sync = grad_sync
+        self.loss_fn = None           # train_step.SupernetStep: `_loss` with adjacent passes evaluated together (same value and gradients)
         self.latency_input = (3, 1024, 2048)
 
     def step(self, input_train, target_train, input_valid, target_valid, eta=None, network_optimizer=None, unrolled=False):
@@ -50,7 +51,7 @@ class Architect(object):
         return loss + loss_latency
 
     def _backward_step(self, input_valid, target_valid):
-        loss = self.model._loss(input_valid, target_valid)
+        loss = self.loss_fn(input_valid, target_valid) if self.loss_fn is not None else self.model._loss(input_valid, target_valid)
         return loss, self._latency_loss()
 
     def _latency_loss(self):

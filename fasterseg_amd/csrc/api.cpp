@@ -22,7 +22,10 @@ int g_deterministic = [] { const char* e = getenv("FS_DETERMINISTIC"); return (e
 extern "C" void fs_set_deterministic(int on) { fs::g_deterministic = on ? 1 : 0; }
 extern "C" int fs_get_deterministic(void) { return fs::g_deterministic; }
 extern "C" const char* fs_last_error(void) { return fs::g_err; }
-namespace fs { int g_fp32x3 = [] { const char* e = getenv("FS_FP32_X3"); return e ? atoi(e) : 1; }(); }
+// (a named function, not a second immediately-invoked lambda: hipcc gave both namespace-scope initialiser lambdas of this file ONE mangled
+//  name and this flag silently took FS_DETERMINISTIC's initialiser - it read 0 whatever FS_FP32_X3 said, round 6)
+static int env_fp32_split() { const char* e = getenv("FS_FP32_X3"); return e ? (atoi(e) != 0) : 1; }
+namespace fs { int g_fp32x3 = env_fp32_split(); }
 extern "C" void fs_set_fp32_split(int on) { fs::g_fp32x3 = on ? 1 : 0; }
 extern "C" int fs_get_fp32_split(void) { return fs::g_fp32x3; }
 extern "C" int fs_version(void) { return FS_ABI_VERSION; }

@@ -117,6 +117,7 @@ struct ConvGroupArgs {
     int blk_start[FS_MAX_GROUP + 1];     // first workgroup of every problem, [n] = grid size
     ConvArgs p[FS_MAX_GROUP];
 };
+FS_ASSERT_KERNARG(ConvGroupArgs);
 // conv_igemm.hip: second pass of a cross-block split-K conv (sum of the slabs, scale / shift / ReLU, BN statistics)
 void launch_splitk_reduce(hipStream_t st, const ConvArgs& a, int dtype, float* ws, int slices);
 

@@ -12,16 +12,20 @@
 
 namespace fs {
 
-constexpr int FS_MAX_GROUP = 8;          // problems per grouped launch (their arguments travel as kernel arguments: < 4 KB)
+constexpr int FS_MAX_GROUP = 12;         // problems per grouped launch (their arguments travel as kernel arguments: < 4 KB, asserted per struct;
+                                         //   round 6: 8 -> 12, two supernet passes of five MixedOps each share a layer call)
+constexpr int FS_KERNARG_MAX = 4096;     // bytes of kernel arguments a HIP launch can carry
 
 template <typename A> struct GroupOf {
     int n;
     int blk_start[FS_MAX_GROUP + 1];     // first workgroup of every problem, [n] = grid size
     A p[FS_MAX_GROUP];
 };
+#define FS_ASSERT_KERNARG(S) static_assert(sizeof(S) <= fs::FS_KERNARG_MAX, #S " does not fit the kernel-argument segment")
 
 // index of the problem workgroup `bid` belongs to (wave-uniform: scalar compares)
 template <typename G> __device__ __forceinline__ int group_locate(const G& g, int bid) {
+    static_assert(sizeof(G) <= FS_KERNARG_MAX, "grouped launch arguments do not fit the kernel-argument segment");
     int i = 0;
 #pragma unroll
     for (int k = 1; k < FS_MAX_GROUP; ++k) i += (k < g.n && bid >= g.blk_start[k]) ? 1 : 0;

@@ -32,12 +32,13 @@ struct WgradArgs {
     int x3;                   // fp32: contract on the bf16 matrix cores with three-way split operands (conv_igemm.h split3_bf16)
 };
 
-constexpr int WG_MAX_GROUP = 8;
+constexpr int WG_MAX_GROUP = FS_MAX_GROUP;
 struct WgradGroupArgs {       // n weight gradients as ONE launch: see conv_igemm2.hip's grouped kernel
     int n;
     int blk_start[WG_MAX_GROUP + 1];
     WgradArgs p[WG_MAX_GROUP];
 };
+FS_ASSERT_KERNARG(WgradGroupArgs);
 
 // Pixels staged per iteration.  Every iteration is one dependent global -> LDS -> MFMA round trip (~1 us of load latency that the
 // two MFMAs of a 32-pixel chunk cannot hide): with 128 pixels per chunk (64 in fp32: LDS) the loads of a whole chunk are in flight

@@ -199,6 +199,31 @@ FAST_PHASE_ACTIVE = False
 _RECORD_STREAM = bool(int(os.environ.get("FS_RECORD_STREAM", "1")))
 
 
+def conflict_free_chunks(items, per, key):
+    """Partition `items` (in order) into chunks of at most `per` such that no chunk holds two items of one key, and items of one key
+    keep their order across chunks; an item goes into the earliest chunk behind the last one that holds its key.  The layer calls use
+    it with key = (MixedOp, output width): two evaluations of one MixedOp at one output width update the same BatchNorm running
+    statistics (USBatchNorm2d keeps one BatchNorm per width, reference search/slimmable_ops.py:51-70) and must stay stream-ordered -
+    the two sources of a cell that is not pair-batched, two passes of forward_multi that drew the same width."""
+    chunks, keys = [], []
+    for item in items:
+        k = key(item)
+        first = 0
+        for c in range(len(chunks) - 1, -1, -1):
+            if k in keys[c]:
+                first = c + 1
+                break
+        for c in range(first, len(chunks)):
+            if len(chunks[c]) < per:
+                chunks[c].append(item)
+                keys[c].add(k)
+                break
+        else:
+            chunks.append([item])
+            keys.append({k})
+    return chunks
+
+
 def _run_tasks(tasks, dest_fn=None):
     """tasks: [(mixed_op, x, alpha, ratios, bn_groups)] -> outputs.  dest_fn(task index, out shape, dtype, device): a tensor the task's
     output should be written into (a functional.PairBuffers half), or None - honoured by the grouped launch programs only.  While capturing, every primitive of every task runs on its own
@@ -258,7 +283,7 @@ def _run_tasks(tasks, dest_fn=None):
             group = group and bool(_GROUP_CAPTURE)
         if prog is not None and group:
             dest = dest_fn(len(pending), prog.out_shape, x.dtype, x.device) if dest_fn is not None else None
-            grouped.append((len(pending), FN.as_nhwc(x), coef, prog, dest))
+            grouped.append((len(pending), FN.as_nhwc(x), coef, prog, dest, (id(op), widths[1])))
             pending.append(None)
             continue
         if prog is not None:          # the whole MixedOp (five primitives, their sum, and in backward the sum of the five input
@@ -291,8 +316,7 @@ def _run_tasks(tasks, dest_fn=None):
             per = MAX_GROUP
             if not capturing and _LAYER_SPLIT > 1:
                 per = min(MAX_GROUP, max(1, -(-len(items) // _LAYER_SPLIT)))
-            for lo in range(0, len(items), per):
-                chunk = items[lo:lo + per]
+            for chunk in conflict_free_chunks(items, per, lambda item: item[5]):
                 if capturing and _GROUP_CAPTURE == 2:
                     with torch.cuda.stream(lane_for(0)):
                         outs = FN.mixed_op_program_group([c[1] for c in chunk], [c[2] for c in chunk], [c[3] for c in chunk], [c[4] for c in chunk])
@@ -747,9 +771,9 @@ class Network_Multi_Path(nn.Module):
             betas = [None] + [torch.ones_like(getattr(self, n)) * 1. / 2 for n in names["betas"]]
         return alphas, betas
 
-    def _cell_ratio(self, i, j, ratios):
-        """(in, out, down) width spec of cell (layer i, scale j) — reference forward :300-316."""
-        shw = self._stem_head_width[self.arch_idx]
+    def _cell_ratio(self, i, j, ratios, k=None):
+        """(in, out, down) width spec of cell (layer i, scale j) — reference forward :300-316.  k: architecture index (default: the active one)."""
+        shw = self._stem_head_width[self.arch_idx if k is None else k]
         if i == 0 and j == 0:
             return (shw[0], ratios[j][i - j], ratios[j + 1][i - j])
         if i == self._layers - 1:
@@ -800,12 +824,71 @@ class Network_Multi_Path(nn.Module):
         return {key: _PreCoef(row) for key, row in zip(plan["keys"], A.unbind(0))}
 
     def forward(self, input):
+        gen = self._forward_steps(input)
+        try:
+            tasks, dest_fn, _ = next(gen)
+            while True:
+                tasks, dest_fn, _ = gen.send(_run_tasks(tasks, dest_fn))
+        except StopIteration as done:
+            return done.value
+
+    def forward_multi(self, input, specs):
+        """Several passes of `_loss` (reference :392-411: the same batch through the supernet once per width mode) evaluated TOGETHER,
+        layer by layer: the MixedOp evaluations of all passes at one layer only depend on the previous layer of their own pass, so they
+        go to ONE layer call (_run_tasks -> fs_exec_program_group) and every kernel of the layer is one grouped launch over the passes'
+        problems - the supernet step is the sum of its kernel durations at ~4 us of boundary per launch, and a pass alone leaves most
+        of the chip idle.  specs: [(arch_idx or None = keep, prun_mode)] in the reference's order; returns the passes' logits tuples.
+        The arithmetic of every pass is what `forward` computes; what is shared between passes is state, and it is kept in the
+        reference's order: width draws happen pass by pass before the first layer (the host RNG streams are consumed as by sequential
+        forwards), stems / refinement / heads run pass by pass, and two evaluations of one MixedOp at the same OUTPUT width - the only
+        way two passes meet in a BatchNorm's running statistics - are never put into one grouped launch (_run_tasks issues them in pass
+        order).  Weight gradients of the passes add into the same slices with fp32 atomics, as the passes of one backward already do."""
+        global _SAMPLING_PASS
+        gens, reqs = [], []
+        for arch_idx, mode in specs:
+            if arch_idx is not None:
+                self.arch_idx = arch_idx
+            self.prun_mode = mode
+            g = self._forward_steps(input)
+            gens.append(g)
+            reqs.append(next(g))            # width draws + stem of this pass, up to its first layer's task list
+        results = [None] * len(gens)
+        live = list(range(len(gens)))
+        while live:
+            tasks, spans = [], []
+            for p in live:
+                t, d, _ = reqs[p]
+                spans.append((p, len(tasks), len(t), d))
+                tasks += t
+
+            def dest_fn(t, shape, dtype, device, spans=spans):
+                for _, start, n, d in spans:
+                    if start <= t < start + n:
+                        return d(t - start, shape, dtype, device) if d is not None else None
+                return None
+            _SAMPLING_PASS = any(reqs[p][2] for p in live)
+            outs = _run_tasks(tasks, dest_fn if any(sp[3] is not None for sp in spans) else None)
+            nxt = []
+            for p, start, n, _ in spans:
+                try:
+                    reqs[p] = gens[p].send(outs[start:start + n])
+                    nxt.append(p)
+                except StopIteration as done:
+                    results[p] = done.value
+            live = nxt
+        return results
+
+    def _forward_steps(self, input):
+        """`forward` as a generator: yields (MixedOp tasks of the next layer, destination planner, pass draws its widths) and is sent
+        their outputs (_run_tasks); returns the logits.  Between a yield and its send another pass may have run (forward_multi): everything
+        the pass needs afterwards is local, and the two module-level switches are put back on resume."""
         k = self.arch_idx
         stem, refine16, refine32 = self.stem[k], self.refine16[k], self.refine32[k]
         alphas, betas = self._arch_tensors()
         mode = self.prun_mode if self.prun_mode is not None else self._prun_modes[k]
         global _SAMPLING_PASS
-        _SAMPLING_PASS = mode in ("random", "arch_ratio")
+        sampling = mode in ("random", "arch_ratio")
+        _SAMPLING_PASS = sampling
         ratios = self.sample_prun_ratio(mode=mode)
         coef_rows = self._coefficient_rows(alphas, ratios, mode) if _BATCHED_COEFS else None
         # one host read of the whole beta tables instead of one implicit sync per cell (reference :326-328)
@@ -844,10 +927,10 @@ class Network_Multi_Path(nn.Module):
             tasks, slots = [], []
             for j, cell in enumerate(cells):
                 alpha = alphas[j][i - j] if coef_rows is None else None
-                ratio = self._cell_ratio(i, j, ratios)
+                ratio = self._cell_ratio(i, j, ratios, k)
                 assert (cell._down and (ratio[2] is not None)) or ((not cell._down) and (ratio[2] is None))
                 if "_ratio_sampled" not in cell._op.__dict__:
-                    which = [r is _SAMPLED for r in self._cell_ratio(i, j, probe)]
+                    which = [r is _SAMPLED for r in self._cell_ratio(i, j, probe, k)]
                     cell._op.__dict__["_ratio_sampled"] = (which[0], which[1])
                     if cell._down:
                         cell.downsample.__dict__["_ratio_sampled"] = (which[0], which[2])
@@ -878,7 +961,10 @@ class Network_Multi_Path(nn.Module):
                 if not (j == 0 or i == j):      # one of two separately evaluated sources: their weighted sum is the output
                     return None
                 return dest_of(i, j, which, shape, dtype, device)
-            res = dict(zip(slots, _run_tasks(tasks, task_dest if pair_plan is not None else None)))
+            outs = yield (tasks, task_dest if pair_plan is not None else None, sampling)
+            FN._pair_buffers = pair_plan            # (another pass may have run since the yield)
+            _SAMPLING_PASS = sampling
+            res = dict(zip(slots, outs))
             out = [None] * len(cells)
             merges = []                         # (j, which, x, beta row): the pair-batched cells' beta merges, one grouped launch
             for j, cell in enumerate(cells):

@@ -160,7 +160,7 @@ class MixedOpProgram:
         K.call("fs_exec_program", K._stream(), words, n, blob, arr, N_SLOTS)
 
 
-MAX_GROUP = 16         # MAX_LAYER of csrc/program.hip: programs per fs_exec_program_group call
+MAX_GROUP = 24         # MAX_LAYER of csrc/program.hip: programs per fs_exec_program_group call (2 x 12 problems per grouped launch)
 
 
 def run_group(progs, backward, slot_lists):

@@ -101,6 +101,10 @@ _FAST_PHASE = bool(int(_os.environ.get("FS_FAST_PHASE", "1")))      # 0: flip re
 # gradient all-reduce of the supernet step under the backward of its last (eager) pass: 1 with more than one rank (default), 2 also the
 # bookkeeping on a single rank (tests), 0 every bucket in sync()
 _DP_OVERLAP = int(_os.environ.get("FS_DP_OVERLAP", "1"))
+# Adjacent passes of one `_loss` call evaluated together, layer by layer (model_search.Network_Multi_Path.forward_multi): the two
+# fixed-width passes (max, min) become ONE captured graph, the two "random" passes of pretraining one eager joint pass - every kernel of
+# a layer is then one grouped launch over both passes' problems.  FS_JOINT_PASSES=0: pass after pass (rounds 1-5).
+_JOINT_PASSES = bool(int(_os.environ.get("FS_JOINT_PASSES", "1")))
 
 
 class SearchConfig:
@@ -183,6 +187,7 @@ class SupernetStep:
             args = type("Args", (), dict(momentum=cfg.momentum, weight_decay=cfg.weight_decay,
                                          arch_learning_rate=cfg.arch_learning_rate, latency_weight=cfg.latency_weight))
             self.architect = Architect(self.model, args, grad_sync=_allreduce_list)
+            self.architect.loss_fn = self._loss_by_groups          # (eager architecture steps: the same pass groups as the graphed ones)
 
     # ---- the passes of one `_loss` call ---------------------------------------------------------------------------
     # A pass = (arch_idx to select or None to leave it, prun_mode); model_search.py `_loss` runs, in this order,
@@ -196,11 +201,34 @@ class SupernetStep:
             return [(None, "max"), (None, "min"), (None, "random"), (None, "random")]
         return [(0, None), (1, None), (None, "max"), (None, "min")]
 
-    def _is_static(self, spec):
+    def _mode(self, spec):
         arch_idx, mode = spec
-        if mode is None:
-            mode = self.model._prun_modes[arch_idx]
-        return mode in ("max", "min")
+        return self.model._prun_modes[arch_idx] if mode is None else mode
+
+    def _is_static(self, spec):
+        return self._mode(spec) in ("max", "min")
+
+    def _groups(self):
+        """The passes of `_specs()` as tuples of ADJACENT passes that are evaluated together (forward_multi).  Two passes are joined when
+        both replay from a graph or both are issued eagerly, the second keeps the architecture index of the first, and they are not the
+        same sub-network (two fixed-width passes of one mode would meet in every BatchNorm's running statistics: nothing to group).
+        Pairs only: a layer of two passes is ten MixedOp programs, a grouped launch carries twelve problems.  Adjacent, so that every
+        BatchNorm sees its momentum updates in the reference's order (forward_multi / _run_tasks keep evaluations of one MixedOp at
+        one output width in pass order); the bit-reproducible mode orders its gradient writes by stream and keeps single passes."""
+        from . import kernels as K
+        from . import model_search
+        specs = self._specs()
+        ok = (_JOINT_PASSES and model_search._PROGRAMS and model_search._GROUP_PROGRAMS and model_search._CAPTURE_PROGRAMS
+              and model_search._GROUP_CAPTURE in (1, 2) and not K.deterministic_on())
+        groups = []
+        for spec in specs:
+            last = groups[-1] if groups else None
+            if (ok and last is not None and len(last) == 1 and spec[0] is None and self._is_static(last[0]) == self._is_static(spec)
+                    and not (self._is_static(spec) and self._mode(last[0]) == self._mode(spec))):
+                groups[-1] = last + (spec,)
+            else:
+                groups.append((spec,))
+        return groups
 
     def _select(self, spec):
         arch_idx, mode = spec
@@ -211,6 +239,15 @@ class SupernetStep:
     def _run_pass(self, spec, imgs, target):
         self._select(spec)
         return sum(self.model._criterion(logit, target) for logit in self.model(imgs))
+
+    def _run_group(self, group, imgs, target):
+        """Loss of the passes of one group (a tuple of specs): the sum, pass by pass, of what _run_pass returns for each."""
+        if len(group) == 1:
+            return self._run_pass(group[0], imgs, target)
+        total = 0
+        for logits in self.model.forward_multi(imgs, list(group)):
+            total = total + sum(self.model._criterion(logit, target) for logit in logits)
+        return total
 
     def _pass_loss(self, mode, imgs, target):
         return self._run_pass((None, mode), imgs, target)
@@ -252,7 +289,7 @@ class SupernetStep:
             else:
                 p.grad.zero_()
 
-    def _capture_pass(self, phase, spec, side):
+    def _capture_pass(self, phase, group, side):
         imgs, target = self.static[phase]
 
         def fresh():
@@ -268,7 +305,7 @@ class SupernetStep:
         saved = [b_.clone() for b_ in buffers]
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                      # warm-up on the capture stream
-            self._run_pass(spec, imgs, target).backward()
+            self._run_group(group, imgs, target).backward()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         with torch.no_grad():
@@ -280,7 +317,7 @@ class SupernetStep:
         with torch.cuda.graph(g, stream=side):
             K.zero_pool.begin_capture(imgs.device)          # one captured fill instead of two per conv-BN module
             try:
-                loss = self._run_pass(spec, imgs, target)
+                loss = self._run_group(group, imgs, target)
                 loss.backward()
             finally:
                 arena = K.zero_pool.end_capture()
@@ -310,12 +347,14 @@ class SupernetStep:
             with torch.cuda.stream(lane):         # the capture: an allocation inside it would put the counter fill into the graph
                 K.stream_workspace(self.static["w"][0].device)
         state = (self.model.arch_idx, self.model.prun_mode)
+        self._pass_groups = self._groups()
         for phase in self.static:
             self._set_phase(phase)
-            for spec in self._specs():
-                self._select(spec)          # also for the eager passes: later ones inherit arch_idx from them
-                if self._is_static(spec) and (phase, spec) not in self.graphs:
-                    self.graphs[(phase, spec)] = self._capture_pass(phase, spec, side)
+            for group in self._pass_groups:
+                for spec in group:
+                    self._select(spec)      # also for the eager passes: later ones inherit arch_idx from them
+                if self._is_static(group[0]) and (phase, group) not in self.graphs:
+                    self.graphs[(phase, group)] = self._capture_pass(phase, group, side)
         self.model.arch_idx, self.model.prun_mode = state
         torch.cuda.synchronize()
         self._capture_done = True             # from here on the phase flips touch the ~600 tensors that are still consulted (_set_phase)
@@ -326,11 +365,12 @@ class SupernetStep:
         s_imgs.copy_(imgs)
         s_target.copy_(target)
         total = 0
-        specs = self._specs()
-        for spec in specs:
-            if self._is_static(spec):
-                g, loss, touched = self.graphs[(phase, spec)]
-                self._select(spec)
+        groups = self._pass_groups
+        for group in groups:
+            if self._is_static(group[0]):
+                g, loss, touched = self.graphs[(phase, group)]
+                for spec in group:
+                    self._select(spec)
                 g.replay()
                 if touched is not None:
                     self.sync.mark_touched(touched)
@@ -338,12 +378,12 @@ class SupernetStep:
                 # the LAST pass of the weight phase, issued eagerly, with more than one rank: its gradient buckets are all-reduced under
                 # its own backward (FlatGradientSync.final_pass) - the launch programs of its forward say which writes
                 # to expect, everything autograd accumulates itself (stem, refinement, heads) is expected once
-                overlap = (phase == "w" and spec == specs[-1] and _DP_OVERLAP and (self.sync.world > 1 or _DP_OVERLAP > 1))
+                overlap = (phase == "w" and group is groups[-1] and _DP_OVERLAP and (self.sync.world > 1 or _DP_OVERLAP > 1))
                 from . import functional as FN
                 if overlap:
                     FN._touch_log = []
                 try:
-                    loss = self._run_pass(spec, imgs, target)
+                    loss = self._run_group(group, imgs, target)
                     log = FN._touch_log
                 finally:
                     FN._touch_log = None
@@ -449,7 +489,8 @@ class SupernetStep:
     def describe(self):
         """How the passes of a step are executed (bench.py prints it)."""
         specs = self._specs()
-        return {"passes_per_phase": len(specs), "graphed": sum(1 for s_ in specs if self._is_static(s_)) if self.use_graphs else 0,
+        return {"passes_per_phase": len(specs), "pass_groups": [[self._mode(s_) for s_ in g] for g in self._groups()],
+                "graphed": sum(1 for s_ in specs if self._is_static(s_)) if self.use_graphs else 0,
                 "eager": sum(1 for s_ in specs if not (self.use_graphs and self._is_static(s_))),
                 "programs_prewarmed": getattr(self, "programs_prewarmed", 0), "gc_frozen": bool(self.gc_freeze and self._prewarmed),
                 "fused_bn_banks": self.fused_pairs}
@@ -472,11 +513,22 @@ class SupernetStep:
         # `_loss` sums its four forwards and ONE backward runs over all of them - but a weight shared by the four forwards is
         # written by four wgrad launches, and the sink's hook fires on the first: buckets must not go out before sync()
         self.sync.prepare(passes=len(self._specs()))
-        loss = self.model._loss(imgs, target, self.pretrain)
+        loss = self._loss_by_groups(imgs, target)
         loss.backward()
         self.sync.sync()
         self.optimizer.step()
         return loss.detach(), loss_arch
+
+    def _loss_by_groups(self, imgs, target):
+        """`model._loss(imgs, target, pretrain)` with the passes evaluated in the groups the graphed step uses (joint passes issue other -
+        fewer, larger - launches than pass-by-pass evaluation, and the census step of bench.py must time the kernels of the timed steps)."""
+        groups = self._groups()
+        if all(len(g) == 1 for g in groups):
+            return self.model._loss(imgs, target, self.pretrain)
+        loss = 0
+        for group in groups:
+            loss = loss + self._run_group(group, imgs, target)
+        return loss
 
 
 def _allreduce_list(params):

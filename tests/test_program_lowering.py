@@ -295,3 +295,24 @@ def test_prewarm_enumerates_every_width_combination_of_a_call_site():
     assert m._programs == before, "a later call lowered a program the prewarm should have built"
     assert m.prewarm_programs() == 0
     model_search._SAMPLING_PASS = False
+
+
+def test_conflict_free_chunks_keep_same_key_items_apart_and_in_order():
+    """Layer calls (model_search._run_tasks): no chunk holds two evaluations of one (MixedOp, output width); such evaluations keep their
+    order across chunks; everything else packs into the earliest chunk with room."""
+    from fasterseg_amd.model_search import conflict_free_chunks
+    key = lambda item: item[1]
+    a = [(i, "k%d" % i) for i in range(5)]                     # pass 1: five MixedOps
+    b = [(10 + i, "k%d" % i) for i in range(5)]                # pass 2 drew the same widths everywhere
+    chunks = conflict_free_chunks(a + b, 24, key)
+    assert chunks == [a, b]
+    b2 = [(10, "k0"), (11, "x1"), (12, "k2"), (13, "x3"), (14, "x4")]       # two collisions
+    chunks = conflict_free_chunks(a + b2, 24, key)
+    assert chunks == [a + [(11, "x1"), (13, "x3"), (14, "x4")], [(10, "k0"), (12, "k2")]]
+    chunks = conflict_free_chunks(a + b2, 6, key)              # capacity: the first chunk takes one more item
+    assert [len(c) for c in chunks] == [6, 4] and all(len({key(i) for i in c}) == len(c) for c in chunks)
+    order = {it: (ci, pos) for ci, c in enumerate(chunks) for pos, it in enumerate(c)}
+    assert order[(0, "k0")] < order[(10, "k0")] and order[(2, "k2")] < order[(12, "k2")]
+    three = [(0, "k"), (1, "k"), (2, "k")]
+    assert conflict_free_chunks(three, 24, key) == [[(0, "k")], [(1, "k")], [(2, "k")]]
+    assert conflict_free_chunks([], 24, key) == []

@@ -335,6 +335,73 @@ def test_direct_pair_buffers_and_grouped_merges_equal_the_copying_path(use_graph
         assert rel < 2e-2, (k, rel)
 
 
+def _run_joint(pretrain, use_graphs, joint, steps=3, widths=None):
+    """`steps` supernet steps with adjacent passes evaluated together (joint) or one after the other; returns the losses, probe weights and
+    BatchNorm running statistics (the state two passes share).  widths: width_mult_list override (one width: every "random" draw of
+    the two random passes meets in the same BatchNorms - the conflict path of the layer calls)."""
+    from fasterseg_amd import train_step
+    cfg = SmallSearch if widths is None else type("Cfg", (SmallSearch,), dict(width_mult_list=widths))
+    saved = train_step._JOINT_PASSES
+    try:
+        train_step._JOINT_PASSES = joint
+        lut = None
+        if not pretrain:
+            import json
+            import os
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "latency_lut_1080ti.json")) as f:
+                lut = json.load(f)
+        st = train_step.SupernetStep(pretrain=pretrain, cfg=cfg, seed=11, use_graphs=use_graphs, lut=lut)
+        assert any(len(g) > 1 for g in st._groups()) == bool(joint)
+        init = [p.detach().cpu().clone() for p in st.arch_params]
+        imgs, tgt = _batch()
+        np.random.seed(21)
+        torch.manual_seed(21)
+        losses = []
+        for _ in range(steps):
+            out = st.step(imgs, tgt, imgs, tgt)
+            losses.append((float(out[0]), None if out[1] is None else float(out[1])))
+    finally:
+        train_step._JOINT_PASSES = saved
+    probe = {k: p.detach().float().cpu().clone() for k, p in st.model.named_parameters()
+             if k in ("stem.0.0.conv.0.weight", "cells.1.0._op._ops.3.conv1.weight", "cells.2.1.downsample._ops.4.bn2.bn.4.weight",
+                      "cells.2.1.downsample._ops.4.bn2.bn.0.weight", "head02.0.conv_1x1.weight")}
+    probe["arch_delta"] = torch.cat([(p.detach().cpu() - i).reshape(-1) for p, i in zip(st.arch_params, init)])
+    stats = {k: b.detach().double().cpu().clone() for k, b in st.model.named_buffers() if "cells.2." in k or "cells.3.0" in k or "stem.0.0" in k}
+    return losses, probe, stats
+
+
+@pytest.mark.parametrize("pretrain,use_graphs,widths", [(True, False, None), (True, True, None), (False, True, None), (False, False, None),
+                                                         (True, False, [8. / 12, 1.]), (True, True, [8. / 12, 1.])],
+                         ids=["pretrain-eager", "pretrain-graphed", "search-graphed", "search-eager", "two-widths-eager", "two-widths-graphed"])
+def test_joint_passes_equal_sequential_passes(pretrain, use_graphs, widths):
+    """Round 6: adjacent passes of `_loss` evaluated together layer by layer (Network_Multi_Path.forward_multi: max + min as one captured
+    graph, random + random as one eager joint pass) against pass-after-pass evaluation from the same seeds: losses, updated weights and
+    architecture parameters, and - the state passes share - every BatchNorm's running statistics and update count.  With two
+    widths the two random passes draw the same width for most MixedOps: those evaluations must not share a grouped launch
+    (conflict_free_chunks), or a running-statistics update is lost."""
+    ref_losses, ref_w, ref_stats = _run_joint(pretrain, use_graphs, False, widths=widths)
+    new_losses, new_w, new_stats = _run_joint(pretrain, use_graphs, True, widths=widths)
+    for a, b in zip(ref_losses, new_losses):
+        for x, y in zip(a, b):
+            if x is not None:
+                assert abs(x - y) <= 5e-3 * abs(x), (ref_losses, new_losses)
+    ref_delta, new_delta = ref_w.pop("arch_delta"), new_w.pop("arch_delta")
+    for k in ref_w:
+        rel = float((ref_w[k] - new_w[k]).norm() / (ref_w[k].norm() + 1e-12))
+        assert rel < 2e-2, (k, rel)
+    if not pretrain:            # Adam's steps follow the gradient's sign pattern: the same criterion as test_graphed_search_step_equals_eager
+        assert float(ref_delta.abs().max()) > 1e-4
+        differing = float(((ref_delta - new_delta).abs() > 1e-4).float().mean())
+        assert differing < 0.05, differing
+    assert ref_stats.keys() == new_stats.keys() and len(ref_stats) > 50
+    for k in ref_stats:
+        if k.endswith("num_batches_tracked"):
+            assert torch.equal(ref_stats[k], new_stats[k]), k          # every BatchNorm saw the same number of momentum updates
+        else:
+            rel = float((ref_stats[k] - new_stats[k]).norm() / (ref_stats[k].norm() + 1e-9))
+            assert rel < 2e-2, (k, rel)
+
+
 def test_prewarmed_programs_cover_every_random_width_draw():
     """After the first graphed step SupernetStep.prewarm_programs() has lowered every width combination of every MixedOp call
     site: later steps, whose "random" passes draw new widths each time, build no further program."""

@@ -32,15 +32,15 @@ for pretrain in (True, False):
         t0 = sync(); r = fn(); T[name] = T.get(name, 0) + (sync() - t0) * 1e3; return r
     def phase(ph, im, tg):
         s_i, s_t = st.static[ph]; s_i.copy_(im); s_t.copy_(tg)
-        for spec in st._specs():
-            if st._is_static(spec):
-                g, loss, touched = st.graphs[(ph, spec)]
-                st._select(spec)
-                timed("%s graph %s" % (ph, spec), g.replay)
+        for group in st._pass_groups:
+            if st._is_static(group[0]):
+                g, loss, touched = st.graphs[(ph, group)]
+                for spec in group: st._select(spec)
+                timed("%s graph %s" % (ph, group), g.replay)
                 if touched is not None: st.sync.mark_touched(touched)
             else:
-                loss = timed("%s eager fwd %s" % (ph, spec), lambda: st._run_pass(spec, im, tg))
-                timed("%s eager bwd %s" % (ph, spec), loss.backward)
+                loss = timed("%s eager fwd %s" % (ph, group), lambda: st._run_group(group, im, tg))
+                timed("%s eager bwd %s" % (ph, group), loss.backward)
     t_all = sync()
     if not pretrain:
         st._set_phase("a"); st._zero_arch_grads(); K.zero_pool.reset(imgs.device)
