@@ -77,6 +77,23 @@ __device__ __forceinline__ void split3_bf16(const float (&x)[8], bf16x8& h, bf16
     m = __builtin_bit_cast(bf16x8, mp);
     l = __builtin_bit_cast(bf16x8, lp);
 }
+// four values (one 16-byte staging vector) -> four packed bf16 per plane
+__device__ __forceinline__ void split3_bf16x4(const u32x4& v, uint2& h, uint2& m, uint2& l) {
+    uint32_t hp[2], mp[2], lp[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const uint32_t x0 = v[2 * q], x1 = v[2 * q + 1];
+        const float r0 = __uint_as_float(x0) - __uint_as_float(x0 & 0xffff0000u), r1 = __uint_as_float(x1) - __uint_as_float(x1 & 0xffff0000u);
+        const uint32_t y0 = __float_as_uint(r0), y1 = __float_as_uint(r1);
+        const float s0 = r0 - __uint_as_float(y0 & 0xffff0000u), s1 = r1 - __uint_as_float(y1 & 0xffff0000u);
+        hp[q] = __builtin_amdgcn_perm(x1, x0, 0x07060302u);
+        mp[q] = __builtin_amdgcn_perm(y1, y0, 0x07060302u);
+        lp[q] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+    }
+    h = uint2{hp[0], hp[1]};
+    m = uint2{mp[0], mp[1]};
+    l = uint2{lp[0], lp[1]};
+}
 struct Split3 {
     bf16x8 h, m, l;
 };

@@ -30,7 +30,17 @@ struct WgradArgs {
     int slabs;
     int grid_y, grid_z;       // tiles_co * tiles_ci, taps (the grouped launch linearises (slab, tile, tap))
     int x3;                   // fp32: contract on the bf16 matrix cores with three-way split operands (conv_igemm.h split3_bf16)
+    unsigned long long howo_magic, wo_magic;   // m / HoWo == (m * howo_magic) >> howo_shift for 0 <= m < 2^31 (likewise Wo): the pixel -> (n, oh, ow)
+    int howo_shift, wo_shift;                  //   decode of every staged vector was a 64-bit and a 32-bit software division (round 6)
+#ifdef FS_BUILD_PROBES
+    int abl;                  // measurement builds only (FS_WGRAD_ABL): 1 plain stores instead of atomics, 2 no MFMA phase, 4 no LDS writes, 8 only the first chunk is loaded
+#endif
 };
+#ifdef FS_BUILD_PROBES
+#define WG_ABL(p, bit) ((p).abl & (bit))
+#else
+#define WG_ABL(p, bit) 0
+#endif
 
 constexpr int WG_MAX_GROUP = FS_MAX_GROUP;
 struct WgradGroupArgs {       // n weight gradients as ONE launch: see conv_igemm2.hip's grouped kernel
@@ -63,8 +73,18 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int bx, con
     typedef typename Stage<T>::elem LT;
     constexpr int LP = Stage<T>::pitch;
     constexpr bool NATIVE = sizeof(LT) == 2;                       // bf16 tiles feed the bf16 MFMA directly
-    __shared__ __attribute__((aligned(16))) LT sA[KC][LP];         // dY  [pixel][co]
-    __shared__ __attribute__((aligned(16))) LT sB[KC][LP];         // X   [pixel][ci]
+    // fp32 with split operands (p.x3): every staged value is split ONCE, when its chunk is written to LDS, into three bf16 planes laid
+    // out like the bf16 tiles ([plane][pixel][PITCH16]); the contraction then reads them with the same transposing LDS reads as the bf16
+    // path.  The first version split inside the MFMA loop - per wave and use: twice the VALU work, all of it between the MFMAs, and the
+    // loop was VALU-bound (~350 clocks of and / sub / perm per 256 clocks of MFMA).  The fp32 tiles alias the front of the plane storage.
+    constexpr int SPLIT_BYTES = sizeof(T) == 4 ? 2 * 3 * KC * PITCH16 * 2 : 0;
+    constexpr int PLAIN_BYTES = 2 * KC * LP * (int)sizeof(LT);
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[SPLIT_BYTES > PLAIN_BYTES ? SPLIT_BYTES : PLAIN_BYTES];
+    LT (*sA)[LP] = reinterpret_cast<LT (*)[LP]>(s_raw);                                        // dY  [pixel][co]
+    LT (*sB)[LP] = reinterpret_cast<LT (*)[LP]>(s_raw + KC * LP * sizeof(LT));                 // X   [pixel][ci]
+    bf16_t (*pA)[KC][PITCH16] = reinterpret_cast<bf16_t (*)[KC][PITCH16]>(s_raw);                              // [plane][pixel][co]
+    bf16_t (*pB)[KC][PITCH16] = reinterpret_cast<bf16_t (*)[KC][PITCH16]>(s_raw + 3 * KC * PITCH16 * 2);       // [plane][pixel][ci]
+    const bool x3 = sizeof(T) == 4 && p.x3;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int wm = wave >> 1, wn = wave & 1;
@@ -100,9 +120,10 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int bx, con
             const bool aok = mok && (co0 + cvec < p.Cout);
             ka[i] = aok ? 0xffffffffu : 0u;
             ra[i] = ldg16(p.dy + (aok ? (mm * p.dy_cs + co0 + cvec) * (long long)sizeof(T) : 0ll));
-            const int n = (int)(mm / p.HoWo);
-            const int rem = (int)(mm - (long long)n * p.HoWo);
-            const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+            const uint32_t mu = (uint32_t)mm;                                  // (M < 2^31: wgrad_prepare)
+            const int n = (int)(((unsigned long long)mu * p.howo_magic) >> p.howo_shift);
+            const uint32_t rem = mu - (uint32_t)n * (uint32_t)p.HoWo;
+            const int oh = (int)(((unsigned long long)rem * p.wo_magic) >> p.wo_shift), ow = (int)rem - oh * p.Wo;
             const int ih = oh * p.stride - p.pad + tr, iw = ow * p.stride - p.pad + ts;
             const bool bok = mok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W && (ci0 + cvec < p.Cin);
             const long long pix = ((long long)n * p.H + ih) * p.W + iw;
@@ -124,6 +145,20 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int bx, con
                     *reinterpret_cast<u32x4*>(&sB[row][cvec]) = vb;
                     continue;
                 }
+                if constexpr (sizeof(T) == 4) {
+                    if (x3) {
+                        uint2 h, m, l;
+                        split3_bf16x4(va, h, m, l);
+                        *reinterpret_cast<uint2*>(&pA[0][row][cvec]) = h;
+                        *reinterpret_cast<uint2*>(&pA[1][row][cvec]) = m;
+                        *reinterpret_cast<uint2*>(&pA[2][row][cvec]) = l;
+                        split3_bf16x4(vb, h, m, l);
+                        *reinterpret_cast<uint2*>(&pB[0][row][cvec]) = h;
+                        *reinterpret_cast<uint2*>(&pB[1][row][cvec]) = m;
+                        *reinterpret_cast<uint2*>(&pB[2][row][cvec]) = l;
+                        continue;
+                    }
+                }
                 float fa[VEC], fb[VEC];
                 Elem<T>::unpack(va, fa);
                 Elem<T>::unpack(vb, fb);
@@ -143,9 +178,9 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int bx, con
     if (m_begin < m_end) {
         load_chunk(m_begin);
         for (long long mc = m_begin; mc < m_end; mc += KC) {
-            store_chunk();
+            if (!WG_ABL(p, 4)) store_chunk();
             __syncthreads();
-            if (mc + KC < m_end) load_chunk(mc + KC);
+            if (mc + KC < m_end && !WG_ABL(p, 8)) load_chunk(mc + KC);
             // this wave's share of the chunk's pixels: [kpart, kpart + 1) * KC / ksplit (compile-time trip counts: the operand reads keep
             // their immediate offsets)
             auto mfma_part = [&](auto ks_tag) {
@@ -175,16 +210,23 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int bx, con
                 } else {
                     const float* pa = reinterpret_cast<const float*>(&sA[kpart * KN + (lane >> 5)][0]) + wm * 32 + (lane & 31);
                     const float* pb = reinterpret_cast<const float*>(&sB[kpart * KN + (lane >> 5)][0]) + wn * 32 + (lane & 31);
-                    if (p.x3) {
-                        // 16 pixels per step: the lane's 8 K slots are pixels k + 2 s (+ 1 in the upper half-wave), the same for both operands
+                    if (x3) {
+                        // the planes were split at staging: per 16 pixels two transposing reads per plane and operand (as in the bf16 path)
+                        typedef __attribute__((ext_vector_type(4))) short s16x4;
+                        typedef __attribute__((ext_vector_type(8))) short s16x8;
+                        typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+                        const int g = lane >> 4, t = lane & 15;
+                        const int prow = kpart * KN + (g >> 1) * 8 + (t >> 2), pcol = (g & 1) * 16 + (t & 3) * 4;
 #pragma unroll
                         for (int k = 0; k < KN; k += 16) {
-                            float xa[8], xb[8];
-#pragma unroll
-                            for (int q = 0; q < 8; ++q) { xa[q] = pa[(k + 2 * q) * PITCH]; xb[q] = pb[(k + 2 * q) * PITCH]; }
                             Split3 sa, sb;
-                            split3_bf16(xa, sa.h, sa.m, sa.l);
-                            split3_bf16(xb, sb.h, sb.m, sb.l);
+                            auto frag = [&](bf16_t (*plane)[PITCH16], int col) {
+                                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)&plane[prow + k][col]);
+                                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)&plane[prow + k + 4][col]);
+                                return __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                            };
+                            sa.h = frag(pA[0], wm * 32 + pcol); sa.m = frag(pA[1], wm * 32 + pcol); sa.l = frag(pA[2], wm * 32 + pcol);
+                            sb.h = frag(pB[0], wn * 32 + pcol); sb.m = frag(pB[1], wn * 32 + pcol); sb.l = frag(pB[2], wn * 32 + pcol);
                             mma_x3(sa, sb, acc);
                         }
                     } else {
@@ -193,7 +235,8 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int bx, con
                     }
                 }
             };
-            if (ksplit == 1) mfma_part(std::integral_constant<int, 1>{});
+            if (WG_ABL(p, 2)) { /* no contraction */ }
+            else if (ksplit == 1) mfma_part(std::integral_constant<int, 1>{});
             else if (ksplit == 2) mfma_part(std::integral_constant<int, 2>{});
             else mfma_part(std::integral_constant<int, 4>{});
             __syncthreads();
@@ -230,6 +273,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int bx, con
                 float* dst = p.o_stride > 0 ? p.dw + row * p.o_stride + ci * p.i_stride + (tr * p.S + ts) * p.t_stride
                                             : p.dw + ((row * p.R + tr) * p.S + ts) * p.Cin + ci;
                 if (p.part != nullptr) *dst += acc[r];
+                else if (WG_ABL(p, 1)) *dst = acc[r];
                 else atomicAdd(dst, acc[r]);
             }
         }
@@ -301,10 +345,22 @@ static fs_status wgrad_prepare(const fs_conv_desc* d, const void* x, const void*
     a.stride = d->stride; a.pad = d->pad; a.Ho = d->Ho; a.Wo = d->Wo;
     a.x_cs = d->x_cs; a.dy_cs = d->y_cs;
     a.x3 = (d->dtype == FS_F32 && g_fp32x3) ? 1 : 0;
+#ifdef FS_BUILD_PROBES
+    { static const int abl = [] { const char* e = getenv("FS_WGRAD_ABL"); return e ? atoi(e) : 0; }(); a.abl = abl; }
+#endif
     a.n_seg = d->n_seg > 0 ? d->n_seg : 0;
     a.g_jump = d->n_seg > 0 ? d->g_jump : 0;
     const long long M = (long long)d->N * d->Ho * d->Wo;
+    FS_REQUIRE(M > 0 && M < (1ll << 31), FS_ERR_UNSUPPORTED, "fs_conv2d_wgrad: %lld output pixels", M);
     a.M = (int)M; a.HoWo = d->Ho * d->Wo;
+    auto magic = [](unsigned int dv, unsigned long long* mg, int* sh) {      // Granlund-Montgomery round-up form, exact for dividends < 2^32
+        int l = 0;
+        while ((1ull << l) < dv) ++l;
+        *sh = 32 + l;
+        *mg = ((1ull << *sh) / dv) + 1;
+    };
+    magic((unsigned int)a.HoWo, &a.howo_magic, &a.howo_shift);
+    magic((unsigned int)d->Wo, &a.wo_magic, &a.wo_shift);
     const int tiles_co = (d->Cout + BCH - 1) / BCH;
     a.tiles_ci = (d->Cin + BCH - 1) / BCH;
     const int taps = d->R * d->S;
