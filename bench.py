@@ -458,12 +458,14 @@ def run_student_train(args, world, rank, backend):
     # ---- parity gate: the FIRST step's loss (the stepper that is about to be timed, teacher engine included) vs the CPU oracle on a
     # slice of the same batch with the same weights.  OHEM's min_kept is per batch (train/train.py:62), so the device side evaluates
     # the same slice through the same modules and criteria (eager teacher) - and the full-batch first step must agree with it too.
+    # (loss_only BEFORE the first step: the oracle gets the weights of step 0, and one SGD step of lr 0.01 already moves this loss by
+    # 0.5 % - within the bf16 bar of rounds 3-5, five times the fp32 bar the gate has had since round 6)
+    nb = 2
+    got = stepper.loss_only(imgs[:nb], target[:nb]) if rank == 0 else None
     first = float(stepper.step(imgs, target))
     parity = None
     if rank == 0:
-        nb = 2
         xi, ti = imgs[:nb], target[:nb]
-        got = stepper.loss_only(xi, ti)
         with torch.no_grad():
             t_logits = ref_ops.derived_forward(pt, meta_t, xi.cpu(), training=False)
             p8, p16, p32 = ref_ops.derived_forward(dict(ps), meta_s, xi.cpu(), training=True)
