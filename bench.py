@@ -171,7 +171,8 @@ def parallelism(world, backend, what):
 def frame_traffic(family, dtype):
     """HBM bytes per launch of a kernel family of the C2 frame: profiles/r03_c2_pmc_frame.json (tools/pmc_frame.py: FETCH_SIZE / WRITE_SIZE
     passes over plan-order frames, conv3x3 and conv1x1 separately), else the round-2 table; None when there is no measurement."""
-    for name, get in (("r05_c2_pmc_frame.json", lambda d: d.get(family, {}).get("hbm_bytes_per_launch")),
+    for name, get in (("r06_c2_pmc_frame.json", lambda d: d.get(family, {}).get("hbm_bytes_per_launch")),
+                      ("r05_c2_pmc_frame.json", lambda d: d.get(family, {}).get("hbm_bytes_per_launch")),
                       ("r04_c2_pmc_frame.json", lambda d: d.get(family, {}).get("hbm_bytes_per_launch")),
                       ("r03_c2_pmc_frame.json", lambda d: d.get(family, {}).get("hbm_bytes_per_launch")),
                       ("pmc_traffic.json", lambda d: d.get(dtype, {}).get(family))):
@@ -191,7 +192,7 @@ def step_traffic(workload, kernels, launched=None):
     """HBM bytes per launch of the given kernels of a train step from profiles/r0N_<workload>_pmc.json (tools/pmc_table.py: separate
     FETCH_SIZE / WRITE_SIZE passes), or None - also when the committed PMC table does not cover the kernels the step launches NOW
     (`launched`: name -> {"launches"} of the census step; a table taken with an older kernel would be a stale figure)."""
-    for rnd in ("r05", "r04", "r03"):
+    for rnd in ("r06", "r05", "r04", "r03"):
         path = os.path.join(ROOT, "profiles", "%s_%s_pmc.json" % (rnd, workload))
         if os.path.exists(path):
             break

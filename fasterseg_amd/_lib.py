@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfasterseg_hip.so")
 
-EXPECTED_ABI = 209          # FS_ABI_VERSION of include/fasterseg_hip.h these bindings were written against
+EXPECTED_ABI = 210          # FS_ABI_VERSION of include/fasterseg_hip.h these bindings were written against
 FS_F32, FS_BF16 = 0, 1
 FS_CONV_RELU, FS_CONV_TRANSPOSED, FS_CONV_ACCUM, FS_CONV_RELU_TAIL = 1, 2, 4, 8
 

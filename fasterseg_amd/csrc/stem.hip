@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void stem_lds_kernel(int H, int W, int Ho, int
 // odd columns de-interleaved) is the direct kernel's; A fragments are gathered from that window with constant offsets; the
 // D fragments go through an LDS transpose so every lane stores 16 bytes (the earlier MFMA attempt mentioned above lost on
 // its 2-byte column stores).
-constexpr int SM_K = 32;
+
 
 struct StemTapOff {
     int off[2][2][8];      // [kk][k-half of the lane][e]: word offset of tap k = kk*16 + half*8 + e relative to the lane's base; -1 = zero pad

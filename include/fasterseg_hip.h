@@ -88,7 +88,7 @@ typedef struct fs_resize_desc {
 const char* fs_last_error(void);
 /* ABI revision of this header; fs_version() returns the one the library was built from.  Bindings check both this and
  * fs_struct_size() when they load the library (fasterseg_amd/_lib.py) - a stale .so must not be used silently. */
-#define FS_ABI_VERSION 209
+#define FS_ABI_VERSION 210
 int fs_version(void);
 /* Bit-reproducible mode (default off; FS_DETERMINISTIC=1 in the environment turns it on at load): every cross-block reduction that
  * otherwise uses float atomics - the pixel slabs of fs_conv2d_wgrad_ws, BatchNorm statistics and parameter gradients of maps above
@@ -511,7 +511,8 @@ fs_status fs_exec_program(void* stream, const long long* words, long long n_word
  * host cost per kernel node is higher.  Events are created / destroyed with fs_event_create / fs_event_destroy. */
 fs_status fs_exec_program_streams(void* const* streams, int n_streams, const long long* words, long long n_words,
                                   const unsigned char* blob, void* const* slots, int n_slots);
-/* Layer form (ABI 209; ABI 208 required identical command structure and k <= 8): k <= 16 independent programs - the MixedOps of one
+/* Layer form (ABI 209; ABI 208 required identical command structure and k <= 8; ABI 210: k <= 24 and up to 12 problems per grouped
+ * launch - two passes of a supernet `_loss` share a layer call): k independent programs - the MixedOps of one
  * supernet layer, which only depend on the previous layer (search/model_search.py:310-333) - issued on ONE stream.  Every round takes
  * the next pending command of each program, picks the op kind of lowest rank among them (cheap early ops first, the closing weighted
  * sum last) and issues the pending commands of that kind as ONE grouped launch per kernel: conv->BN units forward / backward (grouped

@@ -9,7 +9,7 @@ O=$R/gpurun_out
 cd $R
 mkdir -p $O
 what=${1:-all}
-TAG=${2:-r05}
+TAG=${2:-r06}
 export FS_ENGINE_PLAN=$O/${TAG}_c2_plan_choices.json
 if [ $what = all ] || [ $what = c2 ]; then
   rm -f $FS_ENGINE_PLAN.*
@@ -29,6 +29,8 @@ if [ $what = all ] || [ $what = steps ]; then
   bash tools/prof_step.sh c5 3 ${TAG}_c5_supernet_search_bf16 2>&1 | head -1
   bash tools/prof_step.sh c4 5 ${TAG}_c4_student_train_bf16 2>&1 | head -1
   FS_DTYPE=fp32 bash tools/prof_step.sh c3 3 ${TAG}_c3_supernet_pretrain_fp32 2>&1 | head -1
+  FS_DTYPE=fp32 bash tools/prof_step.sh c5 3 ${TAG}_c5_supernet_search_fp32 2>&1 | head -1
+  FS_DTYPE=fp32 bash tools/prof_step.sh c4 5 ${TAG}_c4_student_train_fp32 2>&1 | head -1
 fi
 pmc() {  # name counters... -- command...
   name=$1; shift; ctr=""
@@ -49,7 +51,8 @@ for wl in c3 c5 c4; do
   if [ $what = all ] || [ $what = pmc ] || [ $what = pmc_$wl ]; then
     # ONE eager step per pass (no capture warm-ups, no graph replays: under --pmc every dispatch is serialised and a pass over a graphed
     # run does not fit the GPU budget); the kernels are the ones the timed steps launch (tests/test_measurement_artifacts.py checks the names)
-    export FS_SUPERNET_GRAPHS=0 FS_PROFILE_WARMUP=0
+    # (round 6: the train workloads' printed value is the fp32 step - the traffic tables are taken in fp32 as well)
+    export FS_SUPERNET_GRAPHS=0 FS_PROFILE_WARMUP=0 FS_DTYPE=fp32
     F=$(pmc ${wl}f FETCH_SIZE -- python $R/tools/profile_step.py $wl 1)
     W=$(pmc ${wl}w WRITE_SIZE -- python $R/tools/profile_step.py $wl 1)
     if [ $wl = c3 ]; then            # MFMA busy cycles: one workload is enough to cross-check the FLOP-derived fractions
@@ -58,6 +61,6 @@ for wl in c3 c5 c4; do
     else
       python $R/tools/pmc_table.py $O/${TAG}_${wl}_pmc.json f=$F w=$W | head -8
     fi
-    unset FS_SUPERNET_GRAPHS FS_PROFILE_WARMUP
+    unset FS_SUPERNET_GRAPHS FS_PROFILE_WARMUP FS_DTYPE
   fi
 done
