@@ -24,6 +24,7 @@ from .genotypes import PRIMITIVES
 from .operations import *            # noqa: F401,F403
 from .operations import OPS, BasicResidual2x, ConvNorm
 from .seg_oprs import Head
+from .latency_model import LatencyModelMixin
 
 
 # https://github.com/YongfeiYan/Gumbel_Softmax_VAE (as cited by the reference)
@@ -109,36 +110,11 @@ _PROGRAMS = bool(int(os.environ.get("FS_MIXEDOP_PROGRAMS", "1")))
 # and the five input gradients of a MixedOp are summed by one kernel instead of four autograd adds.  FS_CAPTURE_PROGRAMS=0
 # captures the per-module path.
 _CAPTURE_PROGRAMS = bool(int(os.environ.get("FS_CAPTURE_PROGRAMS", "1")))
-_lane_pool = {}
-
-
-def branch_lanes(stream):
-    """Side streams that fork from `stream` (created on first use; call once BEFORE capturing on `stream`, stream creation
-    is not a capturable operation)."""
-    key = (stream.device, stream.cuda_stream)
-    lanes = _lane_pool.get(key)
-    if lanes is None:
-        lanes = _lane_pool[key] = [torch.cuda.Stream(device=stream.device) for _ in range(max(0, _BRANCH_LANES - 1))]
-    return lanes
-
-
 # One level up, all MixedOps of a layer (up to 3 scales x {from-down, from-keep} x {_op, downsample} = 12) only depend on the
 # previous layer: under capture the primitives of ALL of them fork from the capturing stream at once (one flat fork / join
 # per layer over a pool of 20 streams - 60 measured slower; nested forks - a lane forking its own lanes - crash hipStreamEndCapture on ROCm 7.2),
 # so a layer's critical path is one primitive chain instead of twelve MixedOps in a row.  FS_LAYER_LANES=1 disables it.
 _LAYER_LANES = int(os.environ.get("FS_LAYER_LANES", "20"))
-_task_pool = {}
-
-
-def layer_lanes(stream):
-    """Side streams for the primitives of one layer (create BEFORE capturing on `stream`)."""
-    key = (stream.device, stream.cuda_stream)
-    pool = _task_pool.get(key)
-    if pool is None:
-        pool = _task_pool[key] = [torch.cuda.Stream(device=stream.device) for _ in range(max(0, _LAYER_LANES - 1))]
-    return pool
-
-
 # A cell that is fed both from the scale above (down) and from its own scale (keep) is evaluated ONCE on the two inputs
 # concatenated along the batch, its BatchNorms normalising the two halves independently (functional.bn_groups): the arithmetic
 # of the reference's two evaluations (model_search.py:322-329) at half the launches - the supernet step is launch-bound.
@@ -148,13 +124,6 @@ _PAIR_BATCH = bool(int(os.environ.get("FS_PAIR_BATCH", "1")))
 # per pair, as in round 5), and the beta merges of a layer's pair-batched cells are one grouped launch (FS_MERGE_GROUP=0: one each).
 _PAIR_DIRECT = bool(int(os.environ.get("FS_PAIR_DIRECT", "1")))
 _MERGE_GROUP = bool(int(os.environ.get("FS_MERGE_GROUP", "1")))
-
-
-def _eval(op, x, alpha, ratios, groups):
-    if groups == 1:
-        return op(x, alpha, ratios)
-    with FN.bn_groups(groups):
-        return op(x, alpha, ratios)
 
 
 # Eager ("random" / Gumbel width) passes replay one launch program per MixedOp.  On ONE stream such a pass is bound by the serial
@@ -199,174 +168,9 @@ FAST_PHASE_ACTIVE = False
 _RECORD_STREAM = bool(int(os.environ.get("FS_RECORD_STREAM", "1")))
 
 
-def conflict_free_chunks(items, per, key):
-    """Partition `items` (in order) into chunks of at most `per` such that no chunk holds two items of one key, and items of one key
-    keep their order across chunks; an item goes into the earliest chunk behind the last one that holds its key.  The layer calls use
-    it with key = (MixedOp, output width): two evaluations of one MixedOp at one output width update the same BatchNorm running
-    statistics (USBatchNorm2d keeps one BatchNorm per width, reference search/slimmable_ops.py:51-70) and must stay stream-ordered -
-    the two sources of a cell that is not pair-batched, two passes of forward_multi that drew the same width."""
-    chunks, keys = [], []
-    for item in items:
-        k = key(item)
-        first = 0
-        for c in range(len(chunks) - 1, -1, -1):
-            if k in keys[c]:
-                first = c + 1
-                break
-        for c in range(first, len(chunks)):
-            if len(chunks[c]) < per:
-                chunks[c].append(item)
-                keys[c].add(k)
-                break
-        else:
-            chunks.append([item])
-            keys.append({k})
-    return chunks
-
-
-def _run_tasks(tasks, dest_fn=None):
-    """tasks: [(mixed_op, x, alpha, ratios, bn_groups)] -> outputs.  dest_fn(task index, out shape, dtype, device): a tensor the task's
-    output should be written into (a functional.PairBuffers half), or None - honoured by the grouped launch programs only.  While capturing, every primitive of every task runs on its own
-    stream; the alpha-weighted sums follow on the capturing stream after the join.  Eager training passes put whole MixedOp
-    programs on side streams."""
-    on_gpu = len(tasks) > 1 and tasks[0][1].is_cuda
-    capturing = on_gpu and torch.cuda.is_current_stream_capturing()
-    eager_lanes = (on_gpu and not capturing and _EAGER_LANES > 1 and _PROGRAMS and torch.is_grad_enabled() and tasks[0][0].training)
-    # bit-reproducible mode: the ordered slab reduction of the weight gradient finishes with a plain read-modify-write of the gradient,
-    # which needs the launches that touch one tensor stream-ordered (the same cell._op on two lanes would race: ADVICE r3) - no lanes
-    ordered = on_gpu and K.deterministic_on()
-    if ordered or not ((capturing and _LAYER_LANES > 1) or eager_lanes):
-        return [_eval(op, x, alpha, ratios, g) for op, x, alpha, ratios, g in tasks]
-    main = torch.cuda.current_stream()
-    pool = layer_lanes(main)
-    if not capturing:
-        pool = pool[:_EAGER_LANES]
-    used, slot, pending = [], 0, []
-    grouped = []                 # (index into pending, x, coef, prog) of the tasks that run from launch programs
-    crossing = []                # (tensor, lane) of eager passes: inputs made on `main` and read on a lane, outputs made on a lane
-
-    def hand_over(t, lane):
-        """Caching-allocator bookkeeping of a tensor that crosses streams in an eager pass: without it the block returns to
-        its home stream's pool when the last reference dies and can be rewritten while the other stream's kernels still read it."""
-        if _RECORD_STREAM and not capturing and torch.is_tensor(t) and t.is_cuda and lane is not main:
-            t.record_stream(lane)
-
-    def lane_for(k):
-        if not pool:                                       # FS_LAYER_LANES=1: everything on the current stream
-            return main
-        lane = pool[k % len(pool)]
-        if lane not in used:
-            lane.wait_stream(main)                         # fork: the previous layer's outputs are complete on `main`
-            used.append(lane)
-        return lane
-    for op, x, alpha, ratios, groups in tasks:
-        widths = [None, None]
-        # (the widths are applied to the five primitives' modules only when something reads them there: a launch-program cache miss or
-        # the per-module path - 23 us of attribute stores per MixedOp otherwise, on a host-bound step)
-        coef = op._coefficients(x, alpha, ratios, widths, set_ratio=False)
-        prog = None
-        if _PROGRAMS and (_CAPTURE_PROGRAMS or not capturing) and op.training and torch.is_grad_enabled():
-            with FN.bn_groups(groups):
-                prog = op._program(FN.as_nhwc(x), coef, widths[0], widths[1])
-        if prog is None:
-            # train_step's fast phase flip leaves the cell weights trainable during the architecture phase: correct only while every
-            # MixedOp runs from a launch program (which asks its probe weight); a per-module fallback would compute - and accumulate into
-            # the live flat gradient - weight gradients nobody wants (ADVICE r5)
-            assert not (FAST_PHASE_ACTIVE and op.training and torch.is_grad_enabled() and not op._ops[1].conv1.weight.requires_grad
-                        and any(p.requires_grad for p in op._ops[3].parameters())), \
-                "a MixedOp fell back to the per-module path while only the probe weights carry the phase (FS_FAST_PHASE=0 to disable)"
-            op.set_prun_ratio((widths[0], widths[1]))
-            if FN._touch_log is not None and op.training and torch.is_grad_enabled():
-                FN._touch_log.append(None)          # a MixedOp off the launch programs: its gradient writes are not in the log
-        group = _GROUP_PROGRAMS and (not capturing or _GROUP_CAPTURE)
-        if MIMIC_CAPTURE and not capturing and not _SAMPLING_PASS:
-            group = group and bool(_GROUP_CAPTURE)
-        if prog is not None and group:
-            dest = dest_fn(len(pending), prog.out_shape, x.dtype, x.device) if dest_fn is not None else None
-            grouped.append((len(pending), FN.as_nhwc(x), coef, prog, dest, (id(op), widths[1])))
-            pending.append(None)
-            continue
-        if prog is not None:          # the whole MixedOp (five primitives, their sum, and in backward the sum of the five input
-            lane = lane_for(slot)                          # gradients) as one launch program on one lane
-            xn = FN.as_nhwc(x)
-            hand_over(xn, lane)
-            hand_over(coef, lane)
-            with torch.cuda.stream(lane):
-                out = FN.mixed_op_program(xn, coef, prog)
-            crossing.append((out, lane))
-            pending.append((out, None))
-            slot += 1
-            continue
-        if not capturing:             # no program (nothing to differentiate, gradients outside the sink): per-module path, in place
-            with FN.bn_groups(groups):
-                pending.append((FN.weighted_sum([prim(x) for prim in op._ops], coef), None))
-            continue
-        outs = []
-        for prim in op._ops:
-            with torch.cuda.stream(lane_for(slot)), FN.bn_groups(groups):
-                outs.append(prim(x))
-            slot += 1
-        pending.append((outs, coef))
-    if grouped:
-        from .program import MAX_GROUP
-        buckets = {}
-        for item in grouped:                                # one call needs one dtype; the executor sorts out everything else
-            buckets.setdefault(item[1].dtype, []).append(item)
-        for items in buckets.values():
-            per = MAX_GROUP
-            if not capturing and _LAYER_SPLIT > 1:
-                per = min(MAX_GROUP, max(1, -(-len(items) // _LAYER_SPLIT)))
-            for chunk in conflict_free_chunks(items, per, lambda item: item[5]):
-                if capturing and _GROUP_CAPTURE == 2:
-                    with torch.cuda.stream(lane_for(0)):
-                        outs = FN.mixed_op_program_group([c[1] for c in chunk], [c[2] for c in chunk], [c[3] for c in chunk], [c[4] for c in chunk])
-                elif capturing and _GROUP_CAPTURE >= 3:      # (crashes hipStreamEndCapture: kept for the reproduction only)
-                    with torch.cuda.stream(lane_for(slot % (_GROUP_CAPTURE - 1))):
-                        outs = FN.mixed_op_program_group([c[1] for c in chunk], [c[2] for c in chunk], [c[3] for c in chunk], [c[4] for c in chunk])
-                    slot += 1
-                elif capturing or _LAYER_SPLIT == 1:        # on the current stream itself
-                    outs = FN.mixed_op_program_group([c[1] for c in chunk], [c[2] for c in chunk], [c[3] for c in chunk], [c[4] for c in chunk])
-                else:
-                    lane = lane_for(slot)                   # FS_LAYER_SPLIT calls side by side on the lanes
-                    for c in chunk:
-                        hand_over(c[1], lane)
-                        hand_over(c[2], lane)
-                    with torch.cuda.stream(lane):
-                        outs = FN.mixed_op_program_group([c[1] for c in chunk], [c[2] for c in chunk], [c[3] for c in chunk], [c[4] for c in chunk])
-                    crossing.extend((o, lane) for o in outs)
-                    slot += 1
-                for c, o in zip(chunk, outs):
-                    pending[c[0]] = (o, None)
-    for lane in used:
-        main.wait_stream(lane)                             # one join per layer
-    if _RECORD_STREAM and not capturing:
-        for t, lane in crossing:                           # made on a lane, consumed (and eventually freed) on `main`
-            if lane is not main:
-                t.record_stream(main)
-    return [outs if coef is None else FN.weighted_sum(outs, coef) for outs, coef in pending]
-
-
-def _run_branches(ops, x):
-    main = torch.cuda.current_stream()
-    lanes = branch_lanes(main)
-    used = []
-    plan = []
-    for k, op in enumerate(ops):                  # branch 0 stays on the current stream, the others round-robin the lanes
-        lane = None if k == 0 else lanes[(k - 1) % len(lanes)]
-        if lane is not None and lane not in used:
-            lane.wait_stream(main)                # fork: every lane starts after x is ready
-            used.append(lane)
-        plan.append((op, lane))
-    outs = []
-    for op, lane in plan:
-        if lane is None:
-            outs.append(op(x))
-        else:
-            with torch.cuda.stream(lane):
-                outs.append(op(x))
-    for lane in used:
-        main.wait_stream(lane)                    # join before the weighted sum
-    return outs
+# how a layer's evaluations are issued - stream lanes, layer calls of the launch-program executor, conflict-free chunks - is layer_exec.py
+from .layer_exec import branch_lanes, conflict_free_chunks, layer_lanes          # noqa: E402,F401
+from .layer_exec import run_branches as _run_branches, run_tasks as _run_tasks   # noqa: E402,F401
 
 
 class _PreCoef:
@@ -604,29 +408,7 @@ def _weighted_sum(weights, tensors):
     return acc
 
 
-class _Lin:
-    """A linear form sum_e coef[e] * x_e + const over the MixedOp latencies x_e (forward_latency with constant betas)."""
-    __slots__ = ("c", "k")
-
-    def __init__(self, c=None, k=0.0):
-        self.c, self.k = (c or {}), k
-
-    def __add__(self, o):
-        if isinstance(o, _Lin):
-            c = dict(self.c)
-            for e, v in o.c.items():
-                c[e] = c.get(e, 0.0) + v
-            return _Lin(c, self.k + o.k)
-        return _Lin(dict(self.c), self.k + float(o))
-    __radd__ = __add__
-
-    def __mul__(self, f):
-        f = float(f)
-        return _Lin({e: v * f for e, v in self.c.items()}, self.k * f)
-    __rmul__ = __mul__
-
-
-class Network_Multi_Path(nn.Module):
+class Network_Multi_Path(LatencyModelMixin, nn.Module):
     def __init__(self, num_classes=19, layers=16, criterion=nn.CrossEntropyLoss(ignore_index=-1), Fch=12, width_mult_list=[1., ],
                  prun_modes=['arch_ratio', ], stem_head_width=[(1., 1.), ]):
         super(Network_Multi_Path, self).__init__()
@@ -1012,221 +794,6 @@ class Network_Multi_Path(nn.Module):
         # contiguous NCHW fp32 tensor like the reference does
         return tuple(FN.interpolate(p, size=(p.size(2), p.size(3)), out_nchw=1) for p in preds)
         ###################################
-
-    # ---- forward_latency with constant betas as ONE dot product ---------------------------------------------------------------
-    # With beta=False (two of the three calls of the architect's latency penalty, architect.py:66-72) the reference's layer
-    # recurrence (model_search.py:430-470) is LINEAR in the per-MixedOp latencies x_e = <LUT row, alpha row> * score_in * score_out
-    # with coefficients that depend only on the topology: total = const + <coef, x>.  The plan below derives coef once by running
-    # the same recurrence on linear forms, and tabulates the LUT rows of every width pair of every MixedOp on the device, so a call
-    # is ~15 tensor ops instead of ~500 scalar ones, and the Gumbel-width call needs NO host read-back of the sampled indices (the
-    # per-MixedOp path reads them to build its LUT keys: a device sync in the middle of the architecture step).
-    def _latency_plan(self, size):
-        from . import operations
-        lut = operations.latency_lookup_table
-        key = (self.arch_idx, tuple(size), len(lut), float(sum(lut.values())))
-        plans = self.__dict__.setdefault("_latency_plans", {})
-        if key in plans:
-            return plans[key]
-        k = self.arch_idx
-        W = self._width_mult_list
-        counts = (self._layers - 1, self._layers - 1, self._layers - 2)
-        offs = (0, counts[0], counts[0] + counts[1])
-        slot_probe = [[("slot", offs[s] + n) for n in range(counts[s])] for s in range(3)]
-        stem_latency, sz = 0.0, tuple(size)
-        for m in self.stem[k]:
-            latency, sz = m.forward_latency(sz)
-            stem_latency += float(latency)
-        evals, index = [], {}            # one variable per MixedOp that is evaluated
-
-        def variable(mixed, hw, r_in, r_out, alpha_row):
-            if id(mixed) not in index:
-                index[id(mixed)] = len(evals)
-                evals.append((mixed, hw, r_in, r_out, alpha_row))
-            return _Lin({index[id(mixed)]: 1.0})
-        alpha_off = (0, self._layers, 2 * self._layers - 1)
-        hw_prev = [[(sz[1], sz[2]), None]]
-        T = [[_Lin(k=stem_latency), _Lin()], [_Lin(), _Lin()], [_Lin(), _Lin()]]
-        half = 0.5                                                   # the constant betas (`_arch_tensors(beta=False)`)
-        for i, cells in enumerate(self.cells):
-            hw_out, latency = [], []
-            for j, cell in enumerate(cells):
-                r = self._cell_ratio(i, j, slot_probe)
-                row = alpha_off[j] + (i - j)
-                if j == 0 or i == j:
-                    hw = hw_prev[0][0] if j == 0 else hw_prev[j - 1][1]
-                    o = variable(cell._op, hw, r[0], r[1], row)
-                    d = variable(cell.downsample, hw, r[0], r[2], row) if cell._down else None
-                    hw_out.append((hw, (hw[0] // 2, hw[1] // 2) if cell._down else None))
-                    latency.append([o, d])
-                else:           # from down (0) and from keep (1): the same MixedOp on inputs of one size, weights b0 + b1
-                    hw = hw_prev[j][0]
-                    assert hw_prev[j - 1][1] == hw
-                    o = variable(cell._op, hw, r[0], r[1], row)
-                    d = variable(cell.downsample, hw, r[0], r[2], row) if cell._down else None
-                    hw_out.append((hw, (hw[0] // 2, hw[1] // 2) if cell._down else None))
-                    latency.append([half * o + half * o, (half * d + half * d) if d is not None else _Lin()])
-            hw_prev = hw_out
-            for ii, lat in enumerate(latency):          # the reference's recurrence, including its use of the leftover `j`
-                if ii == 0:
-                    if lat[0] is not None: T[ii][0] = T[ii][0] + lat[0]
-                    if lat[1] is not None: T[ii][1] = T[ii][0] + lat[1]
-                elif i == ii:
-                    if lat[0] is not None: T[ii][0] = T[ii - 1][1] + lat[0]
-                    if lat[1] is not None: T[ii][1] = T[ii - 1][1] + lat[1]
-                else:
-                    if lat[0] is not None: T[ii][0] = half * T[ii][0] + half * T[ii - 1][1] + lat[0]
-                    if lat[1] is not None: T[ii][1] = half * T[ii][0] + half * T[ii - 1][1] + lat[1]
-        total = T[0][0] + T[1][0] + T[2][0]
-        E, nW = len(evals), len(W)
-        n_slots = sum(counts)
-        table = torch.zeros(E, nW * nW, len(PRIMITIVES))
-        slot_in, slot_out, n_out = [], [], []
-        for e, (mixed, hw, r_in, r_out, _) in enumerate(evals):
-            opts_in = list(W) if isinstance(r_in, tuple) else [r_in]
-            opts_out = list(W) if isinstance(r_out, tuple) else [r_out]
-            slot_in.append(r_in[1] if isinstance(r_in, tuple) else n_slots)       # n_slots: the fixed-width pseudo slot
-            slot_out.append(r_out[1] if isinstance(r_out, tuple) else n_slots)
-            n_out.append(len(opts_out))
-            for a, w0 in enumerate(opts_in):
-                for b, w1 in enumerate(opts_out):
-                    mixed.set_prun_ratio((w0, w1))
-                    for q, op in enumerate(mixed._ops):
-                        table[e, a * len(opts_out) + b, q] = float(op.forward_latency((int(op.C_in * w0), hw[0], hw[1]))[0])
-        dev = getattr(self, self._arch_names[k]["alphas"][0]).device
-        coef = torch.tensor([total.c.get(e, 0.0) for e in range(E)], dtype=torch.float32)
-        plan = dict(E=E, const=float(total.k), coef=coef.to(dev), table=table.to(dev), table_host=table, index=index,
-                    stem_latency=stem_latency, slots_host=(slot_in, slot_out, n_out),
-                    slot_in=torch.tensor(slot_in, device=dev), slot_out=torch.tensor(slot_out, device=dev),
-                    n_out=torch.tensor(n_out, device=dev), alpha_rows=torch.tensor([ev[4] for ev in evals], device=dev),
-                    rows=torch.arange(E, device=dev), n_slots=n_slots, fixed={})
-        plans[key] = plan
-        return plan
-
-    def _forward_latency_linear(self, size, alpha, ratio):
-        k = self.arch_idx
-        plan = self._latency_plan(size)
-        mode = "max"
-        if ratio:
-            mode = self.prun_mode if self.prun_mode is not None else self._prun_modes[k]
-        dev = plan["coef"].device
-        nW = len(self._width_mult_list)
-        scores = None
-        if mode == "arch_ratio":
-            ratios = self.sample_prun_ratio(mode=mode, read_indices=False)          # same RNG draws as the per-MixedOp path
-            if getattr(ratios, "stacked", None) is not None:
-                R, idx = ratios.stacked, ratios.index                               # straight-through one-hots [slots, widths], arg-max per slot
-            else:
-                flat = [r for scale in ratios for r in scale]
-                idx = torch.cat([r._fs_index_t for r in flat])                      # sampled width index per slot, on the device
-                R = torch.stack(flat)
-            score = R.gather(1, idx[:, None]).squeeze(1)                            # = ratio[k] of `_width_and_score`
-            idx_ext = torch.cat([idx, idx.new_zeros(1)])
-            scores = torch.cat([score, score.new_ones(1)])
-            k_in, k_out = idx_ext[plan["slot_in"]], idx_ext[plan["slot_out"]]
-            L = plan["table"][plan["rows"], k_in * plan["n_out"] + k_out]
-        else:
-            if mode not in ("max", "min"):
-                return None                                                         # host-sampled widths: per-MixedOp path
-            if mode not in plan["fixed"]:
-                w = 0 if mode == "min" else nW - 1
-                idx_ext = torch.full((plan["n_slots"] + 1,), w, device=dev)
-                idx_ext[-1] = 0
-                k_in, k_out = idx_ext[plan["slot_in"]], idx_ext[plan["slot_out"]]
-                plan["fixed"][mode] = plan["table"][plan["rows"], k_in * plan["n_out"] + k_out]
-            L = plan["fixed"][mode]
-        if alpha:
-            names = self._arch_names[k]["alphas"]
-            A = torch.cat([F.softmax(getattr(self, n), dim=-1) for n in names])[plan["alpha_rows"]]
-            x = (L * A).sum(1)
-        else:
-            x = L.sum(1) * (1. / len(PRIMITIVES))
-        if scores is not None:
-            x = x * scores[plan["slot_in"]] * scores[plan["slot_out"]]
-        return plan["const"] + (plan["coef"] * x).sum()
-
-    # ---- forward_latency with live betas and constant alpha / widths (the architect's third call) ----------------------------
-    # Every assignment of the reference's recurrence is an affine map of the state (T00, T01, T10, T11, T20, T21, 1) whose
-    # entries are linear in the softmaxed betas: M_k = C_k + sum_b beta_b G_k[.,.,b].  All ~90 maps are built by ONE einsum and
-    # multiplied together by a log-depth tree of batched matmuls: ~12 tensor ops instead of ~350 scalar ones, same arithmetic up
-    # to fp32 summation order.
-    def _latency_beta_plan(self, size):
-        base = self._latency_plan(size)
-        if "beta" in base:
-            return base["beta"]
-        k = self.arch_idx
-        nW = len(self._width_mult_list)
-        slot_in, slot_out, n_out = base["slots_host"]
-        n_slots = base["n_slots"]
-        x = []                                         # per MixedOp: <LUT row at the maximum widths, uniform alpha>
-        for e in range(base["E"]):
-            k_in = nW - 1 if slot_in[e] < n_slots else 0
-            k_out = nW - 1 if slot_out[e] < n_slots else 0
-            x.append(float(base["table_host"][e, k_in * n_out[e] + k_out].sum()) * (1. / len(PRIMITIVES)))
-        index = base["index"]
-        rows = (0, self._layers - 2, self._layers - 3)                 # rows of betas[1], betas[2]
-        boff = (0, 0, 2 * rows[1])
-
-        def bsym(j, row, c):                                            # flat index of betas[j][row][c], python negative-row semantics
-            return boff[j] + (row % rows[j]) * 2 + c
-        nb = 2 * (rows[1] + rows[2])
-        ONE = 6
-        steps = []                                                      # (target, [(beta index or None, coefficient, source)])
-
-        def var(ii, c):
-            return 2 * ii + c
-        for i, cells in enumerate(self.cells):
-            lat = []
-            for j, cell in enumerate(cells):
-                xo = x[index[id(cell._op)]]
-                xd = x[index[id(cell.downsample)]] if cell._down else None
-                if j == 0 or i == j:
-                    lat.append(([(None, xo, ONE)], [(None, xd, ONE)] if xd is not None else None))
-                else:
-                    b0, b1 = bsym(j, i - j - 1, 0), bsym(j, i - j - 1, 1)
-                    lat.append(([(b0, xo, ONE), (b1, xo, ONE)], [(b0, xd, ONE), (b1, xd, ONE)] if xd is not None else []))
-            jl = len(cells) - 1                                         # the reference's leftover loop variable
-            for ii, (l0, l1) in enumerate(lat):
-                if ii == 0:
-                    steps.append((var(0, 0), [(None, 1.0, var(0, 0))] + l0))
-                    if l1 is not None:
-                        steps.append((var(0, 1), [(None, 1.0, var(0, 0))] + l1))
-                elif i == ii:
-                    steps.append((var(ii, 0), [(None, 1.0, var(ii - 1, 1))] + l0))
-                    if l1 is not None:
-                        steps.append((var(ii, 1), [(None, 1.0, var(ii - 1, 1))] + l1))
-                else:
-                    w0, w1 = bsym(jl, i - jl - 1, 0), bsym(jl, i - jl - 1, 1)
-                    steps.append((var(ii, 0), [(w1, 1.0, var(ii, 0)), (w0, 1.0, var(ii - 1, 1))] + l0))
-                    if l1 is not None:
-                        steps.append((var(ii, 1), [(w1, 1.0, var(ii, 0)), (w0, 1.0, var(ii - 1, 1))] + l1))
-        K_ = 1
-        while K_ < len(steps):
-            K_ *= 2
-        C = torch.eye(7).repeat(K_, 1, 1)
-        G = torch.zeros(K_, 7, 7, nb)
-        for n, (target, terms) in enumerate(steps):
-            C[n, target] = 0.0
-            for b, coef, src in terms:
-                if b is None:
-                    C[n, target, src] += coef
-                else:
-                    G[n, target, src, b] += coef
-        dev = base["coef"].device
-        s0 = torch.zeros(7)
-        s0[0], s0[ONE] = base["stem_latency"], 1.0
-        sel = torch.zeros(7)
-        sel[0] = sel[2] = sel[4] = 1.0
-        base["beta"] = dict(C=C.to(dev), G=G.to(dev), s0=s0.to(dev), sel=sel.to(dev))
-        return base["beta"]
-
-    def _forward_latency_beta(self, size):
-        plan = self._latency_beta_plan(size)
-        names = self._arch_names[self.arch_idx]["betas"]
-        bflat = torch.cat([F.softmax(getattr(self, n), dim=-1).reshape(-1) for n in names])
-        M = plan["C"] + torch.matmul(plan["G"], bflat)                  # [K, 7, 7]; step n applies M[n]
-        while M.shape[0] > 1:                                           # later steps multiply from the left
-            M = torch.bmm(M[1::2], M[0::2])
-        return torch.dot(plan["sel"], M[0] @ plan["s0"])
 
     def forward_latency(self, size, alpha=True, beta=True, ratio=True):
         if not beta and _LINEAR_LATENCY:
