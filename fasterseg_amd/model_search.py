@@ -173,6 +173,32 @@ from .layer_exec import branch_lanes, conflict_free_chunks, layer_lanes         
 from .layer_exec import run_branches as _run_branches, run_tasks as _run_tasks   # noqa: E402,F401
 
 
+# forward_multi(batch_tails=True): refinement + heads of a pass pair in one evaluation on the batch-concatenated maps; FS_TAIL_BATCH=0: per pass
+_TAIL_BATCH = bool(int(os.environ.get("FS_TAIL_BATCH", "1")))
+# ... and their stem evaluated once (FS_STEM_SHARE=0: once per pass)
+_STEM_SHARE = bool(int(os.environ.get("FS_STEM_SHARE", "1")))
+
+
+class _DeferredTail:
+    """What a pass hands back when its refinement / heads are evaluated by the caller: architecture index + the last layer's maps."""
+    __slots__ = ("k", "o0", "o1", "o2")
+
+    def __init__(self, k, o0, o1, o2):
+        self.k, self.o0, self.o1, self.o2 = k, o0, o1, o2
+
+
+class JointLogits:
+    """The five logits tensors of `passes` passes concatenated along the batch (pass after pass)."""
+    __slots__ = ("logits", "passes")
+
+    def __init__(self, logits, passes):
+        self.logits, self.passes = logits, passes
+
+    def split(self):
+        n = self.logits[0].shape[0] // self.passes
+        return [tuple(t[p * n:(p + 1) * n] for t in self.logits) for p in range(self.passes)]
+
+
 class _PreCoef:
     """The five coefficients of one MixedOp evaluation, already multiplied by the width scores (Network_Multi_Path computes
     those of a whole pass in a few batched ops, see `_coefficient_rows`)."""
@@ -614,7 +640,7 @@ class Network_Multi_Path(LatencyModelMixin, nn.Module):
         except StopIteration as done:
             return done.value
 
-    def forward_multi(self, input, specs):
+    def forward_multi(self, input, specs, batch_tails=False):
         """Several passes of `_loss` (reference :392-411: the same batch through the supernet once per width mode) evaluated TOGETHER,
         layer by layer: the MixedOp evaluations of all passes at one layer only depend on the previous layer of their own pass, so they
         go to ONE layer call (_run_tasks -> fs_exec_program_group) and every kernel of the layer is one grouped launch over the passes'
@@ -626,12 +652,26 @@ class Network_Multi_Path(LatencyModelMixin, nn.Module):
         way two passes meet in a BatchNorm's running statistics - are never put into one grouped launch (_run_tasks issues them in pass
         order).  Weight gradients of the passes add into the same slices with fp32 atomics, as the passes of one backward already do."""
         global _SAMPLING_PASS
+        # batch_tails (two passes of one architecture index, training on the GPU): refinement and heads - the same modules on maps of the
+        # same shape in both passes - run ONCE on the two passes' maps concatenated along the batch, their BatchNorms normalising the
+        # halves independently and updating the running statistics half after half (functional.bn_groups: the arithmetic of two
+        # evaluations in pass order, as for a doubly-fed cell); returns ONE JointLogits instead of the passes' tuples.
+        joint_tail = (batch_tails and _TAIL_BATCH and len(specs) == 2 and specs[1][0] is None and self.training and input.is_cuda
+                      and torch.is_grad_enabled())
         gens, reqs = [], []
-        for arch_idx, mode in specs:
+        shared_stem = None
+        for n, (arch_idx, mode) in enumerate(specs):
             if arch_idx is not None:
                 self.arch_idx = arch_idx
             self.prun_mode = mode
-            g = self._forward_steps(input)
+            if joint_tail and _STEM_SHARE:
+                # The stem (fixed width per architecture index, reference forward :286-288) maps the same images through the same weights
+                # in both passes: evaluated ONCE, used by both (autograd adds the two passes' gradients of its output before the one
+                # backward: J^T g1 + J^T g2 = J^T (g1 + g2)).  Its BatchNorms owe the second pass's momentum update, with the same batch
+                # statistics b: r1 = (1 - m) r0 + m b, r2 = (1 - m) r1 + m b = r1 + (1 - m) (r1 - r0); num_batches_tracked += 1.
+                if n == 0:
+                    shared_stem = self._stem_once(self.stem[self.arch_idx], input)
+            g = self._forward_steps(input, defer_tail=joint_tail, stem_out=shared_stem)
             gens.append(g)
             reqs.append(next(g))            # width draws + stem of this pass, up to its first layer's task list
         results = [None] * len(gens)
@@ -658,14 +698,38 @@ class Network_Multi_Path(LatencyModelMixin, nn.Module):
                 except StopIteration as done:
                     results[p] = done.value
             live = nxt
+        if joint_tail:
+            a, b = results
+            assert a.k == b.k
+            with FN.bn_groups(2):
+                logits = self._tail(a.k, FN.batch_pair(a.o0, b.o0), FN.batch_pair(a.o1, b.o1), FN.batch_pair(a.o2, b.o2))
+            return JointLogits(logits, 2)
         return results
 
-    def _forward_steps(self, input):
+    def _stem_once(self, stem, input):
+        """stem(input) with the BatchNorm running statistics of TWO identical evaluations (forward_multi)."""
+        plan = self.__dict__.setdefault("_stem_bn", {}).get(id(stem))
+        if plan is None:
+            bns = [m for m in stem.modules() if isinstance(m, nn.BatchNorm2d) and m.track_running_stats]
+            assert all(m.momentum == bns[0].momentum and m.momentum is not None for m in bns)
+            plan = self.__dict__["_stem_bn"][id(stem)] = ([t for m in bns for t in (m.running_mean, m.running_var)],
+                                                          [m.num_batches_tracked for m in bns], float(bns[0].momentum))
+        floats, counts, momentum = plan
+        with torch.no_grad():
+            before = torch._foreach_add(floats, 0.0)
+        out = stem(input)
+        with torch.no_grad():
+            delta = torch._foreach_sub(floats, before)
+            torch._foreach_add_(floats, delta, alpha=1.0 - momentum)
+            torch._foreach_add_(counts, 1)
+        return out
+
+    def _forward_steps(self, input, defer_tail=False, stem_out=None):
         """`forward` as a generator: yields (MixedOp tasks of the next layer, destination planner, pass draws its widths) and is sent
         their outputs (_run_tasks); returns the logits.  Between a yield and its send another pass may have run (forward_multi): everything
         the pass needs afterwards is local, and the two module-level switches are put back on resume."""
         k = self.arch_idx
-        stem, refine16, refine32 = self.stem[k], self.refine16[k], self.refine32[k]
+        stem = self.stem[k]
         alphas, betas = self._arch_tensors()
         mode = self.prun_mode if self.prun_mode is not None else self._prun_modes[k]
         global _SAMPLING_PASS
@@ -681,7 +745,7 @@ class Network_Multi_Path(LatencyModelMixin, nn.Module):
         # rows handed out by ONE unbind per table: `betas[j][row]` per cell is a select whose backward is a zero-fill + copy + add per cell
         beta_rows = [None] + [b.unbind(0) for b in betas[1:]]
 
-        out_prev = [[stem(input), None]]  # stem: one cell
+        out_prev = [[stem(input) if stem_out is None else stem_out, None]]  # stem: one cell
         probe = [[_SAMPLED] * len(r) for r in ratios]          # which entries of a cell's (in, out, down) widths are sampled
         # Every cell output has ONE consumer cell in the next layer; a consumer fed from two scales evaluates once on both inputs
         # concatenated along the batch.  The joint buffers are planned one layer ahead so that the producers write into their halves
@@ -779,12 +843,19 @@ class Network_Multi_Path(LatencyModelMixin, nn.Module):
                     out[j][which] = y
             out_prev = out
         FN._pair_buffers = None
+        if defer_tail:          # forward_multi evaluates the refinement / heads of its passes together (_tail on the batched maps)
+            return _DeferredTail(k, out[0][0], out[1][0], out[2][0])
+        return self._tail(k, out[0][0], out[1][0], out[2][0])
+
+    def _tail(self, k, o0, o1, o2):
+        """Refinement + the five heads (reference forward :335-353) on the last layer's three maps."""
+        refine16, refine32 = self.refine16[k], self.refine32[k]
         ###################################
         up2 = lambda t: FN.interpolate(t, scale_factor=2)
-        out0 = out[0][0]
-        out1 = refine16[1](FN.cat([up2(refine16[0](out[1][0])), out[0][0]]))
-        out2 = refine32[1](FN.cat([up2(refine32[0](out[2][0])), out[1][0]]))
-        out2 = refine32[3](FN.cat([up2(refine32[2](out2)), out[0][0]]))
+        out0 = o0
+        out1 = refine16[1](FN.cat([up2(refine16[0](o1)), o0]))
+        out2 = refine32[1](FN.cat([up2(refine32[0](o2)), o1]))
+        out2 = refine32[3](FN.cat([up2(refine32[2](out2)), o0]))
 
         preds = [self.head0[k](out0), self.head1[k](out1), self.head2[k](out2),
                  self.head02[k](FN.cat([out0, out2])), self.head12[k](FN.cat([out1, out2]))]

@@ -131,7 +131,7 @@ class SupernetStep:
     same sub-network."""
 
     def __init__(self, pretrain=True, cfg=SearchConfig, seed=12345, device="cuda", lut=None, use_graphs=None,
-                 compute_dtype=torch.float32, gc_freeze=None):
+                 compute_dtype=torch.float32, gc_freeze=None, bucket_mb=128):
         import os
         self.compute_dtype = compute_dtype
         self.use_graphs = bool(int(os.environ.get("FS_SUPERNET_GRAPHS", "1"))) if use_graphs is None else use_graphs
@@ -161,7 +161,7 @@ class SupernetStep:
         self.arch_params = [p for group in self.model._arch_parameters for p in group]
         for p in self.arch_params:
             p.requires_grad_(False)
-        self.sync = FlatGradientSync(self.weights, bucket_mb=128, average="defer")      # FlatSGD folds 1 / world into its clip scale
+        self.sync = FlatGradientSync(self.weights, bucket_mb=bucket_mb, average="defer")      # FlatSGD folds 1 / world into its clip scale
         # train_search.py:94-98 SGD + :249 clip_grad_norm_(5), one launch over the flat buffers
         self.optimizer = FlatSGD(self.sync, cfg.lr, cfg.momentum, cfg.weight_decay, max_norm=cfg.grad_clip,
                                  pack_dtype=compute_dtype, unused=os.environ.get("FS_SGD_UNUSED", "skip"))
@@ -244,8 +244,15 @@ class SupernetStep:
         """Loss of the passes of one group (a tuple of specs): the sum, pass by pass, of what _run_pass returns for each."""
         if len(group) == 1:
             return self._run_pass(group[0], imgs, target)
+        out = self.model.forward_multi(imgs, list(group), batch_tails=True)
+        from .model_search import JointLogits
+        if isinstance(out, JointLogits):
+            # the passes' logits along the batch: the criterion is a mean over the valid pixels, every pass sees the same labels, so
+            # sum_p CE(logit_p, target) = passes * CE(logits of all passes, target repeated)
+            t = torch.cat([target] * out.passes)
+            return out.passes * sum(self.model._criterion(logit, t) for logit in out.logits)
         total = 0
-        for logits in self.model.forward_multi(imgs, list(group)):
+        for logits in out:
             total = total + sum(self.model._criterion(logit, target) for logit in logits)
         return total
 
@@ -366,7 +373,15 @@ class SupernetStep:
         s_target.copy_(target)
         total = 0
         groups = self._pass_groups
-        for group in groups:
+        # Comm / compute overlap under DP: the gradient buckets are all-reduced under the backward of the LAST EAGER
+        # group (FlatGradientSync.final_pass - a replayed graph runs no Python hooks and offers no point to launch a collective from).
+        # When graphs are replayed after it (the search step: arch 0 | Gumbel pass | max + min graph), its FORWARD stays where the reference
+        # has it - the BatchNorm running statistics see their updates in the reference's order - and its BACKWARD is issued after the
+        # remaining replays: gradient accumulation commutes, and by then every other write of the step is enqueued.
+        eager = [i for i, g_ in enumerate(groups) if not self._is_static(g_[0])]
+        last_eager = eager[-1] if eager else None
+        deferred = None
+        for gi, group in enumerate(groups):
             if self._is_static(group[0]):
                 g, loss, touched = self.graphs[(phase, group)]
                 for spec in group:
@@ -378,7 +393,7 @@ class SupernetStep:
                 # the LAST pass of the weight phase, issued eagerly, with more than one rank: its gradient buckets are all-reduced under
                 # its own backward (FlatGradientSync.final_pass) - the launch programs of its forward say which writes
                 # to expect, everything autograd accumulates itself (stem, refinement, heads) is expected once
-                overlap = (phase == "w" and group is groups[-1] and _DP_OVERLAP and (self.sync.world > 1 or _DP_OVERLAP > 1))
+                overlap = (phase == "w" and gi == last_eager and _DP_OVERLAP and (self.sync.world > 1 or _DP_OVERLAP > 1))
                 from . import functional as FN
                 if overlap:
                     FN._touch_log = []
@@ -387,15 +402,26 @@ class SupernetStep:
                     log = FN._touch_log
                 finally:
                     FN._touch_log = None
-                if overlap and log is not None and all(p is not None for p in log):
-                    if self._other_params is None:
-                        cells = {id(p) for p in self.model.cells.parameters()}
-                        self._other_params = [p for p in self.weights if id(p) not in cells]
-                    self.sync.final_pass(log, [p for p in self._other_params if p.requires_grad])
-                loss.backward()
+                usable = overlap and log is not None and all(p is not None for p in log)
+                if usable and gi != len(groups) - 1:
+                    deferred = (loss, log)
+                else:
+                    if usable:
+                        self._declare_final_pass(log)
+                    loss.backward()
                 loss = loss.detach()
             total = total + loss
+        if deferred is not None:
+            loss, log = deferred
+            self._declare_final_pass(log)
+            loss.backward()
         return total
+
+    def _declare_final_pass(self, log):
+        if self._other_params is None:
+            cells = {id(p) for p in self.model.cells.parameters()}
+            self._other_params = [p for p in self.weights if id(p) not in cells]
+        self.sync.final_pass(log, [p for p in self._other_params if p.requires_grad])
 
     def _graphed_pretrain_loss(self, imgs, target):
         return self._phase_loss("w", imgs, target)

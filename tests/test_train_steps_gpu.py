@@ -402,6 +402,55 @@ def test_joint_passes_equal_sequential_passes(pretrain, use_graphs, widths):
             assert rel < 2e-2, (k, rel)
 
 
+@pytest.mark.parametrize("pretrain", [True, False], ids=["pretrain", "search"])
+def test_dp_overlap_bookkeeping_of_the_last_eager_group_changes_nothing(pretrain):
+    """Under DP the gradient buckets leave under the backward of the step's last EAGER group (FlatGradientSync.final_pass; in the search
+    step that group's backward is issued after the graph replays that follow it).  FS_DP_OVERLAP=2 runs the bookkeeping on a single
+    rank: buckets are declared complete before sync() (early_launches), and losses, weights, architecture parameters and BatchNorm
+    statistics equal the step without it."""
+    from fasterseg_amd import train_step
+    saved = train_step._DP_OVERLAP
+    res = {}
+    try:
+        for mode in (0, 2):
+            train_step._DP_OVERLAP = mode
+            lut = None
+            if not pretrain:
+                import json
+                import os
+                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "latency_lut_1080ti.json")) as f:
+                    lut = json.load(f)
+            st = train_step.SupernetStep(pretrain=pretrain, cfg=SmallSearch, seed=11, use_graphs=True, lut=lut, bucket_mb=1)   # several buckets
+            imgs, tgt = _batch()
+            np.random.seed(21)
+            torch.manual_seed(21)
+            losses, early = [], []
+            for _ in range(3):
+                out = st.step(imgs, tgt, imgs, tgt)
+                losses.append(float(out[0]))
+                early.append(st.sync.early_launches)
+            res[mode] = (losses, early, len(st.sync.buckets),
+                         {k: p.detach().float().cpu().clone() for k, p in st.model.named_parameters()
+                          if k in ("stem.0.0.conv.0.weight", "cells.1.0._op._ops.3.conv1.weight", "cells.2.1.downsample._ops.4.bn2.bn.4.weight",
+                                   "head02.0.conv_1x1.weight") or k.startswith("alpha")},
+                         {k: b.detach().double().cpu().clone() for k, b in st.model.named_buffers() if "cells.2." in k})
+    finally:
+        train_step._DP_OVERLAP = saved
+    (l0, e0, nb, w0, s0), (l2, e2, _, w2, s2) = res[0], res[2]
+    assert nb > 2 and all(e == 0 for e in e0)
+    assert all(1 <= e <= nb for e in e2[1:]), (e2, nb)          # (the first step captures its graphs: hooks are off inside a capture)
+    for a, b in zip(l0, l2):
+        assert abs(a - b) <= 5e-3 * abs(a), (l0, l2)
+    for k in w0:
+        rel = float((w0[k] - w2[k]).norm() / (w0[k].norm() + 1e-12))
+        assert rel < (0.1 if k.startswith("alpha") else 2e-2), (k, rel)
+    for k in s0:
+        if k.endswith("num_batches_tracked"):
+            assert torch.equal(s0[k], s2[k]), k
+        else:
+            assert float((s0[k] - s2[k]).norm() / (s0[k].norm() + 1e-9)) < 2e-2, k
+
+
 def test_prewarmed_programs_cover_every_random_width_draw():
     """After the first graphed step SupernetStep.prewarm_programs() has lowered every width combination of every MixedOp call
     site: later steps, whose "random" passes draw new widths each time, build no further program."""
