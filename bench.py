@@ -45,6 +45,9 @@ if ROOT not in sys.path:
 
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}      # dense MFMA peaks, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
+# arithmetic of the committed PMC traffic tables (profiles/r06_<workload>_pmc.json; tools/prof_round.sh): `roofline.traffic` of a train
+# step is quoted only for the leg that matches (the fp32 pass of C4 crashed rocprofv3 itself: its table is the bf16 step's, as in round 5)
+PMC_TABLE_DTYPE = {"c3": "fp32", "c5": "fp32", "c4": "bf16"}
 PUBLISHED_STUDENT_FPS = 163.9                        # BASELINE.md §1 (GTX 1080Ti + TensorRT fp32, latency/ variant)
 METRIC = "supernet train-step images/sec @1024x2048 (1/2/4/8 GPU) + student fps"
 PRECISION = {"bf16": "bf16 activations + bf16 MFMA, fp32 accumulate / BN statistics / master weights / parameter gradients",
@@ -402,8 +405,13 @@ def _timed_census(args, world, rank, step_fn, extra_entries=(), workload=None):
     if rank != 0:
         return None
     roof, families, kernels = census.roofline_timed(rec, args.dtype, PEAK_TFLOPS[args.dtype], PEAK_HBM_GBS, extra_entries)
-    if roof is not None and workload and args.dtype == "bf16":
+    if roof is not None and workload and args.dtype == PMC_TABLE_DTYPE.get(workload, "bf16"):
         roof["traffic"] = step_traffic(workload, STEP_FAMILY_KERNELS.get(roof["kernel"], ()), kernels)
+    if roof is not None and roof.get("bound") == "mfma" and args.dtype == "fp32":
+        # (detail file only) what `peak` is: the fp32 MFMA's dense peak.  Since round 6 the fp32 convolutions contract on the bf16 matrix
+        # cores with exactly split operands - 8 bf16 MFMAs per 16 values of K, i.e. a ceiling of 2500 / 8 = 312.5 TFLOP/s of fp32 work
+        roof["peak_note"] = "157.3 = dense fp32 MFMA peak; the split form's ceiling is 2500 / 8 = 312.5 TFLOP/s: frac %.4f of that" % (
+            roof["achieved"] / 312.5)
     out = {"roofline": roof, "kernel_families": families, "kernels_in_step": kernels}
     if roof is not None and roof.get("step_ideal_ms"):
         # the whole step against the roofs (the analogue of C2's frame_roofline): every family at its own roof - convolutions at the dense
