@@ -529,7 +529,7 @@ inline bool bn_small_ok(long long pixels, int groups) {
 
 // ---- grid-wide passes (elementwise.hip) ------------------------------------------------------------------------------------------------
 struct BnApplyArgs {
-    long long pixels; int cv; const void* x; int x_cs; const float* stats; float count; const float* gamma; const float* beta;
+    long long pixels; DivInt cv; const void* x; int x_cs; const float* stats; float count; const float* gamma; const float* beta;
     float eps, momentum; float* running_mean; float* running_var; long long* num_batches_tracked; float* saved; void* y; int y_cs;
     int relu, groups;
 };
@@ -577,9 +577,9 @@ __device__ __forceinline__ void bn_train_apply_body(const BnApplyArgs& a, int bx
     const long long total = pixels * cv;
     const long long stride = (long long)(gx - 1) * blockDim.x;
     for (long long idx = (bx - 1) * (long long)blockDim.x + threadIdx.x; idx < total; idx += stride) {
-        const long long pix = idx / cv;
+        const long long pix = fast_div(idx, a.cv);
         const int c = (int)(idx - pix * cv) * VEC;
-        const float* stats_g = groups > 1 ? stats + (pix / mg) * 2 * C : stats;
+        const float* stats_g = groups > 1 ? stats + (groups == 2 ? (long long)(pix >= mg) : pix / mg) * 2 * C : stats;
         float f[VEC];
         Elem<T>::unpack(ldg16(x + pix * x_cs + c), f);
 #pragma unroll

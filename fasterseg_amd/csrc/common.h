@@ -180,6 +180,46 @@ template <> struct Elem<bf16_t> {
     }
 };
 
+// An int divisor that carries its magic numbers (round 6).  The element-wise kernels of a train step - BatchNorm passes, weighted sums,
+// resamples - decode every 16-byte vector's (pixel, channel vector) from a linear index; with a `long long` index that was a 64-bit
+// SOFTWARE division (~150 VALU instructions) per 16 bytes moved, three to six of them in the resamples: the "HBM-bound" families ran at
+// 0.5-1.5 TB/s, bound by their index arithmetic.  fast_div(n, d) = n / d by one v_mul_hi + shift for 0 <= n < 2^31 (Granlund-Montgomery
+// round-up form: magic = floor(2^(31 + l) / d) + 1 with l = ceil(log2 d) fits 32 bits and is exact below 2^31), the plain division above.
+// Constructed from an int on the host (the args structs are aggregate-initialised with ints), reads as an int everywhere else.
+struct DivInt {
+    int v;
+    uint32_t magic;
+    int shift;
+    DivInt() = default;
+    __host__ __device__ DivInt(int d) : v(d), magic(0), shift(0) {
+        if (d > 1) {
+            int l = 0;
+            while ((1u << l) < (unsigned)d) ++l;
+            shift = l - 1;
+            magic = (uint32_t)(((1ull << (31 + l)) / (unsigned)d) + 1ull);
+        }
+    }
+    __host__ __device__ operator int() const { return v; }
+};
+__device__ __forceinline__ long long fast_div(long long n, const DivInt& d) {
+    if ((unsigned long long)n < 0x80000000ull) return (long long)(d.v == 1 ? (uint32_t)n : (__umulhi((uint32_t)n, d.magic) >> d.shift));
+    return n / d.v;
+}
+
+// r = t % d; t /= d with a 32-bit division while t fits (kernels whose divisors arrive as plain ints: ~35 instead of ~150 instructions)
+__device__ __forceinline__ int divmod32(long long& t, int d) {
+    if ((unsigned long long)t < 0x100000000ull) {
+        const uint32_t q = (uint32_t)t / (uint32_t)d;
+        const int r = (int)((uint32_t)t - q * (uint32_t)d);
+        t = (long long)q;
+        return r;
+    }
+    const long long q = t / d;
+    const int r = (int)(t - q * d);
+    t = q;
+    return r;
+}
+
 __device__ __forceinline__ u32x4 ldg16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
 __device__ __forceinline__ void stg16(void* p, const u32x4& v) { *reinterpret_cast<u32x4*>(p) = v; }
 

@@ -30,15 +30,15 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, long long o_stri
         long long t = idx;
         float v;
         if (!tflip) {   // out[co][r][s][ci]
-            const int ci = (int)(t % Cin); t /= Cin;
-            const int s = (int)(t % S); t /= S;
-            const int r = (int)(t % R); t /= R;
+            const int ci = divmod32(t, Cin);
+            const int s = divmod32(t, S);
+            const int r = divmod32(t, R);
             const int co = (int)t;
             v = w[co * o_stride + ci * i_stride + r * S + s];
         } else {        // out[ci][R-1-r][S-1-s][co] = w[co][ci][r][s]
-            const int co = (int)(t % Cout); t /= Cout;
-            const int s2 = (int)(t % S); t /= S;
-            const int r2 = (int)(t % R); t /= R;
+            const int co = divmod32(t, Cout);
+            const int s2 = divmod32(t, S);
+            const int r2 = divmod32(t, R);
             const int ci = (int)t;
             v = w[co * o_stride + ci * i_stride + (R - 1 - r2) * S + (S - 1 - s2)];
         }
@@ -52,9 +52,9 @@ __global__ void unpack_wgrad_kernel(const float* __restrict__ dw, int Cout, int 
     for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
         long long t = idx;
-        const int ci = (int)(t % Cin); t /= Cin;
-        const int s = (int)(t % S); t /= S;
-        const int r = (int)(t % R); t /= R;
+        const int ci = divmod32(t, Cin);
+        const int s = divmod32(t, S);
+        const int r = divmod32(t, R);
         const int co = (int)t;
         float* dst = out + co * o_stride + ci * i_stride + r * S + s;
         const float v = dw[idx];
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(int C, int HW, const 
 enum { EW_COPY = 0, EW_AFFINE = 1, EW_AXPY = 2, EW_AXPY_ACC = 3 };
 
 struct EwArgs {
-    long long pixels; int cv; const void* x; int x_cs; void* y; int y_cs; const float* scale; const float* shift; int relu;
+    long long pixels; DivInt cv; const void* x; int x_cs; void* y; int y_cs; const float* scale; const float* shift; int relu;
 };
 
 template <typename T, int OP>
@@ -132,7 +132,7 @@ __device__ __forceinline__ void ew_body(const EwArgs& a, int bx, int gx) {
     float alpha = 1.f;
     if (OP == EW_AXPY || OP == EW_AXPY_ACC) alpha = scale[0];
     for (long long idx = bx * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gx * blockDim.x) {
-        const long long pix = idx / cv;
+        const long long pix = fast_div(idx, a.cv);
         const int c = (int)(idx - pix * cv) * VEC;
         u32x4 v = ldg16(x + pix * x_cs + c);
         if (OP == EW_COPY) {
@@ -196,7 +196,7 @@ template <typename T, int MODE> __global__ __launch_bounds__(256) void chan_redu
 }
 
 struct BnBwdApplyArgs {
-    long long pixels; int cv; const void* x; int x_cs; const void* dy; int dy_cs; const void* yo; int y_cs; const float* mean;
+    long long pixels; DivInt cv; const void* x; int x_cs; const void* dy; int dy_cs; const void* yo; int y_cs; const float* mean;
     const float* invstd; const float* gamma; const float* red; float inv_count; int relu; void* dx; int dx_cs; float* dgamma_acc;
     float* dbeta_acc; int groups, saved_stride; float* red_total;
 };
@@ -246,9 +246,9 @@ __device__ __forceinline__ void bn_bwd_apply_body(const BnBwdApplyArgs& a, int b
     }
     const long long stride = (long long)(gx - 1) * blockDim.x;
     for (long long idx = (bx - 1) * (long long)blockDim.x + threadIdx.x; idx < total; idx += stride) {
-        const long long pix = idx / cv;
+        const long long pix = fast_div(idx, a.cv);
         const int c = (int)(idx - pix * cv) * VEC;
-        const long long grp = groups > 1 ? pix / mg : 0;
+        const long long grp = groups > 1 ? (groups == 2 ? (long long)(pix >= mg) : pix / mg) : 0;
         const float* mean_g = mean + grp * saved_stride;
         const float* invstd_g = invstd + grp * saved_stride;
         const float* red_g = red + grp * 2 * C;
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void dot_kernel(long long pixels, int cv, cons
     float acc = 0.f;
     for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
-        const long long pix = idx / cv;
+        const long long pix = (unsigned long long)idx < 0x100000000ull ? (long long)((uint32_t)idx / (uint32_t)cv) : idx / cv;
         const int c = (int)(idx - pix * cv) * VEC;
         float f[VEC], g[VEC];
         Elem<T>::unpack(ldg16(x + pix * x_cs + c), f);
@@ -371,7 +371,7 @@ struct WsumOperands {
 };
 
 struct WsumArgs {          // t: the output map (wsum) / the incoming gradient (wsum_bwd, wsum_dot); out: the dot products (wsum_dot)
-    long long pixels; int cv; WsumOperands a; const float* coef; void* t; int t_cs; float* out;
+    long long pixels; DivInt cv; WsumOperands a; const float* coef; void* t; int t_cs; float* out;
 };
 
 template <typename T>
@@ -386,7 +386,7 @@ __device__ __forceinline__ void wsum_body(const WsumArgs& q, int bx, int gx) {
 #pragma unroll
     for (int k = 0; k < FS_WSUM_MAX; ++k) w[k] = k < a.n ? coef[k] : 0.f;
     for (long long idx = bx * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gx * blockDim.x) {
-        const long long pix = idx / cv;
+        const long long pix = fast_div(idx, q.cv);
         const int c = (int)(idx - pix * cv) * VEC;
         float acc[VEC];
 #pragma unroll
@@ -416,7 +416,7 @@ __device__ __forceinline__ void wsum_bwd_body(const WsumArgs& q, int bx, int gx)
 #pragma unroll
     for (int k = 0; k < FS_WSUM_MAX; ++k) w[k] = k < a.n ? coef[k] : 0.f;
     for (long long idx = bx * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gx * blockDim.x) {
-        const long long pix = idx / cv;
+        const long long pix = fast_div(idx, q.cv);
         const int c = (int)(idx - pix * cv) * VEC;
         float g[VEC];
         Elem<T>::unpack(ldg16(dy + pix * dy_cs + c), g);
@@ -445,7 +445,7 @@ __device__ __forceinline__ void wsum_dot_body(const WsumArgs& q, int bx, int gx)
 #pragma unroll
     for (int k = 0; k < FS_WSUM_MAX; ++k) acc[k] = 0.f;
     for (long long idx = bx * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gx * blockDim.x) {
-        const long long pix = idx / cv;
+        const long long pix = fast_div(idx, q.cv);
         const int c = (int)(idx - pix * cv) * VEC;
         float g[VEC];
         Elem<T>::unpack(ldg16(dy + pix * dy_cs + c), g);

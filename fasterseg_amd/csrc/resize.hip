@@ -18,7 +18,7 @@ static inline float host_scale(int in, int out) { return out > 1 ? (float)(in - 
 // NHWC resample arguments as a record (the grouped launches of group.h carry up to FS_MAX_GROUP of them by value).  Forward: a = x,
 // out = y; backward: a = dy, b = y_out (ReLU mask), out = dx, a_cs = b_cs = the OUTPUT map's channel stride, out_cs the input map's.
 struct ResizeArgs {
-    int N, Hi, Wi, Ho, Wo, cv; float rh, rw; const void* a; int a_cs; const void* b; int b_cs; void* out; int out_cs; int relu;
+    int N; DivInt Hi, Wi, Ho, Wo, cv; float rh, rw; const void* a; int a_cs; const void* b; int b_cs; void* out; int out_cs; int relu;
 };
 
 template <typename T>
@@ -30,11 +30,11 @@ __device__ __forceinline__ void bilinear_fwd_body(const ResizeArgs& q, int bx, i
     T* __restrict__ y = (T*)q.out;
     const long long total = (long long)N * Ho * Wo * cv;
     for (long long idx = bx * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gx * blockDim.x) {
-        long long t = idx;
-        const int c = (int)(t % cv) * VEC; t /= cv;
-        const int ow = (int)(t % Wo); t /= Wo;
-        const int oh = (int)(t % Ho);
-        const int n = (int)(t / Ho);
+        long long t = idx, u = fast_div(t, q.cv);
+        const int c = (int)(t - u * cv) * VEC; t = u; u = fast_div(t, q.Wo);
+        const int ow = (int)(t - u * Wo); t = u; u = fast_div(t, q.Ho);
+        const int oh = (int)(t - u * Ho);
+        const int n = (int)u;
         const Tap th = make_tap(rh, oh, Hi), tw = make_tap(rw, ow, Wi);
         const T* base = x + (long long)n * Hi * Wi * x_cs + c;
         float p00[VEC], p01[VEC], p10[VEC], p11[VEC];
@@ -89,10 +89,10 @@ __global__ __launch_bounds__(256) void bilinear_fwd_nchw_kernel(int N, int Hi, i
     for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
         long long t = idx;
-        const int ow0 = (int)(t % wq) * 4; t /= wq;
-        const int oh = (int)(t % Ho); t /= Ho;
-        const int c0 = (int)(t % cg) * 4;
-        const int n = (int)(t / cg);
+        const int ow0 = divmod32(t, wq) * 4;
+        const int oh = divmod32(t, Ho);
+        const int c0 = divmod32(t, cg) * 4;
+        const int n = (int)t;
         const Tap th = make_tap(rh, oh, Hi);
         const T* r0 = x + ((long long)n * Hi + th.i0) * Wi * x_cs + c0;
         const T* r1 = x + ((long long)n * Hi + th.i1) * Wi * x_cs + c0;
@@ -123,10 +123,10 @@ __global__ void bilinear_fwd_nchw_scalar_kernel(int N, int Hi, int Wi, int Ho, i
     for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
         long long t = idx;
-        const int ow = (int)(t % Wo); t /= Wo;
-        const int oh = (int)(t % Ho); t /= Ho;
-        const int c = (int)(t % C);
-        const int n = (int)(t / C);
+        const int ow = divmod32(t, Wo);
+        const int oh = divmod32(t, Ho);
+        const int c = divmod32(t, C);
+        const int n = (int)t;
         const Tap th = make_tap(rh, oh, Hi), tw = make_tap(rw, ow, Wi);
         const T* b = x + (long long)n * Hi * Wi * x_cs + c;
         const float p00 = Elem<T>::load(b + ((long long)th.i0 * Wi + tw.i0) * x_cs);
@@ -170,11 +170,11 @@ __device__ __forceinline__ void bilinear_bwd_body(const ResizeArgs& q, int bx, i
     T* __restrict__ dx = (T*)q.out;
     const long long total = (long long)N * Hi * Wi * cv;
     for (long long idx = bx * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gx * blockDim.x) {
-        long long t = idx;
-        const int c = (int)(t % cv) * VEC; t /= cv;
-        const int iw = (int)(t % Wi); t /= Wi;
-        const int ih = (int)(t % Hi);
-        const int n = (int)(t / Hi);
+        long long t = idx, u = fast_div(t, q.cv);
+        const int c = (int)(t - u * cv) * VEC; t = u; u = fast_div(t, q.Wi);
+        const int iw = (int)(t - u * Wi); t = u; u = fast_div(t, q.Hi);
+        const int ih = (int)(t - u * Hi);
+        const int n = (int)u;
         int hlo, hhi, wlo, whi;
         cand_range(rh, ih, Ho, hlo, hhi);
         cand_range(rw, iw, Wo, wlo, whi);
@@ -273,10 +273,10 @@ __global__ void bilinear_bwd_nchw_kernel(int N, int Hi, int Wi, int Ho, int Wo, 
     for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
         long long t = idx;
-        const int iw = (int)(t % Wi); t /= Wi;      // iw fastest: neighbouring lanes read neighbouring dy columns
-        const int ih = (int)(t % Hi); t /= Hi;
-        const int c = (int)(t % C);
-        const int n = (int)(t / C);
+        const int iw = divmod32(t, Wi);      // iw fastest: neighbouring lanes read neighbouring dy columns
+        const int ih = divmod32(t, Hi);
+        const int c = divmod32(t, C);
+        const int n = (int)t;
         int hlo, hhi, wlo, whi;
         cand_range(rh, ih, Ho, hlo, hhi);
         cand_range(rw, iw, Wo, wlo, whi);
@@ -334,10 +334,10 @@ __global__ void bilinear_bwd_nchw_h_kernel(int N, int C, int Hi, int Wi, int Ho,
     for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
         long long t = idx;
-        const int iw = (int)(t % Wi); t /= Wi;
-        const int ih = (int)(t % Hi); t /= Hi;
-        const int c = (int)(t % C);
-        const int n = (int)(t / C);
+        const int iw = divmod32(t, Wi);
+        const int ih = divmod32(t, Hi);
+        const int c = divmod32(t, C);
+        const int n = (int)t;
         int lo, hi;
         cand_range(rh, ih, Ho, lo, hi);
         const float* plane = tmp + ((long long)n * C + c) * Ho * Wi + iw;

@@ -2,8 +2,13 @@ export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 O=$R/gpurun_out; mkdir -p $O
-( time timeout 1500 python bench.py --detail $O/r06_bench_default_detail.json ) > $O/r06_bench_default.json 2> $O/r06_bench_default.err
-tail -4 $O/r06_bench_default.err | cut -c1-300
-wc -c $O/r06_bench_default.json
-python tools/extract_bench.py $O/r06_bench_default.json 2>&1 | head -30
-timeout 2400 python -W ignore -m pytest tests/ -m gpu -q --timeout 900 2>&1 | grep -v "not found in latency" | tail -12 | cut -c1-400 | tee $O/r06_gpu_tests.log
+timeout 1500 python -W ignore -m pytest tests/test_kernels_gpu.py tests/test_bn_group_gpu.py tests/test_ops_gpu.py tests/test_losses_gpu.py tests/test_engine_gpu.py tests/test_program_group_gpu.py tests/test_eval_path.py -m gpu -q -x --timeout 600 2>&1 | tail -6 | cut -c1-400 | tee $O/r06u_tests.txt
+out=$O/r06u_times.txt; : > $out
+t() { echo "=== $WL $DT $*" | tee -a $out; env "$@" timeout 400 python -W ignore tools/step_time.py $WL 15 $DT 2>&1 | grep -a -E "STEP_TIME|Error|error" | tee -a $out; }
+WL=c3; DT=fp32; t FS_X=1
+WL=c3; DT=; t FS_X=1
+WL=c5; DT=fp32; t FS_X=1
+WL=c5; DT=; t FS_X=1
+WL=c4; DT=fp32; t FS_X=1
+WL=c4; DT=; t FS_X=1
+timeout 400 python bench.py --workloads c2 --no-cpu-baseline 2>/dev/null | python tools/extract_bench.py /dev/stdin 2>&1 | head -3 | tee -a $out
