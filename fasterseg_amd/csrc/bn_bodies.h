@@ -576,6 +576,39 @@ __device__ __forceinline__ void bn_train_apply_body(const BnApplyArgs& a, int bx
     }
     const long long total = pixels * cv;
     const long long stride = (long long)(gx - 1) * blockDim.x;
+    // Every block derives the channels' (scale, shift) ONCE into LDS (round 6).  The loop used to finalise the statistics per ELEMENT - two
+    // IEEE divisions, a square root and four scalar loads for each of a vector's 8 values, ~400 instructions per 16 bytes moved: the
+    // normalisation pass was bound by that arithmetic, not by HBM.  (Block 0 publishes the same numbers in `saved`, but the other blocks
+    // cannot wait for it.)  Wider than the table: the per-element form below.
+    constexpr int TABLE = 2048;                       // groups * C entries (a fused pair of 384-channel units in two BatchNorm groups: 1536)
+    __shared__ float s_scale[TABLE], s_shift[TABLE];
+    if (groups * C <= TABLE) {
+        for (int k = threadIdx.x; k < groups * C; k += blockDim.x) {
+            const int g_ = k / C, c = k - g_ * C;
+            const float* st = stats + (long long)g_ * 2 * C;
+            const float m = st[c] / count;
+            const float var = fmaxf(st[C + c] / count - m * m, 0.f);
+            const float sc = (gamma ? gamma[c] : 1.f) * (1.0f / sqrtf(var + eps));
+            s_scale[k] = sc;
+            s_shift[k] = (beta ? beta[c] : 0.f) - m * sc;
+        }
+        __syncthreads();
+        for (long long idx = (bx - 1) * (long long)blockDim.x + threadIdx.x; idx < total; idx += stride) {
+            const long long pix = fast_div(idx, a.cv);
+            const int c = (int)(idx - pix * cv) * VEC;
+            const int k0 = (groups > 1 ? (groups == 2 ? (int)(pix >= mg) : (int)(pix / mg)) * C : 0) + c;
+            float f[VEC];
+            Elem<T>::unpack(ldg16(x + pix * x_cs + c), f);
+            const bool rl = relu_at(relu, c);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                const float o = f[i] * s_scale[k0 + i] + s_shift[k0 + i];
+                f[i] = rl ? fmaxf(o, 0.f) : o;
+            }
+            stg16(y + pix * y_cs + c, Elem<T>::pack(f));
+        }
+        return;
+    }
     for (long long idx = (bx - 1) * (long long)blockDim.x + threadIdx.x; idx < total; idx += stride) {
         const long long pix = fast_div(idx, a.cv);
         const int c = (int)(idx - pix * cv) * VEC;

@@ -94,7 +94,21 @@ struct UnitBwdCall {
     void* dx; int dx_cs, wf_os, wf_ts; void* ws; long long ws_bytes;
 };
 fs_status unit_fwd_group(void* stream, const UnitFwdCall* u, int n);
-fs_status unit_bwd_group(void* stream, const UnitBwdCall* u, int n);
+// Deferred weight gradients (round 6): nothing in a layer call reads a weight gradient, and the operands of one - the unit's saved input
+// and its dz - live until the call returns (the launch programs' arenas never reuse a slot).  The layer executor collects the weight
+// gradients of ALL its scheduler rounds here and issues them at the end, FS_MAX_GROUP problems per launch: a round's five to ten
+// gradients no longer pay a launch of their own (~20 us of launch / block start-up floor each, profiles/r06_wgrad_ablation_in_step.txt).
+struct WgradDeferred {
+    fs_conv_desc d; const void* x; const void* dy; float* dw; long long o_stride, i_stride, t_stride;
+};
+struct WgradSink {
+    static constexpr int CAP = 192;
+    WgradDeferred q[CAP];
+    int n;
+    void* ws; long long ws_bytes;
+};
+fs_status wgrad_sink_flush(void* stream, WgradSink* sink);          // wgrad.hip: issues and empties the sink
+fs_status unit_bwd_group(void* stream, const UnitBwdCall* u, int n, WgradSink* sink = nullptr);
 
 // `relu` argument of the BatchNorm kernels: bit 0 = apply ReLU, bits 8.. = the first channel it applies to (0: every channel);
 // forward kernels: bit 1 = num_batches_tracked points at TWO adjacent counters (the two BatchNorm modules of a fused pair).

@@ -317,7 +317,7 @@ static fs_status run_grouped_ew(int op, int nargs, Args* const* q, int n, void* 
 // n commands of one op that do not depend on each other (a JOIN run, or the same command of several lockstep programs): bare
 // convolutions and strided weight gradients as grouped launches of up to FS_MAX_GROUP problems, anything else one by one
 constexpr int MAX_POOL = 2 * FS_MAX_GROUP;
-static fs_status run_pool(int op, int nargs, Args* pool, int n, void* stream, int index) {
+static fs_status run_pool(int op, int nargs, Args* pool, int n, void* stream, int index, fs::WgradSink* sink = nullptr) {
     fs_status st = FS_OK;
     for (int lo = 0; lo < n && st == FS_OK; lo += FS_MAX_GROUP) {
         const int m = n - lo < FS_MAX_GROUP ? n - lo : FS_MAX_GROUP;
@@ -331,6 +331,11 @@ static fs_status run_pool(int op, int nargs, Args* pool, int n, void* stream, in
                                       &args[i]);
             }
             if (st == FS_OK) st = fs::conv_launch_group(stream, dp, args, m);
+        } else if (sink && op == FS_OP_WGRAD_STRIDED && nargs == 9) {
+            if (sink->n + m > fs::WgradSink::CAP) st = fs::wgrad_sink_flush(stream, sink);
+            for (int i = 0; i < m && st == FS_OK; ++i)
+                sink->q[sink->n++] = fs::WgradDeferred{*(const fs_conv_desc*)q[i].pv[0], q[i].pv[1], q[i].pv[2], (float*)q[i].pv[3], q[i].iv[4], q[i].iv[5], q[i].iv[6]};
+            sink->ws = q[0].pv[7]; sink->ws_bytes = q[0].iv[8];
         } else if (m > 1 && op == FS_OP_WGRAD_STRIDED && nargs == 9) {
             const fs_conv_desc* dp[FS_MAX_GROUP];
             const void* xs[FS_MAX_GROUP];
@@ -428,7 +433,7 @@ static inline void repoint_arrays(Args& dst, int nargs) {
 }
 
 // m <= FS_MAX_GROUP independent commands of one (op, nargs), none of them joined
-static fs_status run_same_op(int op, int nargs, Args* const* q, int m, void* stream, int index) {
+static fs_status run_same_op(int op, int nargs, Args* const* q, int m, void* stream, int index, fs::WgradSink* sink = nullptr) {
     fs_status st = FS_OK;
     if (m > 1 && op == FS_OP_UNIT_FWD && nargs == 16) {
         fs::UnitFwdCall u[FS_MAX_GROUP];
@@ -439,19 +444,19 @@ static fs_status run_same_op(int op, int nargs, Args* const* q, int m, void* str
         }
         return fs::unit_fwd_group(stream, u, m);
     }
-    if (m > 1 && op == FS_OP_UNIT_BWD && nargs == 23) {
+    if ((m > 1 || sink) && op == FS_OP_UNIT_BWD && nargs == 23) {
         fs::UnitBwdCall u[FS_MAX_GROUP];
         for (int i = 0; i < m; ++i) {
             Args& a = *q[i];
             u[i] = fs::UnitBwdCall{(const fs_conv_desc*)P(0), P(1), P(2), P(3), P(4), P(5), I(6), PF(7), PF(8), PF(9), PF(10), PF(11), P(12), PF(13), L(14),
                                    L(15), L(16), P(17), I(18), I(19), I(20), P(21), L(22)};
         }
-        return fs::unit_bwd_group(stream, u, m);
+        return fs::unit_bwd_group(stream, u, m, sink);
     }
-    if (m > 1 && (op == FS_OP_CONV_FWD || op == FS_OP_WGRAD_STRIDED) && nargs == 9) {
+    if ((m > 1 || (sink && op == FS_OP_WGRAD_STRIDED)) && (op == FS_OP_CONV_FWD || op == FS_OP_WGRAD_STRIDED) && nargs == 9) {
         static thread_local Args flat[FS_MAX_GROUP];
         for (int i = 0; i < m; ++i) { flat[i] = *q[i]; repoint_arrays(flat[i], nargs); }
-        return run_pool(op, nargs, flat, m, stream, index);
+        return run_pool(op, nargs, flat, m, stream, index, sink);
     }
     st = m > 1 && fs::group_ew_enabled() ? run_grouped_ew(op, nargs, q, m, stream) : FS_ERR_UNSUPPORTED;
     if (st == FS_ERR_UNSUPPORTED) {          // no grouped form: program after program
@@ -471,6 +476,11 @@ extern "C" fs_status fs_exec_program_group(void* stream, int k, const long long*
     bool have[MAX_LAYER] = {false};
     int op[MAX_LAYER], nargs[MAX_LAYER], join[MAX_LAYER];
     int index = 0;
+    // weight gradients of every round are collected and issued when the call is done (FS_WGRAD_DEFER=0: round by round)
+    static const bool defer = [] { const char* e = getenv("FS_WGRAD_DEFER"); return !(e && e[0] == '0'); }();
+    static thread_local fs::WgradSink sink_store;
+    fs::WgradSink* sink = (defer && !fs::g_deterministic) ? &sink_store : nullptr;
+    if (sink) sink->n = 0;
     for (;;) {
         int best = -1;
         for (int i = 0; i < k; ++i) {
@@ -510,18 +520,19 @@ extern "C" fs_status fs_exec_program_group(void* stream, int k, const long long*
                 }
                 have[i] = false;
             }
-            st = run_pool(op0, nargs0, pool, pooled, stream, index);
+            st = run_pool(op0, nargs0, pool, pooled, stream, index, sink);
         } else {
             for (int lo = 0; lo < n_sel && st == FS_OK; lo += FS_MAX_GROUP) {
                 const int m = n_sel - lo < FS_MAX_GROUP ? n_sel - lo : FS_MAX_GROUP;
                 Args* q[FS_MAX_GROUP];
                 for (int j = 0; j < m; ++j) q[j] = &head[sel[lo + j]];
-                st = run_same_op(op0, nargs0, q, m, stream, index);
+                st = run_same_op(op0, nargs0, q, m, stream, index, sink);
             }
             for (int j = 0; j < n_sel; ++j) have[sel[j]] = false;
         }
         if (st != FS_OK) return st;
         ++index;
     }
+    if (sink) return fs::wgrad_sink_flush(stream, sink);
     return FS_OK;
 }

@@ -314,7 +314,7 @@ fs_status fs::unit_fwd_group(void* stream, const UnitFwdCall* u, int n) {
     return bn_fwd_group(stream, bn, n);          // (statistics pass +) normalisation of all units: one launch per step
 }
 
-fs_status fs::unit_bwd_group(void* stream, const UnitBwdCall* u, int n) {
+fs_status fs::unit_bwd_group(void* stream, const UnitBwdCall* u, int n, WgradSink* sink) {
     FS_REQUIRE(n >= 1 && n <= FS_MAX_GROUP, FS_ERR_INVALID, "unit_bwd_group: %d units", n);
     fs_status s;
     // 1. BatchNorm backward of every unit (dz): one launch per step of the sequence for all units (bn_bwd_group)
@@ -353,7 +353,14 @@ fs_status fs::unit_bwd_group(void* stream, const UnitBwdCall* u, int n) {
             so[m] = q.o_stride; si[m] = q.i_stride; st[m] = q.t_stride;
             ++m;
         }
-        if (m) {
+        if (m && sink) {                 // the layer executor issues them at the end of its call
+            if (sink->n + m > WgradSink::CAP) {
+                s = wgrad_sink_flush(stream, sink);
+                if (s != FS_OK) return s;
+            }
+            for (int i = 0; i < m; ++i) sink->q[sink->n++] = WgradDeferred{w[i], xs[i], dzs[i], dws[i], so[i], si[i], st[i]};
+            sink->ws = u[0].ws; sink->ws_bytes = u[0].ws_bytes;
+        } else if (m) {
             s = wgrad_launch_group(stream, m, wp, xs, dzs, dws, so, si, st, u[0].ws, u[0].ws_bytes);
             if (s != FS_OK) return s;
         }

@@ -467,3 +467,38 @@ fs_status fs::wgrad_launch_group(void* stream, int n, const fs_conv_desc* const*
     else FS_LAUNCH((wgrad_group_kernel<bf16_t>), dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, g);
     return check_launch("fs_conv2d_wgrad (group)");
 }
+
+// the deferred weight gradients of a layer call, largest first (a launch is as long as its longest block), WG_MAX_GROUP per launch
+fs_status fs::wgrad_sink_flush(void* stream, WgradSink* sink) {
+    const int n = sink->n;
+    sink->n = 0;
+    if (n <= 0) return FS_OK;
+    int order[WgradSink::CAP];
+    double work[WgradSink::CAP];
+    for (int i = 0; i < n; ++i) {
+        const fs_conv_desc& d = sink->q[i].d;
+        order[i] = i;
+        work[i] = (double)d.N * d.Ho * d.Wo * d.Cout * d.Cin * d.R * d.S;
+    }
+    for (int i = 1; i < n; ++i) {                    // insertion sort, stable: equal problems keep their program order
+        const int o = order[i];
+        int j = i;
+        while (j > 0 && work[order[j - 1]] < work[o]) { order[j] = order[j - 1]; --j; }
+        order[j] = o;
+    }
+    for (int lo = 0; lo < n; lo += WG_MAX_GROUP) {
+        const int m = n - lo < WG_MAX_GROUP ? n - lo : WG_MAX_GROUP;
+        const fs_conv_desc* dp[WG_MAX_GROUP];
+        const void* xs[WG_MAX_GROUP];
+        const void* dys[WG_MAX_GROUP];
+        float* dws[WG_MAX_GROUP];
+        long long so[WG_MAX_GROUP], si[WG_MAX_GROUP], ts[WG_MAX_GROUP];
+        for (int k = 0; k < m; ++k) {
+            const WgradDeferred& q = sink->q[order[lo + k]];
+            dp[k] = &q.d; xs[k] = q.x; dys[k] = q.dy; dws[k] = q.dw; so[k] = q.o_stride; si[k] = q.i_stride; ts[k] = q.t_stride;
+        }
+        const fs_status st = wgrad_launch_group(stream, m, dp, xs, dys, dws, so, si, ts, sink->ws, sink->ws_bytes);
+        if (st != FS_OK) return st;
+    }
+    return FS_OK;
+}
