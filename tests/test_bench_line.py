@@ -68,16 +68,19 @@ def test_step_traffic_is_null_when_the_pmc_table_predates_the_kernels():
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     fam = bench.STEP_FAMILY_KERNELS["conv_igemm (fwd + dgrad)"]
-    if not os.path.exists(os.path.join(root, "profiles", "r05_c3_pmc.json")):
+    tables = [os.path.join(root, "profiles", "%s_c3_pmc.json" % r) for r in ("r06", "r05")]          # the newest one is what bench.py quotes
+    tables = [t for t in tables if os.path.exists(t)]
+    if not tables:
         import pytest
-        pytest.skip("needs the round-5 PMC table")
-    with open(os.path.join(root, "profiles", "r05_c3_pmc.json")) as f:
+        pytest.skip("needs a committed PMC table")
+    with open(tables[0]) as f:
         table = json.load(f)
     per = lambda k: table[k]["hbm_read_bytes_per_launch"] + table[k]["hbm_write_bytes_per_launch"]
     now = {"conv_igemm2_kernel": {"launches": 1800}, "conv_igemm2_group_kernel": {"launches": 636}, "splitk_reduce_kernel": {"launches": 10}}
     got = bench.step_traffic("c3", fam, now)
-    # the table's per-launch bytes of every kernel, weighted by the launches of the step that asks (not by the PMC run's own mix)
-    want = sum(v["launches"] * per(k) for k, v in now.items()) / sum(v["launches"] for v in now.values())
+    # the table's per-launch bytes of every kernel it knows, weighted by the launches of the step that asks (not by the PMC run's own mix)
+    known = {k: v for k, v in now.items() if k in table}
+    want = sum(v["launches"] * per(k) for k, v in known.items()) / sum(v["launches"] for v in known.values())
     assert abs(got - want) <= 1.0 and got > 1e6
     future = {"conv_igemm3_kernel": {"launches": 2000}, "conv_igemm2_kernel": {"launches": 100}}
     assert bench.step_traffic("c3", fam + ("conv_igemm3_kernel",), future) is None      # mostly kernels the table has never seen: null
