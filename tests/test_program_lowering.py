@@ -316,3 +316,42 @@ def test_conflict_free_chunks_keep_same_key_items_apart_and_in_order():
     three = [(0, "k"), (1, "k"), (2, "k")]
     assert conflict_free_chunks(three, 24, key) == [[(0, "k")], [(1, "k")], [(2, "k")]]
     assert conflict_free_chunks([], 24, key) == []
+
+
+def test_fast_division_magic_numbers_are_exact_below_2_31():
+    """csrc/common.h DivInt / fast_div (element-wise kernels) and the magic pair of csrc/wgrad.hip, restated: n // d by one multiply-high and
+    a shift must be exact for every 0 <= n < 2^31 - checked at the edges of every quotient step around random and extreme dividends."""
+    import random
+    rng = random.Random(7)
+
+    def div_int(d):                                   # DivInt(int d)
+        if d <= 1:
+            return None
+        l = 0
+        while (1 << l) < d:
+            l += 1
+        magic = ((1 << (31 + l)) // d) + 1
+        assert magic < (1 << 32)
+        return magic, l - 1
+
+    def fast_div(n, d, m):
+        return n if m is None else ((n * m[0]) >> 32) >> m[1]         # __umulhi(n, magic) >> shift
+
+    def wgrad_magic(d):                               # wgrad_prepare's lambda: 64-bit product, dividends < 2^32
+        l = 0
+        while (1 << l) < d:
+            l += 1
+        return ((1 << (32 + l)) // d) + 1, 32 + l
+
+    top = (1 << 31) - 1
+    divisors = list(range(1, 130)) + [192, 384, 768, 1000, 4095, 4096, 4097, 65535, 65536, 1 << 20, (1 << 30) + 1, top] + [rng.randrange(2, 1 << 30) for _ in range(200)]
+    for d in divisors:
+        m, (wm, ws) = div_int(d), wgrad_magic(d)
+        probes = {0, 1, d - 1, d, d + 1, top, top - 1, top - d if top > d else 0}
+        for _ in range(40):
+            q = rng.randrange(0, top // d + 1)
+            probes.update(x for x in (q * d - 1, q * d, q * d + d - 1) if 0 <= x <= top)
+            probes.add(rng.randrange(0, top + 1))
+        for n in probes:
+            assert fast_div(n, d, m) == n // d, (n, d)
+            assert (n * wm) >> ws == n // d, (n, d)
