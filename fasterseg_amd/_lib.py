@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfasterseg_hip.so")
 
-EXPECTED_ABI = 210          # FS_ABI_VERSION of include/fasterseg_hip.h these bindings were written against
+EXPECTED_ABI = 211          # FS_ABI_VERSION of include/fasterseg_hip.h these bindings were written against
 FS_F32, FS_BF16 = 0, 1
 FS_CONV_RELU, FS_CONV_TRANSPOSED, FS_CONV_ACCUM, FS_CONV_RELU_TAIL = 1, 2, 4, 8
 
@@ -55,6 +55,9 @@ SIGNATURES = {
     "fs_conv2d_fwd_ws": [c_vp, ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll],
     "fs_conv2d_wgrad": [c_vp, ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp],
     "fs_conv2d_wgrad_strided": [c_vp, ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_ll, c_ll, c_ll],
+    "fs_factorized_reduce_fwd": [c_vp, ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp],
+    "fs_factorized_reduce_wgrad": [c_vp, ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp],
+    "fs_time_op": [c_vp, ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_int, c_int, ctypes.POINTER(ctypes.c_float)],
     "fs_conv2d_wgrad_ws": [c_vp, ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_ll, c_ll, c_ll, c_vp, c_ll],
     "fs_pack_weight_frag": [c_vp, c_vp, c_ll, c_ll, c_int, c_int, c_int, c_vp],
     "fs_conv3x3_s1_fwd": [c_vp, ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],

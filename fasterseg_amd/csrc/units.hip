@@ -402,3 +402,47 @@ fs_status fs::unit_bwd_group(void* stream, const UnitBwdCall* u, int n, WgradSin
     }
     return FS_OK;
 }
+
+// ---- SURVEY section 8b's convenience entry points (ABI 211) ---------------------------------------------------------------------------
+extern "C" fs_status fs_factorized_reduce_fwd(void* stream, const fs_conv_desc* d1, const void* x1, const void* w1_packed, void* y1, float* stats1,
+                                              const fs_conv_desc* d2, const void* x2, const void* w2_packed, void* y2, float* stats2) {
+    FS_REQUIRE(d1 && d2 && d1->dtype == d2->dtype, FS_ERR_INVALID, "fs_factorized_reduce_fwd: two descriptors of one dtype");
+    const fs_conv_desc* dp[2] = {d1, d2};
+    fs::ConvArgs args[2];
+    fs_status s = fs::conv_prepare(d1, x1, w1_packed, nullptr, nullptr, y1, stats1, &args[0]);
+    if (s != FS_OK) return s;
+    s = fs::conv_prepare(d2, x2, w2_packed, nullptr, nullptr, y2, stats2, &args[1]);
+    if (s != FS_OK) return s;
+    return fs::conv_launch_group(stream, dp, args, 2);
+}
+
+extern "C" fs_status fs_factorized_reduce_wgrad(void* stream, const fs_conv_desc* d1, const void* x1, const void* dy1, float* dw1_packed,
+                                                const fs_conv_desc* d2, const void* x2, const void* dy2, float* dw2_packed) {
+    FS_REQUIRE(d1 && d2 && d1->dtype == d2->dtype, FS_ERR_INVALID, "fs_factorized_reduce_wgrad: two descriptors of one dtype");
+    const fs_conv_desc* dp[2] = {d1, d2};
+    const void* xs[2] = {x1, x2};
+    const void* dys[2] = {dy1, dy2};
+    float* dws[2] = {dw1_packed, dw2_packed};
+    const long long zero[2] = {0, 0};
+    return fs::wgrad_launch_group(stream, 2, dp, xs, dys, dws, zero, zero, zero, nullptr, 0);
+}
+
+extern "C" fs_status fs_time_op(void* stream, const fs_conv_desc* d, const void* x, const void* w_packed, void* y, int warmup, int iters,
+                                float* ms_out) {
+    FS_REQUIRE(ms_out && iters > 0 && warmup >= 0, FS_ERR_INVALID, "fs_time_op: iters > 0, warmup >= 0, ms_out != NULL");
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    FS_REQUIRE(hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess, FS_ERR_LAUNCH, "fs_time_op: event creation failed");
+    fs_status s = FS_OK;
+    for (int i = 0; i < warmup && s == FS_OK; ++i) s = fs_conv2d_fwd(stream, d, x, w_packed, nullptr, nullptr, y, nullptr);
+    if (s == FS_OK && hipEventRecord(e0, (hipStream_t)stream) != hipSuccess) s = FS_ERR_LAUNCH;
+    for (int i = 0; i < iters && s == FS_OK; ++i) s = fs_conv2d_fwd(stream, d, x, w_packed, nullptr, nullptr, y, nullptr);
+    float ms = 0.f;
+    if (s == FS_OK && (hipEventRecord(e1, (hipStream_t)stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+                       hipEventElapsedTime(&ms, e0, e1) != hipSuccess))
+        s = FS_ERR_LAUNCH;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (s == FS_OK) *ms_out = ms / (float)iters;
+    else if (s == FS_ERR_LAUNCH) fs::set_error("fs_time_op: HIP event timing failed");
+    return s;
+}

@@ -88,7 +88,7 @@ typedef struct fs_resize_desc {
 const char* fs_last_error(void);
 /* ABI revision of this header; fs_version() returns the one the library was built from.  Bindings check both this and
  * fs_struct_size() when they load the library (fasterseg_amd/_lib.py) - a stale .so must not be used silently. */
-#define FS_ABI_VERSION 210
+#define FS_ABI_VERSION 211
 int fs_version(void);
 /* Bit-reproducible mode (default off; FS_DETERMINISTIC=1 in the environment turns it on at load): every cross-block reduction that
  * otherwise uses float atomics - the pixel slabs of fs_conv2d_wgrad_ws, BatchNorm statistics and parameter gradients of maps above
@@ -139,6 +139,22 @@ fs_status fs_conv2d_fwd(void* stream, const fs_conv_desc* d, const void* x, cons
 fs_status fs_conv2d_fwd_ws(void* stream, const fs_conv_desc* d, const void* x, const void* w_packed,
                            const float* scale, const float* shift, void* y, float* stats, void* workspace,
                            long long workspace_bytes);
+
+/* FactorizedReduce (search/operations.py:505-535: two 1x1 stride-2 convolutions, the second on x[:, :, 1:, 1:], written into the two channel
+ * halves of one map) and, generally, any TWO independent convolutions as ONE grouped launch (ABI 211; SURVEY section 8b's
+ * fs_factorized_reduce_*).  Each (descriptor, x, w, y) as for fs_conv2d_fwd without scale / shift; stats1 / stats2 (nullable) receive
+ * the per-channel sum / sum of squares of the respective output (one BatchNorm over the concatenation: pass &stats[0] and
+ * &stats[Cout1] of a [2][Cout1 + Cout2] buffer laid out by the caller, or two buffers).  The data gradients are the same call on the
+ * flipped packs with FS_CONV_TRANSPOSED; fs_factorized_reduce_wgrad is the pair of weight gradients (packed [Cout][R][S][Cin] fp32
+ * targets, accumulated with atomics like fs_conv2d_wgrad) as one grouped launch.  Both descriptors must have one dtype. */
+fs_status fs_factorized_reduce_fwd(void* stream, const fs_conv_desc* d1, const void* x1, const void* w1_packed, void* y1, float* stats1,
+                                   const fs_conv_desc* d2, const void* x2, const void* w2_packed, void* y2, float* stats2);
+fs_status fs_factorized_reduce_wgrad(void* stream, const fs_conv_desc* d1, const void* x1, const void* dy1, float* dw1_packed,
+                                     const fs_conv_desc* d2, const void* x2, const void* dy2, float* dw2_packed);
+/* Average milliseconds of one fs_conv2d_fwd call of this geometry, timed on `stream` with HIP events over `iters` back-to-back launches
+ * after `warmup` untimed ones (ABI 211; SURVEY section 8b's fs_time_op: what the latency lookup table is made of - fasterseg_amd/latency.py
+ * times whole operators through the same events).  Blocks the calling thread until the last launch has finished. */
+fs_status fs_time_op(void* stream, const fs_conv_desc* d, const void* x, const void* w_packed, void* y, int warmup, int iters, float* ms_out);
 
 /* 3x3 / stride 1 / pad 1 convolution with an LDS-staged input halo tile (conv3x3_halo.hip): same contract as
  * fs_conv2d_fwd (flags: FS_CONV_RELU only) but the filter must be packed in MFMA fragment order by fs_pack_weight_frag

@@ -276,6 +276,56 @@ def test_fp32_on_bf16_matrix_cores_matches_the_fp32_mfma(case, cfg):
         assert e_split <= 4 * e_native + 2e-7, (which, e_native, e_split)          # the split form is as exact as the fp32 MFMA
 
 
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_factorized_reduce_pair_entry_points_and_time_op(dtype):
+    """ABI 211: FactorizedReduce's two 1x1 stride-2 convolutions (search/operations.py:521-526: conv_1(x), conv_2(x[:, :, 1:, 1:])
+    into the two channel halves of one map) and their two weight gradients as ONE grouped launch each, against F.conv2d + autograd; fs_time_op
+    returns a positive per-launch time for a convolution geometry."""
+    import ctypes
+    from fasterseg_amd._lib import call
+    k = K()
+    N, Cin, H, W, half = 2, 64, 12, 16, 48
+    x = q(rnd(N, Cin, H, W, seed=41), dtype).requires_grad_(True)
+    w1 = q(rnd(half, Cin, 1, 1, seed=42, scale=0.2), dtype).requires_grad_(True)
+    w2 = q(rnd(half, Cin, 1, 1, seed=43, scale=0.2), dtype).requires_grad_(True)
+    ref = torch.cat([F.conv2d(x, w1, None, 2, 0), F.conv2d(x[:, :, 1:, 1:], w2, None, 2, 0)], dim=1)
+    dy = q(rnd(*ref.shape, seed=44), dtype)
+    ref.backward(dy)
+    xd = k.to_nhwc(x.detach().cuda(), dtype)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    out = k.empty_nhwc(N, 2 * half, Ho, Wo, dtype, "cuda", zero=True)
+    d1 = k.conv_desc(xd.shape, k.channel_stride(xd), half, 1, 1, 2, 0, 2 * half, dtype, 0, (Ho, Wo))
+    d2 = k.conv_desc(xd.shape, k.channel_stride(xd), half, 1, 1, 2, -1, 2 * half, dtype, 0, (Ho, Wo))
+    p1, p2 = k.pack_weight(w1.detach().cuda(), dtype), k.pack_weight(w2.detach().cuda(), dtype)
+    es = out.element_size()
+    st1 = torch.zeros(2 * half, device="cuda")
+    st2 = torch.zeros(2 * half, device="cuda")
+    call("fs_factorized_reduce_fwd", k._stream(), ctypes.byref(d1), k._p(xd), k._p(p1), out.data_ptr(), k._p(st1),
+         ctypes.byref(d2), k._p(xd), k._p(p2), out.data_ptr() + half * es, k._p(st2))
+    check(out, ref.detach(), dtype, "factorized reduce pair")
+    got = k.to_nchw(out).float()
+    for st, sl in ((st1, slice(0, half)), (st2, slice(half, 2 * half))):
+        want = got[:, sl].sum(dim=(0, 2, 3))
+        assert float((st[:half] - want).abs().max()) <= 2e-2 * float(want.abs().max()) + 1e-3
+    # weight gradients of the pair: dy channel halves against x and the shifted x
+    dyd = k.to_nhwc(dy.cuda(), dtype)
+    g1 = k.conv_desc(xd.shape, k.channel_stride(xd), half, 1, 1, 2, 0, 2 * half, dtype, 0, (Ho, Wo))
+    g2 = k.conv_desc(xd.shape, k.channel_stride(xd), half, 1, 1, 2, -1, 2 * half, dtype, 0, (Ho, Wo))
+    dw1 = torch.zeros(half, 1, 1, Cin, device="cuda")
+    dw2 = torch.zeros(half, 1, 1, Cin, device="cuda")
+    call("fs_factorized_reduce_wgrad", k._stream(), ctypes.byref(g1), k._p(xd), dyd.data_ptr(), k._p(dw1),
+         ctypes.byref(g2), k._p(xd), dyd.data_ptr() + half * es, k._p(dw2))
+    for dw, w in ((dw1, w1), (dw2, w2)):
+        want = w.grad.reshape(half, Cin)
+        tol = (2e-4 if dtype == torch.float32 else 2e-2) * float(want.abs().max()) + 1e-4
+        assert float((dw.reshape(half, Cin).cpu() - want).abs().max()) <= tol
+    ms = ctypes.c_float(0.0)
+    y = k.empty_nhwc(N, half, Ho, Wo, dtype, "cuda")
+    d = k.conv_desc(xd.shape, k.channel_stride(xd), half, 1, 1, 2, 0, half, dtype, 0, (Ho, Wo))
+    call("fs_time_op", k._stream(), ctypes.byref(d), k._p(xd), k._p(p1), k._p(y), 3, 20, ctypes.byref(ms))
+    assert 1e-4 < ms.value < 5.0, ms.value                      # a 1x1 convolution on a 6 x 8 map: microseconds, not zero
+
+
 S2_DGRAD_CASES = [
     # N, Cin, H, W, Cout, k, stride, pad   (forward geometry; dx has the size of x)
     (2, 32, 12, 16, 64, 3, 2, 1),
