@@ -175,8 +175,10 @@ from .layer_exec import run_branches as _run_branches, run_tasks as _run_tasks  
 
 # forward_multi(batch_tails=True): refinement + heads of a pass pair in one evaluation on the batch-concatenated maps; FS_TAIL_BATCH=0: per pass
 _TAIL_BATCH = bool(int(os.environ.get("FS_TAIL_BATCH", "1")))
-# ... and their stem evaluated once (FS_STEM_SHARE=0: once per pass)
-_STEM_SHARE = bool(int(os.environ.get("FS_STEM_SHARE", "1")))
+# ... and, OPT-IN (FS_STEM_SHARE=1), their stem evaluated once: the two passes feed the same images through the same stem weights, so the
+# second evaluation is a common subexpression (outputs, gradients and BatchNorm statistics end up identical, tested) - but the reference
+# does evaluate it per pass, and the benchmarked step does the reference's work: default off (C3 fp32 +1.8 ms without it)
+_STEM_SHARE = bool(int(os.environ.get("FS_STEM_SHARE", "0")))
 
 
 class _DeferredTail:

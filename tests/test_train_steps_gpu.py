@@ -335,15 +335,18 @@ def test_direct_pair_buffers_and_grouped_merges_equal_the_copying_path(use_graph
         assert rel < 2e-2, (k, rel)
 
 
-def _run_joint(pretrain, use_graphs, joint, steps=3, widths=None):
+def _run_joint(pretrain, use_graphs, joint, steps=3, widths=None, stem_share=False):
     """`steps` supernet steps with adjacent passes evaluated together (joint) or one after the other; returns the losses, probe weights and
     BatchNorm running statistics (the state two passes share).  widths: width_mult_list override (one width: every "random" draw of
     the two random passes meets in the same BatchNorms - the conflict path of the layer calls)."""
     from fasterseg_amd import train_step
     cfg = SmallSearch if widths is None else type("Cfg", (SmallSearch,), dict(width_mult_list=widths))
+    from fasterseg_amd import model_search
     saved = train_step._JOINT_PASSES
+    saved_stem = model_search._STEM_SHARE
     try:
         train_step._JOINT_PASSES = joint
+        model_search._STEM_SHARE = bool(stem_share)
         lut = None
         if not pretrain:
             import json
@@ -362,11 +365,12 @@ def _run_joint(pretrain, use_graphs, joint, steps=3, widths=None):
             losses.append((float(out[0]), None if out[1] is None else float(out[1])))
     finally:
         train_step._JOINT_PASSES = saved
+        model_search._STEM_SHARE = saved_stem
     probe = {k: p.detach().float().cpu().clone() for k, p in st.model.named_parameters()
              if k in ("stem.0.0.conv.0.weight", "cells.1.0._op._ops.3.conv1.weight", "cells.2.1.downsample._ops.4.bn2.bn.4.weight",
                       "cells.2.1.downsample._ops.4.bn2.bn.0.weight", "head02.0.conv_1x1.weight")}
     probe["arch_delta"] = torch.cat([(p.detach().cpu() - i).reshape(-1) for p, i in zip(st.arch_params, init)])
-    stats = {k: b.detach().double().cpu().clone() for k, b in st.model.named_buffers() if "cells.2." in k or "cells.3.0" in k or "stem.0.0" in k}
+    stats = {k: b.detach().double().cpu().clone() for k, b in st.model.named_buffers() if "cells.2." in k or "cells.3.0" in k or k.startswith("stem.")}
     return losses, probe, stats
 
 
@@ -400,6 +404,29 @@ def test_joint_passes_equal_sequential_passes(pretrain, use_graphs, widths):
         else:
             rel = float((ref_stats[k] - new_stats[k]).norm() / (ref_stats[k].norm() + 1e-9))
             assert rel < 2e-2, (k, rel)
+
+
+@pytest.mark.parametrize("pretrain,use_graphs", [(True, False), (True, True), (False, True)], ids=["pretrain-eager", "pretrain-graphed", "search-graphed"])
+def test_shared_stem_of_a_pass_pair_equals_per_pass_stems(pretrain, use_graphs):
+    """FS_STEM_SHARE=1 (opt-in): the two passes of a pair feed the same images through the same stem - evaluated once, its BatchNorms given
+    the second pass's momentum update in closed form (r2 = r1 + (1 - m)(r1 - r0), num_batches_tracked += 1), the two passes' gradients of its
+    output added before its one backward.  Losses, weights and the stem's running statistics equal pass-after-pass evaluation."""
+    ref_losses, ref_w, ref_stats = _run_joint(pretrain, use_graphs, False)
+    new_losses, new_w, new_stats = _run_joint(pretrain, use_graphs, True, stem_share=True)
+    for a, b in zip(ref_losses, new_losses):
+        for x, y in zip(a, b):
+            if x is not None:
+                assert abs(x - y) <= 5e-3 * abs(x), (ref_losses, new_losses)
+    ref_w.pop("arch_delta"), new_w.pop("arch_delta")
+    for k in ref_w:
+        assert float((ref_w[k] - new_w[k]).norm() / (ref_w[k].norm() + 1e-12)) < 2e-2, k
+    stem = [k for k in ref_stats if k.startswith("stem.")]
+    assert len(stem) >= 10
+    for k in stem:
+        if k.endswith("num_batches_tracked"):
+            assert torch.equal(ref_stats[k], new_stats[k]), k
+        else:
+            assert float((ref_stats[k] - new_stats[k]).norm() / (ref_stats[k].norm() + 1e-9)) < 2e-2, k
 
 
 @pytest.mark.parametrize("pretrain", [True, False], ids=["pretrain", "search"])
