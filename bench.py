@@ -655,14 +655,15 @@ def run_supernet(args, world, rank, backend, pretrain):
         for k, v in params.items():
             if v.is_floating_point() and not k.endswith(("running_mean", "running_var")):
                 v.requires_grad_(True)
-        xi, ti = imgs[:1].cpu(), target[:1].cpu()
+        # the WHOLE per-GPU batch (one image normalises its BatchNorms over a third / half of the pixels the step does)
+        xi, ti = imgs.cpu(), target.cpu()
 
         def cpu_step():
             if not pretrain:                               # the architecture step's `_loss` on the search batch, then the weight step's
                 ref_supernet.loss(params, cfg, xi, ti, False).backward()
             ref_supernet.loss(params, cfg, xi, ti, pretrain).backward()
-        line["cpu_baseline"] = _time_cpu(cpu_step, 1, args.cpu_seconds,
-                                         "1 image of 3x%dx%d: %s through oracle/ref_supernet (port of search/model_search.py on torch-CPU "
+        line["cpu_baseline"] = _time_cpu(cpu_step, batch, args.cpu_seconds,
+                                         "the step's batch, %d images" % batch + " of 3x%dx%d: %s through oracle/ref_supernet (port of search/model_search.py on torch-CPU "
                                          "kernels, fixture-pinned)" % (H, W, "`_loss(pretrain)` forward+backward" if pretrain else
                                                                        "`_loss` forward+backward of the arch step and of the weight step"),
                                          threads=(16, 32, 8))
