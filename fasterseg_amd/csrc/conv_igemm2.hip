@@ -534,7 +534,24 @@ template <typename T> static void launch2(hipStream_t st, const ConvArgs& a, int
 static int g_igemm2_mode = [] { const char* e = getenv("FS_IGEMM2"); return e ? atoi(e) : 1; }();   // 0: never, 1: heuristic
 static int g_igemm2_slices = [] { const char* e = getenv("FS_IGEMM2_SLICES"); return e ? atoi(e) : 0; }();   // > 0: force a slice count
 
+#ifdef FS_BUILD_PROBES      // measurement build: FS_IGEMM2_GROUP_ABL = 1 (no fragment reads / MFMAs), 2 (no DMA), 3 (no K loop) in the grouped launches
+template <typename T, int ABLV> static void launch2_group_abl(hipStream_t st, const ConvGroupArgs& g, int cfg, int grid) {
+    switch (cfg) {
+        case 0: FS_LAUNCH((conv_igemm2_group_kernel<T, 2, 2, 1, 1, 1, 4, ABLV>), dim3((unsigned)grid), dim3(256), 0, st, g); break;
+        case 4: FS_LAUNCH((conv_igemm2_group_kernel<T, 1, 1, 4, 1, 1, 4, ABLV>), dim3((unsigned)grid), dim3(256), 0, st, g); break;
+        case 5: FS_LAUNCH((conv_igemm2_group_kernel<T, 2, 1, 2, 1, 1, 4, ABLV>), dim3((unsigned)grid), dim3(256), 0, st, g); break;
+        default: FS_LAUNCH((conv_igemm2_group_kernel<T, 1, 2, 2, 1, 1, 4, ABLV>), dim3((unsigned)grid), dim3(256), 0, st, g); break;
+    }
+}
+#endif
+
 template <typename T> static void launch2_group(hipStream_t st, const ConvGroupArgs& g, int cfg, int grid) {
+#ifdef FS_BUILD_PROBES
+    static const int abl = [] { const char* e = getenv("FS_IGEMM2_GROUP_ABL"); return e ? atoi(e) : 0; }();
+    if (abl == 1) return launch2_group_abl<T, 1>(st, g, cfg, grid);
+    if (abl == 2) return launch2_group_abl<T, 2>(st, g, cfg, grid);
+    if (abl == 3) return launch2_group_abl<T, 3>(st, g, cfg, grid);
+#endif
     if (sizeof(T) == 4 && g_fp32x3 && launch2_group_x3(st, g, cfg, grid)) return;
     switch (cfg) {
         case 0: FS_LAUNCH((conv_igemm2_group_kernel<T, 2, 2, 1, 1, 1, 4>), dim3((unsigned)grid), dim3(256), 0, st, g); break;    // 64 x 64
