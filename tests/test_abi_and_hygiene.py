@@ -148,5 +148,9 @@ def test_measurement_scripts_parse_and_probes_are_not_in_the_product_build():
         tails = [re.search(r"Li(\d)ELi(\d)EEEvNS_8ConvArgsE$", l) for l in syms.splitlines() if "conv_igemm2_kernelI" in l]
         assert tails and all(t is not None for t in tails)
         assert {(t.group(1), t.group(2)) for t in tails} <= {("3", "0"), ("4", "0"), ("3", "5"), ("4", "5")}, sorted({(t.group(1), t.group(2)) for t in tails})
+        # ... and the grouped launches carry no ablation instantiation either (FS_IGEMM2_GROUP_ABL lives behind FS_BUILD_PROBES)
+        gtails = [re.search(r"Li(\d)ELi(\d)EEEvNS_13ConvGroupArgsE$", l) for l in syms.splitlines() if "conv_igemm2_group_kernelI" in l]
+        assert gtails and all(t is not None for t in gtails)
+        assert {(t.group(1), t.group(2)) for t in gtails} <= {("4", "0"), ("4", "5")}, sorted({(t.group(1), t.group(2)) for t in gtails})
     tracked = subprocess.run(["git", "ls-files", "tools/probes"], capture_output=True, text=True, cwd=root).stdout.split()
     assert all(f.endswith(".hip") for f in tracked), tracked
